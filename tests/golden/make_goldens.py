@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own numpy code.
+
+Run ONLY in the authoring container (needs /root/reference):
+
+    python tests/golden/make_goldens.py
+
+The reference cannot be imported as-is (``import dolfin`` at
+hippyflow/collectives/collective.py:15; hippylib and mpi4py are absent too), so
+three throw-away stand-in modules are injected into ``sys.modules`` *in this
+process only* -- they provide just enough surface (a numpy-backed ``Vector``,
+``ParameterList``, a few constants, a fake communicator) for ``import
+hippyflow`` to succeed.  Everything that is then executed and recorded is the
+reference's own code, unchanged:
+
+* ``PODProjectorFromData.construct_subspace``  (modeling/PODProjector.py:699-852)
+  for 3 methods x 2 shift modes, plus ``weighted_l2_norm_vector`` (:658-661)
+* ``MeanJTJfromDataOperator.mult``             (modeling/operatorWrappers.py:95-114)
+* ``npToDolfinOperator.mult/transpmult``       (modeling/operatorWrappers.py:42-52)
+* ``JTJ.mult`` / ``JJT.mult`` over a dense J   (modeling/jacobian.py:142-193)
+* ``SummedListOperator.mult``                  (modeling/activeSubspaceProjector.py:69-95)
+* ``CollectiveOperator.mult`` and ``MatrixMultCollectiveOperator.matMvMult``
+  over a fake 4-rank communicator              (collectives/collectiveOperator.py:14-97,
+                                                collectives/collective.py:43-117)
+* ``NullCollective``                           (collectives/collective.py:19-38)
+* ``MassPreconditionedCovarianceOperator.mult``(modeling/KLEProjector.py:47-69)
+* ``PriorPreconditionedProjector.mult``        (modeling/priorPreconditionedProjector.py:19-55)
+* ``LowRankRectangularOperator.mult/transpmult`` (modeling/lowRankRectangularOperator.py:17-66)
+
+Only INPUTS and OUTPUTS are stored (data, not source).  Nothing from the
+reference or from the stand-ins is written into the repository.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# stand-in modules (process-local)
+# --------------------------------------------------------------------------
+class _FakeComm:
+    """Single-process stand-in that emulates P ranks for Allreduce: the 'other
+    ranks' contributions are supplied through ``pending``."""
+
+    def __init__(self, size=1, rank=0):
+        self._size, self._rank = size, rank
+        self.pending = []          # list of per-call lists of other-rank arrays
+
+    def Get_size(self):
+        return self._size
+
+    def Get_rank(self):
+        return self._rank
+
+    rank = property(lambda self: self._rank)
+    size = property(lambda self: self._size)
+
+    def Allreduce(self, send, recv, op=None):
+        others = self.pending.pop(0) if self.pending else []
+        recv[...] = send
+        for o in others:
+            recv[...] += o
+
+    def Bcast(self, v, root=0):
+        return v
+
+
+class _Vector:
+    def __init__(self, other=None):
+        self._a = np.zeros(0)
+        self._comm = _FakeComm()
+        if isinstance(other, _Vector):
+            self._a = other._a.copy()
+
+    def init(self, n):
+        self._a = np.zeros(int(n))
+
+    def get_local(self):
+        return self._a.copy()
+
+    def set_local(self, a):
+        self._a = np.array(a, dtype=np.float64).copy()
+
+    def gather_on_zero(self):
+        return self._a.copy()
+
+    def apply(self, mode=""):
+        pass
+
+    def zero(self):
+        self._a[...] = 0.0
+
+    def axpy(self, alpha, x):
+        self._a += alpha * x._a
+
+    def inner(self, x):
+        return float(self._a @ x._a)
+
+    def norm(self, kind="l2"):
+        return float(np.linalg.norm(self._a))
+
+    def mpi_comm(self):
+        return self._comm
+
+    def __imul__(self, s):
+        self._a *= s
+        return self
+
+
+class _MultiVector:
+    """Column list with the members hippyflow touches (dot_v / reduce / [])."""
+
+    def __init__(self, v, nvec=None):
+        if isinstance(v, _MultiVector):
+            self.cols = [_Vector(c) for c in v.cols]
+        else:
+            self.cols = [_Vector(v) for _ in range(nvec)]
+            for c in self.cols:
+                c.zero()
+
+    def nvec(self):
+        return len(self.cols)
+
+    def __getitem__(self, i):
+        return self.cols[i]
+
+    def zero(self):
+        for c in self.cols:
+            c.zero()
+
+    def dot_v(self, x):
+        return np.array([c.inner(x) for c in self.cols])
+
+    def reduce(self, y, alpha):
+        for a, c in zip(alpha, self.cols):
+            y.axpy(float(a), c)
+
+
+class _ParameterList(dict):
+    def __init__(self, data):
+        super().__init__({k: v[0] for k, v in data.items()})
+
+
+class _Permissive(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        cls = type(name, (), {"__init__": lambda self, *a, **k: None})
+        setattr(self, name, cls)
+        return cls
+
+
+def _install_standins():
+    dl = _Permissive("dolfin")
+    dl.Vector = _Vector
+    hp = _Permissive("hippylib")
+    hp.ParameterList = _ParameterList
+    hp.MultiVector = _MultiVector
+    hp.STATE, hp.PARAMETER, hp.ADJOINT = 0, 1, 2
+    mpi4py = _Permissive("mpi4py")
+    MPI = _Permissive("mpi4py.MPI")
+    MPI.SUM = "sum"
+    MPI.COMM_WORLD = _FakeComm()
+    mpi4py.MPI = MPI
+    sys.modules.update({"dolfin": dl, "hippylib": hp, "mpi4py": mpi4py, "mpi4py.MPI": MPI})
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+def vec(a):
+    v = _Vector()
+    v.set_local(a)
+    return v
+
+
+def mass_matrix_1d(N):
+    """SPD tridiagonal P1 mass matrix on a uniform 1-D mesh (CSR)."""
+    h = 1.0 / (N - 1)
+    main = np.full(N, 4.0 * h / 6.0)
+    main[0] = main[-1] = 2.0 * h / 6.0
+    off = np.full(N - 1, h / 6.0)
+    return sp.diags([off, main, off], [-1, 0, 1], format="csr")
+
+
+def main():
+    _install_standins()
+    sys.path.insert(0, REF)
+    import hippyflow as hf
+    from hippyflow.modeling.PODProjector import weighted_l2_norm_vector
+    from hippyflow.modeling.activeSubspaceProjector import SummedListOperator
+    from hippyflow.modeling.KLEProjector import MassPreconditionedCovarianceOperator
+    from hippyflow.modeling.priorPreconditionedProjector import PriorPreconditionedProjector
+
+    rng = np.random.default_rng(20251002)
+
+    # ---- 1. deterministic POD (3 methods x 2 shifts) on a 64 x 512 miniature ----
+    n, N, r = 64, 512, 12
+    U0, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    W0, _ = np.linalg.qr(rng.standard_normal((N, n)))
+    sig = np.exp(-0.35 * np.arange(n))
+    u_data = (U0 * sig) @ W0.T + 0.3 * np.sin(np.linspace(0, 3, N))[None, :]
+    M = mass_matrix_1d(N)
+    pod = object.__new__(hf.PODProjectorFromData)   # ctor needs dolfin function spaces
+    pod.M_csr = M
+    out = dict(u_data=u_data, M_data=M.data, M_indices=M.indices, M_indptr=M.indptr,
+               N=N, n=n, r=r)
+    for shifted in (True, False):
+        for method in ("hep", "ghep", "inverse_ghep"):
+            d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=shifted,
+                                                         method=method, verify=False)
+            tag = "%s_%d" % (method, int(shifted))
+            out["d_" + tag], out["phi_" + tag] = d, phi
+            out["Mphi_" + tag], out["shift_" + tag] = Mphi, shift
+    out["wl2_in"] = u_data.T[:, :5].copy()
+    out["wl2_out"] = weighted_l2_norm_vector(u_data.T[:, :5], M)
+    np.savez_compressed(os.path.join(OUT, "pod_from_data.npz"), **out)
+
+    # ---- 2. MeanJTJfromDataOperator.mult ----
+    ndata, q, dM = 7, 5, 50
+    J = rng.standard_normal((ndata, q, dM))
+    Gam = rng.standard_normal((q, q))
+    Gam = Gam @ Gam.T + q * np.eye(q)
+
+    class _Prior:
+        class R:
+            @staticmethod
+            def init_vector(x, dim):
+                x.init(dM)
+
+    xs = rng.standard_normal((dM, 4))
+    ys, ys_g = np.zeros((dM, 4)), np.zeros((dM, 4))
+    op = hf.MeanJTJfromDataOperator(J, _Prior())
+    opg = hf.MeanJTJfromDataOperator(J, _Prior(), noise_cov_inv=Gam)
+    for j in range(4):
+        y = vec(np.zeros(dM))
+        op.mult(vec(xs[:, j]), y)
+        ys[:, j] = y.get_local()
+        opg.mult(vec(xs[:, j]), y)
+        ys_g[:, j] = y.get_local()
+    np.savez_compressed(os.path.join(OUT, "mean_jtj.npz"), J=J, Gamma_inv=Gam, x=xs, y=ys, y_gamma=ys_g)
+
+    # ---- 3. dense operator wrapper, JTJ/JJT, SummedListOperator ----
+    A = rng.standard_normal((9, 13))
+    npop = hf.npToDolfinOperator(A)
+    x13, x9 = rng.standard_normal(13), rng.standard_normal(9)
+    y9, y13 = vec(np.zeros(9)), vec(np.zeros(13))
+    npop.mult(vec(x13), y9)
+    npop.transpmult(vec(x9), y13)
+
+    class _DenseJ:                       # a Jacobian with the reference's protocol
+        def __init__(self, A):
+            self.A = A
+
+        def mpi_comm(self):
+            return _FakeComm()
+
+        def init_vector(self, x, dim):
+            x.init(self.A.shape[dim])
+
+        def mult(self, x, y):
+            y.set_local(self.A @ x.get_local())
+
+        def transpmult(self, x, y):
+            y.set_local(self.A.T @ x.get_local())
+
+    Js = [rng.standard_normal((9, 13)) for _ in range(3)]
+    jtj_out, jjt_out = vec(np.zeros(13)), vec(np.zeros(9))
+    hf.JTJ(_DenseJ(Js[0])).mult(vec(x13), jtj_out)
+    hf.JJT(_DenseJ(Js[0])).mult(vec(x9), jjt_out)
+    summed = SummedListOperator([hf.JTJ(_DenseJ(Ji)) for Ji in Js], average=True)
+    ysum = vec(np.zeros(13))
+    summed.mult(vec(x13), ysum)
+    np.savez_compressed(os.path.join(OUT, "operators.npz"), A=A, x13=x13, x9=x9,
+                        np_mult=y9.get_local(), np_transpmult=y13.get_local(),
+                        Js=np.stack(Js), jtj=jtj_out.get_local(), jjt=jjt_out.get_local(),
+                        summed_avg=ysum.get_local())
+
+    # ---- 4. collectives: 4 emulated ranks ----
+    P, Nc, kc = 4, 40, 3
+    parts = rng.standard_normal((P, Nc, kc))
+    res = {}
+    for mpi_op in ("sum", "avg", "Avg"):
+        comm = _FakeComm(size=P, rank=0)
+        coll = hf.MultipleSamePartitioningPDEsCollective(comm)
+        arr = parts[0, :, 0].copy()
+        comm.pending.append([parts[p, :, 0] for p in range(1, P)])
+        res["array_" + mpi_op] = coll.allReduce(arr, mpi_op)
+        comm.pending.append([np.array([float(p)]) for p in range(1, P)])
+        res["scalar_" + mpi_op] = coll.allReduce(0.5, mpi_op)
+
+        class _Local:                        # rank-0 local operator: y = parts[0] column scaled by x[0]
+            def mult(self, x, y):
+                y.set_local(parts[0, :, 0] * x.get_local()[0])
+
+            def init_vector(self, x, dim):
+                x.init(Nc)
+
+        x = vec(np.full(Nc, 2.0))
+        y = vec(np.zeros(Nc))
+        comm.pending.append([parts[p, :, 0] * 2.0 for p in range(1, P)])
+        hf.CollectiveOperator(_Local(), coll, mpi_op=mpi_op).mult(x, y)
+        res["collop_" + mpi_op] = y.get_local()
+
+        class _LocalBlock:
+            def matMvMult(self, X, Y):
+                for j in range(kc):
+                    Y[j].set_local(parts[0, :, j])
+
+            def init_vector(self, x, dim):
+                x.init(Nc)
+
+        X = _MultiVector(vec(np.zeros(Nc)), kc)
+        Y = _MultiVector(vec(np.zeros(Nc)), kc)
+        for j in range(kc):
+            comm.pending.append([parts[p, :, j] for p in range(1, P)])
+        hf.MatrixMultCollectiveOperator(_LocalBlock(), coll, mpi_op=mpi_op).matMvMult(X, Y)
+        res["mmcollop_" + mpi_op] = np.stack([Y[j].get_local() for j in range(kc)], axis=1)
+    nc = hf.NullCollective()
+    res["null_size"], res["null_rank"] = nc.size(), nc.rank()
+    res["null_allreduce"] = nc.allReduce(parts[0, :, 0].copy(), "avg")
+    try:
+        nc.allReduce(1.0, "max")
+        res["null_bad_op_raises"] = 0
+    except NotImplementedError:
+        res["null_bad_op_raises"] = 1
+    try:
+        hf.MultipleSamePartitioningPDEsCollective(_FakeComm(2, 0)).allReduce("a string", "sum")
+        res["mpi_bad_type_raises"] = 0
+    except NotImplementedError:
+        res["mpi_bad_type_raises"] = 1
+    np.savez_compressed(os.path.join(OUT, "collectives.npz"), parts=parts, **res)
+
+    # ---- 5. KLE mass-preconditioned covariance; projector consumers ----
+    Nk = 60
+    Mk = mass_matrix_1d(Nk)
+    Craw = rng.standard_normal((Nk, Nk))
+    Cov = Craw @ Craw.T / Nk + np.eye(Nk)
+
+    class _MatOp:
+        def __init__(self, A):
+            self.A = A
+
+        def mpi_comm(self):
+            return _FakeComm()
+
+        def init_vector(self, x, dim):
+            x.init(self.A.shape[0])
+
+        def mult(self, x, y):
+            y.set_local(self.A @ x.get_local())
+
+    xk = rng.standard_normal(Nk)
+    yk = vec(np.zeros(Nk))
+    MassPreconditionedCovarianceOperator(_MatOp(Cov), _MatOp(Mk)).mult(vec(xk), yk)
+
+    Ublk = _MultiVector(vec(np.zeros(Nk)), 6)
+    Udense = rng.standard_normal((Nk, 6))
+    for j in range(6):
+        Ublk[j].set_local(Udense[:, j])
+    ypp = vec(np.zeros(Nk))
+    PriorPreconditionedProjector(Ublk, _MatOp(Mk), lambda x, dim: x.init(Nk)).mult(vec(xk), ypp)
+
+    Vblk = _MultiVector(vec(np.zeros(13)), 6)
+    Vdense = rng.standard_normal((13, 6))
+    for j in range(6):
+        Vblk[j].set_local(Vdense[:, j])
+    svals = rng.random(6) + 0.1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lrr = hf.LowRankRectangularOperator(Ublk, svals, Vblk)
+    ylr, ylrt = vec(np.zeros(Nk)), vec(np.zeros(13))
+    lrr.mult(vec(x13), ylr)
+    lrr.transpmult(vec(xk), ylrt)
+    np.savez_compressed(os.path.join(OUT, "kle_and_consumers.npz"), Cov=Cov, M_data=Mk.data,
+                        M_indices=Mk.indices, M_indptr=Mk.indptr, x=xk, mcm=yk.get_local(),
+                        U=Udense, prior_precond_proj=ypp.get_local(), V=Vdense, s=svals, x13=x13,
+                        lowrank_mult=ylr.get_local(), lowrank_transpmult=ylrt.get_local())
+
+    # ---- 6. parameter-list defaults (names + default values are API surface) ----
+    def _plain(pl):
+        return {k: (v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)) for k, v in pl.items()}
+
+    import json
+    with open(os.path.join(OUT, "parameter_defaults.json"), "w") as f:
+        json.dump({"ActiveSubspaceParameterList": _plain(hf.ActiveSubspaceParameterList()),
+                   "PODParameterList": _plain(hf.PODParameterList()),
+                   "KLEParameterList": _plain(hf.KLEParameterList())}, f, indent=1, sort_keys=True)
+    print("goldens written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
