@@ -1,0 +1,21 @@
+"""hippyflow_amd -- MI355X-native (gfx950) randomized double-pass eigensolve behind hippyflow's
+model-based projectors (ActiveSubspaceProjector, KLEProjector, PODProjector).
+
+Host code is Python over a C ABI (include/hfmi.h, hippyflow_amd/libhfmi.so: hand-written HIP).
+There is no CPU fallback: importing the package is cheap and GPU-free, but any compute call
+raises if libhfmi.so or a GPU is missing.
+"""
+from ._lib import Context, HfmiError, device_count, load
+from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, MultipleSamePartitioningPDEsCollective,
+                          MultipleSerialPDEsCollective, NullCollective, TorchCollective)
+from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector
+from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator,
+                        LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
+                        MeanJJTfromDataOperator, MeanJTJfromDataOperator, PriorPreconditionedProjector,
+                        SnapshotGramOperator, Solver2Operator, SummedListOperator, as_device_operator, npToDeviceOperator)
+from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, KLEParameterList, KLEProjector,
+                         ParameterList, PODParameterList, PODProjector, PODProjectorFromData, weighted_l2_norm_vector)
+from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
+from .utilities import dense_to_mv_local, mv_to_dense, mv_to_dense_local
+
+__version__ = "0.1.0"

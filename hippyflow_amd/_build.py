@@ -1,0 +1,66 @@
+"""Build libhfmi.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container; the
+resulting .so travels to the GPU box with the repository snapshot."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libhfmi.so")
+SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_misc.hip", "hfmi_small.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need the ROCm toolchain to build libhfmi.so)")
+    return exe
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile every translation unit for gfx950 and link hippyflow_amd/libhfmi.so."""
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, "hfmi_internal.h"), os.path.join(INCLUDE, "hfmi.h")]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or not _newer(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[hfmi build]", " ".join(os.path.relpath(c, ROOT) if os.path.isabs(c) else c for c in cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout)
+        return r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or not _newer(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,187 @@
+"""ctypes binding of libhfmi.so (include/hfmi.h).  No CPU fallback: every compute
+entry point raises if the library or a GPU is missing."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhfmi.so")
+
+LAYOUT_VECTORS = 0
+LAYOUT_DENSE = 1
+QR_CHOL, QR_MGS, QR_AUTO = 0, 1, 2
+
+HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_int)
+POST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class HfmiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libhfmi error %d: %s" % (code, message))
+        self.code = code
+
+
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_D = C.POINTER(C.c_double)
+
+# name -> argtypes; every function returns int status except the two noted below
+SIGNATURES = {
+    "hfmi_device_count": [C.POINTER(C.c_int)],
+    "hfmi_ctx_create": [C.c_int, _PP],
+    "hfmi_ctx_destroy": [_P],
+    "hfmi_ctx_set_stream": [_P, _P],
+    "hfmi_ctx_get_stream": [_P, _PP],
+    "hfmi_ctx_synchronize": [_P],
+    "hfmi_ctx_device_info": [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "hfmi_timer_start": [_P],
+    "hfmi_timer_stop": [_P, _D],
+    "hfmi_block_create": [_P, C.c_int64, C.c_int, _PP],
+    "hfmi_block_wrap": [_P, _P, C.c_int64, C.c_int, C.c_int64, _PP],
+    "hfmi_block_view": [_P, C.c_int, C.c_int, _PP],
+    "hfmi_block_destroy": [_P],
+    "hfmi_block_info": [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64), _PP],
+    "hfmi_block_upload": [_P, _P, C.c_int],
+    "hfmi_block_download": [_P, _P, C.c_int],
+    "hfmi_block_zero": [_P],
+    "hfmi_block_copy": [_P, _P],
+    "hfmi_block_scale": [_P, C.c_double],
+    "hfmi_block_axpy": [_P, C.c_double, _P],
+    "hfmi_block_norms": [_P, _P],
+    "hfmi_randn_fill": [_P, C.c_uint64, C.c_uint32, C.c_double],
+    "hfmi_philox_raw": [_P, C.c_uint64, C.c_uint32, _P],
+    "hfmi_block_dot": [_P, _P, _P],
+    "hfmi_block_gemm_small": [_P, _P, C.c_double, C.c_double, _P],
+    "hfmi_csr_create": [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _PP],
+    "hfmi_csr_destroy": [_P],
+    "hfmi_op_snapshot_gram": [_P, _P, C.c_double, _PP],
+    "hfmi_op_jtj": [_P, _P, C.c_int, C.c_int, _P, C.c_double, _PP],
+    "hfmi_op_jjt": [_P, _P, C.c_int, C.c_int, C.c_double, _PP],
+    "hfmi_op_dense_sym": [_P, _P, _PP],
+    "hfmi_op_csr": [_P, _P, _PP],
+    "hfmi_op_csr_pcg": [_P, _P, C.c_double, C.c_int, _PP],
+    "hfmi_op_compose3": [_P, _P, _P, _P, _PP],
+    "hfmi_op_host_callback": [_P, HOST_APPLY_FN, _P, C.c_int64, _PP],
+    "hfmi_op_set_post_apply": [_P, POST_APPLY_FN, _P],
+    "hfmi_op_apply": [_P, _P, _P, C.c_int],
+    "hfmi_op_destroy": [_P],
+    "hfmi_borth_qr": [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int)],
+    "hfmi_sym_eig_small": [_P, _P, C.c_int, C.c_int, _P, _P],
+    "hfmi_double_pass": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "hfmi_double_pass_g": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "hfmi_bench_tsgemm_tn": [_P, _P, C.c_int, C.c_int, _P, _D],
+    "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
+    "hfmi_bench_peaks": [_P, _D, _D, _D],
+}
+NON_STATUS = {"hfmi_last_error": (C.c_char_p, []), "hfmi_version": (C.c_int, [])}
+
+_lib = None
+
+
+def _preload_hip_runtime():
+    """If PyTorch is installed, bind to ITS HIP runtime so that a later `import torch` (used only for
+    torch.distributed / RCCL plumbing) shares one runtime with libhfmi instead of loading a second copy."""
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load():
+    """Load libhfmi.so (built in-tree by hippyflow_amd._build).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hippyflow_amd has no CPU fallback)" % LIB_PATH)
+    _preload_hip_runtime()
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (res, argtypes) in NON_STATUS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise HfmiError(status, load().hfmi_last_error().decode("utf-8", "replace"))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def device_count():
+    n = C.c_int(0)
+    call("hfmi_device_count", C.byref(n))
+    return n.value
+
+
+def as_f64(a, order="C"):
+    return np.require(a, dtype=np.float64, requirements=["C_CONTIGUOUS" if order == "C" else "F_CONTIGUOUS", "ALIGNED"])
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per GPU (hfmi_ctx).  `Context.default()` gives the process-wide context of
+    cuda:LOCAL_RANK (one process per GPU)."""
+    _default = None
+
+    def __init__(self, device=0):
+        self.handle = C.c_void_p()
+        call("hfmi_ctx_create", int(device), C.byref(self.handle))
+        self.device = int(device)
+
+    @classmethod
+    def default(cls):
+        if cls._default is None:
+            cls._default = cls(int(os.environ.get("LOCAL_RANK", "0")) % max(device_count(), 1))
+        return cls._default
+
+    def synchronize(self):
+        call("hfmi_ctx_synchronize", self.handle)
+
+    def set_stream(self, stream_ptr):
+        call("hfmi_ctx_set_stream", self.handle, C.c_void_p(stream_ptr))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int(0)
+        mem = C.c_int64(0)
+        call("hfmi_ctx_device_info", self.handle, name, 256, C.byref(cus), C.byref(mem))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+    def timer_start(self):
+        call("hfmi_timer_start", self.handle)
+
+    def timer_stop(self):
+        ms = C.c_double(0.0)
+        call("hfmi_timer_stop", self.handle, C.byref(ms))
+        return ms.value
+
+    def bench_peaks(self):
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        call("hfmi_bench_peaks", self.handle, C.byref(a), C.byref(b), C.byref(c))
+        return {"mfma_f64_tflops": a.value, "fma_f64_tflops": b.value, "hbm_copy_gbs": c.value}
+
+    def close(self):
+        if self.handle:
+            load().hfmi_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()

@@ -1,0 +1,1035 @@
+// C ABI of libhfmi.so (include/hfmi.h): object management, operator application, B-orthogonal QR,
+// Rayleigh-Ritz and the fused double-pass solves.  Host-side orchestration only; kernels live in
+// hfmi_gemm.hip / hfmi_misc.hip / hfmi_small.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "hfmi_internal.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void hfmi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* hfmi_last_error(void) { return g_err; }
+extern "C" int hfmi_version(void) { return HFMI_VERSION; }
+
+extern "C" int hfmi_device_count(int* count) {
+  if (!count) HFMI_FAIL(HFMI_ERR_INVALID, "device_count: null argument");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ context
+int ctx_ws(hfmi_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (bytes > ctx->ws_bytes[slot]) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws[slot]) HIP_TRY(hipFree(ctx->ws[slot]));
+    ctx->ws[slot] = nullptr;
+    ctx->ws_bytes[slot] = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&ctx->ws[slot], want));
+    ctx->ws_bytes[slot] = want;
+  }
+  *out = ctx->ws[slot];
+  return HFMI_OK;
+}
+int ctx_pinned(hfmi_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->pinned_bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned) HIP_TRY(hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    HIP_TRY(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_bytes = bytes;
+  }
+  *out = ctx->pinned;
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
+  if (!out) HFMI_FAIL(HFMI_ERR_INVALID, "ctx_create: null out");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    HFMI_FAIL(HFMI_ERR_NO_DEVICE, "no HIP device visible (libhfmi has no CPU path)");
+  }
+  if (device < 0 || device >= n) HFMI_FAIL(HFMI_ERR_INVALID, "ctx_create: device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  hfmi_ctx* c = new (std::nothrow) hfmi_ctx();
+  if (!c) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  c->own_stream = true;
+  for (int i = 0; i < WS_NSLOTS; ++i) {
+    c->ws[i] = nullptr;
+    c->ws_bytes[i] = 0;
+  }
+  c->pinned = nullptr;
+  c->pinned_bytes = 0;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc((void**)&c->small, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(c->small, 0, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double), c->stream));
+  HIP_TRY(hipMalloc((void**)&c->status_dev, sizeof(hfmi_status_words)));
+  HIP_TRY(hipMemsetAsync(c->status_dev, 0, sizeof(hfmi_status_words), c->stream));
+  HIP_TRY(hipHostMalloc((void**)&c->status_host, sizeof(hfmi_status_words), hipHostMallocDefault));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
+  if (!ctx) return HFMI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (hfmi_block* b : ctx->tmp_blocks)
+    if (b) {
+      if (b->owner && b->p) (void)hipFree(b->p);
+      delete b;
+    }
+  for (int i = 0; i < WS_NSLOTS; ++i)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipFree(ctx->small);
+  (void)hipFree(ctx->status_dev);
+  (void)hipHostFree(ctx->status_host);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_ctx_set_stream(hfmi_ctx* ctx, void* hip_stream) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  if (hip_stream != nullptr && ctx->stream == (hipStream_t)hip_stream) return HFMI_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (hip_stream == nullptr) {
+    if (!ctx->own_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+  } else {
+    if (ctx->own_stream) HIP_TRY(hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+  }
+  return HFMI_OK;
+}
+extern "C" int hfmi_ctx_get_stream(hfmi_ctx* ctx, void** hip_stream) {
+  if (!ctx || !hip_stream) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  *hip_stream = (void*)ctx->stream;
+  return HFMI_OK;
+}
+extern "C" int hfmi_ctx_synchronize(hfmi_ctx* ctx) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return HFMI_OK;
+}
+extern "C" int hfmi_ctx_device_info(hfmi_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_len > 0) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return HFMI_OK;
+}
+extern "C" int hfmi_timer_start(hfmi_ctx* ctx) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  return HFMI_OK;
+}
+extern "C" int hfmi_timer_stop(hfmi_ctx* ctx, double* milliseconds) {
+  if (!ctx || !milliseconds) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *milliseconds = ms;
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ blocks
+static int block_alloc(hfmi_ctx* ctx, int64_t N, int nvec, hfmi_block** out) {
+  if (N <= 0 || nvec <= 0) HFMI_FAIL(HFMI_ERR_INVALID, "block: N=%lld nvec=%d must be positive", (long long)N, nvec);
+  hfmi_block* b = new (std::nothrow) hfmi_block();
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  b->ctx = ctx;
+  b->N = N;
+  b->nvec = nvec;
+  b->ld = round_up(N, 32);
+  b->owner = true;
+  b->p = nullptr;
+  hipError_t e = hipMalloc((void**)&b->p, (size_t)b->ld * nvec * sizeof(double));
+  if (e != hipSuccess) {
+    delete b;
+    HFMI_FAIL(HFMI_ERR_HIP, "hipMalloc of a %lld x %d block (%.2f GB) failed: %s", (long long)N, nvec,
+              (double)b->ld * nvec * 8 / 1e9, hipGetErrorString(e));
+  }
+  *out = b;
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_create(hfmi_ctx* ctx, int64_t N, int nvec, hfmi_block** out) {
+  if (!ctx || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hfmi_block* b = nullptr;
+  HFMI_TRY(block_alloc(ctx, N, nvec, &b));
+  hipError_t e = hipMemsetAsync(b->p, 0, (size_t)b->ld * nvec * sizeof(double), ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(b->p);
+    delete b;
+    HFMI_FAIL(HFMI_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+  }
+  *out = b;
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_wrap(hfmi_ctx* ctx, double* dptr, int64_t N, int nvec, int64_t ld, hfmi_block** out) {
+  if (!ctx || !out || !dptr) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (N <= 0 || nvec <= 0) HFMI_FAIL(HFMI_ERR_INVALID, "block_wrap: N and nvec must be positive");
+  if (ld % 32 != 0 || ld < N) HFMI_FAIL(HFMI_ERR_INVALID, "block_wrap: ld=%lld must be a multiple of 32 and >= N", (long long)ld);
+  if (((uintptr_t)dptr) % 128 != 0) HFMI_FAIL(HFMI_ERR_INVALID, "block_wrap: pointer must be 128-byte aligned");
+  hfmi_block* b = new (std::nothrow) hfmi_block();
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  b->ctx = ctx;
+  b->p = dptr;
+  b->N = N;
+  b->nvec = nvec;
+  b->ld = ld;
+  b->owner = false;
+  int s = launch_zero_pad(ctx, dptr, N, nvec, ld);
+  if (s != HFMI_OK) {
+    delete b;
+    return s;
+  }
+  *out = b;
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_view(hfmi_block* parent, int first, int count, hfmi_block** out) {
+  if (!parent || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (first < 0 || count <= 0 || first + count > parent->nvec)
+    HFMI_FAIL(HFMI_ERR_INVALID, "block_view: [%d,%d) outside [0,%d)", first, first + count, parent->nvec);
+  hfmi_block* b = new (std::nothrow) hfmi_block(*parent);
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  b->p = parent->p + (int64_t)first * parent->ld;
+  b->nvec = count;
+  b->owner = false;
+  *out = b;
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_destroy(hfmi_block* b) {
+  if (!b) return HFMI_OK;
+  if (b->owner && b->p) {
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->p);
+  }
+  delete b;
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_info(const hfmi_block* b, int64_t* N, int* nvec, int64_t* ld, double** dptr) {
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
+  if (N) *N = b->N;
+  if (nvec) *nvec = b->nvec;
+  if (ld) *ld = b->ld;
+  if (dptr) *dptr = b->p;
+  return HFMI_OK;
+}
+
+int ctx_tmp_block(hfmi_ctx* ctx, int idx, int64_t N, int nvec, hfmi_block** out) {
+  if ((int)ctx->tmp_blocks.size() <= idx) ctx->tmp_blocks.resize(idx + 1, nullptr);
+  hfmi_block* b = ctx->tmp_blocks[idx];
+  if (b && (b->N != N || b->nvec < nvec)) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(b->p);
+    delete b;
+    b = nullptr;
+    ctx->tmp_blocks[idx] = nullptr;
+  }
+  if (!b) {
+    HFMI_TRY(block_alloc(ctx, N, nvec, &b));
+    HIP_TRY(hipMemsetAsync(b->p, 0, (size_t)b->ld * nvec * sizeof(double), ctx->stream));
+    ctx->tmp_blocks[idx] = b;
+  }
+  *out = b;
+  return HFMI_OK;
+}
+
+static int check_same_shape(const hfmi_block* a, const hfmi_block* b, const char* what) {
+  if (!a || !b) HFMI_FAIL(HFMI_ERR_INVALID, "%s: null block", what);
+  if (a->N != b->N || a->nvec != b->nvec)
+    HFMI_FAIL(HFMI_ERR_INVALID, "%s: x and y have non-matching shapes (%lld x %d vs %lld x %d)", what, (long long)a->N,
+              a->nvec, (long long)b->N, b->nvec);
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_block_upload(hfmi_block* b, const double* host, int layout) {
+  if (!b || !host) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = b->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (layout == HFMI_LAYOUT_VECTORS) {
+    HIP_TRY(hipMemcpy2DAsync(b->p, (size_t)b->ld * sizeof(double), host, (size_t)b->N * sizeof(double),
+                             (size_t)b->N * sizeof(double), (size_t)b->nvec, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  } else if (layout == HFMI_LAYOUT_DENSE) {
+    // stage in slabs of rows so that the staging buffer stays bounded
+    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)b->nvec * 8));
+    void* stage = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_STAGE, (size_t)std::min<int64_t>(rows_per, b->N) * b->nvec * sizeof(double), &stage));
+    for (int64_t t0 = 0; t0 < b->N; t0 += rows_per) {
+      const int64_t rows = std::min<int64_t>(rows_per, b->N - t0);
+      HIP_TRY(hipMemcpyAsync(stage, host + t0 * b->nvec, (size_t)rows * b->nvec * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+      HFMI_TRY(launch_dense_to_block(ctx, (const double*)stage, b->p + t0, b->ld, rows, b->nvec));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+  } else {
+    HFMI_FAIL(HFMI_ERR_INVALID, "block_upload: unknown layout %d", layout);
+  }
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_download(const hfmi_block* b, double* host, int layout) {
+  if (!b || !host) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = b->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (layout == HFMI_LAYOUT_VECTORS) {
+    HIP_TRY(hipMemcpy2DAsync(host, (size_t)b->N * sizeof(double), b->p, (size_t)b->ld * sizeof(double),
+                             (size_t)b->N * sizeof(double), (size_t)b->nvec, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  } else if (layout == HFMI_LAYOUT_DENSE) {
+    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)b->nvec * 8));
+    void* stage = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_STAGE, (size_t)std::min<int64_t>(rows_per, b->N) * b->nvec * sizeof(double), &stage));
+    for (int64_t t0 = 0; t0 < b->N; t0 += rows_per) {
+      const int64_t rows = std::min<int64_t>(rows_per, b->N - t0);
+      HFMI_TRY(launch_block_to_dense(ctx, b->p + t0, b->ld, (double*)stage, rows, b->nvec));
+      HIP_TRY(hipMemcpyAsync(host + t0 * b->nvec, stage, (size_t)rows * b->nvec * sizeof(double), hipMemcpyDeviceToHost,
+                             ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+  } else {
+    HFMI_FAIL(HFMI_ERR_INVALID, "block_download: unknown layout %d", layout);
+  }
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_zero(hfmi_block* b) {
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
+  return launch_fill(b->ctx, b->p, b->N, b->nvec, b->ld, 0.0, true);
+}
+extern "C" int hfmi_block_copy(hfmi_block* dst, const hfmi_block* src) {
+  HFMI_TRY(check_same_shape(dst, src, "block_copy"));
+  return launch_copy(dst->ctx, dst->p, dst->ld, src->p, src->ld, src->N, src->nvec);
+}
+extern "C" int hfmi_block_scale(hfmi_block* b, double alpha) {
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
+  return launch_scale(b->ctx, b->p, b->ld, b->N, b->nvec, alpha);
+}
+extern "C" int hfmi_block_axpy(hfmi_block* y, double alpha, const hfmi_block* x) {
+  HFMI_TRY(check_same_shape(y, x, "block_axpy"));
+  return launch_axpy(y->ctx, y->p, y->ld, alpha, x->p, x->ld, x->N, x->nvec);
+}
+
+// read `count` doubles of device memory back to the host (synchronises the stream)
+static int read_back(hfmi_ctx* ctx, const double* dev, size_t count, double* host) {
+  void* pin = nullptr;
+  HFMI_TRY(ctx_pinned(ctx, count * sizeof(double), &pin));
+  HIP_TRY(hipMemcpyAsync(pin, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  memcpy(host, pin, count * sizeof(double));
+  return HFMI_OK;
+}
+static int read_status(hfmi_ctx* ctx, hfmi_status_words* out) {
+  HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *out = *ctx->status_host;
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_block_norms(const hfmi_block* b, double* host_norms) {
+  if (!b || !host_norms) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = b->ctx;
+  void* out = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)b->nvec * sizeof(double), &out));
+  HFMI_TRY(launch_col_dots(ctx, b->p, b->ld, b->p, b->ld, b->N, b->nvec, (double*)out));
+  HFMI_TRY(read_back(ctx, (const double*)out, b->nvec, host_norms));
+  for (int j = 0; j < b->nvec; ++j) host_norms[j] = sqrt(host_norms[j]);
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_randn_fill(hfmi_block* b, uint64_t seed, uint32_t stream, double sigma) {
+  if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
+  return launch_randn(b->ctx, b->p, b->N, b->nvec, b->ld, seed, stream, sigma);
+}
+extern "C" int hfmi_philox_raw(hfmi_block* shape_of, uint64_t seed, uint32_t stream, uint32_t* host_out) {
+  if (!shape_of || !host_out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = shape_of->ctx;
+  const size_t words = (size_t)shape_of->nvec * ((shape_of->N + 1) / 2) * 4;
+  void* dev = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, words * sizeof(uint32_t), &dev));
+  HFMI_TRY(launch_philox_raw(ctx, (uint32_t*)dev, shape_of->N, shape_of->nvec, seed, stream));
+  HIP_TRY(hipMemcpyAsync(host_out, dev, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_block_dot(const hfmi_block* A, const hfmi_block* B, double* host_out) {
+  if (!A || !B || !host_out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (A->N != B->N) HFMI_FAIL(HFMI_ERR_INVALID, "block_dot: vector lengths differ (%lld vs %lld)", (long long)A->N, (long long)B->N);
+  hfmi_ctx* ctx = A->ctx;
+  void* out = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)A->nvec * B->nvec * sizeof(double), &out));
+  HFMI_TRY(launch_tsgemm_tn(ctx, A->p, A->ld, A->nvec, B->p, B->ld, B->nvec, A->N, 1.0, 0.0, (double*)out, B->nvec, 1, 0));
+  return read_back(ctx, (const double*)out, (size_t)A->nvec * B->nvec, host_out);
+}
+
+// upload a host row-major (rows x cols) matrix into a device buffer with leading dimension ld (zero padded)
+static int upload_small(hfmi_ctx* ctx, const double* host, int rows, int cols, double* dev, int ld) {
+  void* pin = nullptr;
+  HFMI_TRY(ctx_pinned(ctx, (size_t)rows * ld * sizeof(double), &pin));
+  double* p = (double*)pin;
+  for (int i = 0; i < rows; ++i) {
+    memcpy(p + (size_t)i * ld, host + (size_t)i * cols, (size_t)cols * sizeof(double));
+    for (int j = cols; j < ld; ++j) p[(size_t)i * ld + j] = 0.0;
+  }
+  HIP_TRY(hipMemcpyAsync(dev, pin, (size_t)rows * ld * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // the pinned buffer is reused
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_block_gemm_small(const hfmi_block* A, const double* host_S, double alpha, double beta, hfmi_block* Y) {
+  if (!A || !host_S || !Y) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (A->N != Y->N) HFMI_FAIL(HFMI_ERR_INVALID, "block_gemm_small: vector lengths differ");
+  hfmi_ctx* ctx = A->ctx;
+  const int m = A->nvec, r = Y->nvec;
+  const int ld = (int)round_up(r, 16);
+  void* S = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)m * ld * sizeof(double), &S));
+  HFMI_TRY(upload_small(ctx, host_S, m, r, (double*)S, ld));
+  return launch_tsgemm_nn(ctx, A->p, A->ld, m, (const double*)S, ld, r, alpha, beta, Y->p, Y->ld, A->N);
+}
+
+// ------------------------------------------------------------------ CSR
+extern "C" int hfmi_csr_create(hfmi_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr,
+                               const int32_t* indices, const double* data, hfmi_csr** out) {
+  if (!ctx || !indptr || !indices || !data || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (nrows <= 0 || ncols <= 0 || nnz < 0 || indptr[0] != 0 || indptr[nrows] != nnz)
+    HFMI_FAIL(HFMI_ERR_INVALID, "csr_create: inconsistent CSR arrays");
+  for (int64_t z = 0; z < nnz; ++z)
+    if (indices[z] < 0 || indices[z] >= ncols) HFMI_FAIL(HFMI_ERR_INVALID, "csr_create: column index out of range");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hfmi_csr* m = new (std::nothrow) hfmi_csr();
+  if (!m) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  m->ctx = ctx;
+  m->nrows = nrows;
+  m->ncols = ncols;
+  m->nnz = nnz;
+  m->inv_diag = nullptr;
+  HIP_TRY(hipMalloc((void**)&m->indptr, (size_t)(nrows + 1) * sizeof(int64_t)));
+  HIP_TRY(hipMalloc((void**)&m->indices, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&m->data, (size_t)std::max<int64_t>(nnz, 1) * sizeof(double)));
+  HIP_TRY(hipMemcpy(m->indptr, indptr, (size_t)(nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->indices, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->data, data, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  *out = m;
+  return HFMI_OK;
+}
+extern "C" int hfmi_csr_destroy(hfmi_csr* m) {
+  if (!m) return HFMI_OK;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  (void)hipFree(m->indptr);
+  (void)hipFree(m->indices);
+  (void)hipFree(m->data);
+  if (m->inv_diag) (void)hipFree(m->inv_diag);
+  delete m;
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ operators
+static hfmi_op* op_new(hfmi_ctx* ctx, hfmi_op_kind kind) {
+  hfmi_op* op = new (std::nothrow) hfmi_op();
+  if (!op) return nullptr;
+  memset((void*)op, 0, sizeof(*op));
+  op->ctx = ctx;
+  op->kind = kind;
+  op->scale = 1.0;
+  return op;
+}
+extern "C" int hfmi_op_snapshot_gram(hfmi_ctx* ctx, const hfmi_block* X, double scale, hfmi_op** out) {
+  if (!ctx || !X || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_op* op = op_new(ctx, OP_SNAPSHOT_GRAM);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->X = *X;
+  op->X.owner = false;
+  op->scale = scale;
+  *out = op;
+  return HFMI_OK;
+}
+static int op_jac(hfmi_ctx* ctx, hfmi_op_kind kind, const hfmi_block* J, int ndata, int q, const double* host_gamma_inv,
+                  double scale, hfmi_op** out) {
+  if (!ctx || !J || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (ndata <= 0 || q <= 0 || (int64_t)ndata * q != J->nvec)
+    HFMI_FAIL(HFMI_ERR_INVALID, "jacobian operator: ndata*q = %lld must equal the number of stored rows %d",
+              (long long)ndata * q, J->nvec);
+  hfmi_op* op = op_new(ctx, kind);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->X = *J;
+  op->X.owner = false;
+  op->ndata = ndata;
+  op->q = q;
+  op->scale = scale;
+  if (host_gamma_inv) {
+    const int ld = (int)round_up(q, 16);
+    HIP_TRY(hipMalloc((void**)&op->gamma_inv, (size_t)q * ld * sizeof(double)));
+    int s = upload_small(ctx, host_gamma_inv, q, q, op->gamma_inv, ld);
+    if (s != HFMI_OK) return s;
+  }
+  *out = op;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_jtj(hfmi_ctx* ctx, const hfmi_block* J, int ndata, int q, const double* host_gamma_inv,
+                           double scale, hfmi_op** out) {
+  return op_jac(ctx, OP_JTJ, J, ndata, q, host_gamma_inv, scale, out);
+}
+extern "C" int hfmi_op_jjt(hfmi_ctx* ctx, const hfmi_block* J, int ndata, int q, double scale, hfmi_op** out) {
+  return op_jac(ctx, OP_JJT, J, ndata, q, nullptr, scale, out);
+}
+extern "C" int hfmi_op_dense_sym(hfmi_ctx* ctx, const hfmi_block* C, hfmi_op** out) {
+  if (!ctx || !C || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (C->N != C->nvec) HFMI_FAIL(HFMI_ERR_INVALID, "dense_sym: matrix must be square (%lld x %d)", (long long)C->N, C->nvec);
+  hfmi_op* op = op_new(ctx, OP_DENSE_SYM);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->X = *C;
+  op->X.owner = false;
+  *out = op;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_csr(hfmi_ctx* ctx, const hfmi_csr* M, hfmi_op** out) {
+  if (!ctx || !M || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_op* op = op_new(ctx, OP_CSR);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->csr = M;
+  *out = op;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_csr_pcg(hfmi_ctx* ctx, const hfmi_csr* M, double rel_tol, int max_iter, hfmi_op** out) {
+  if (!ctx || !M || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (M->nrows != M->ncols) HFMI_FAIL(HFMI_ERR_INVALID, "csr_pcg: matrix must be square");
+  hfmi_op* op = op_new(ctx, OP_CSR_PCG);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->csr = M;
+  op->rel_tol = rel_tol > 0 ? rel_tol : 1e-13;
+  op->max_iter = max_iter > 0 ? max_iter : 500;
+  *out = op;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_compose3(hfmi_ctx* ctx, hfmi_op* a, hfmi_op* b, hfmi_op* c, hfmi_op** out) {
+  if (!ctx || !a || !b || !c || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_op* op = op_new(ctx, OP_COMPOSE3);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->a = a;
+  op->b = b;
+  op->c = c;
+  *out = op;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_host_callback(hfmi_ctx* ctx, hfmi_host_apply_fn fn, void* user, int64_t N, hfmi_op** out) {
+  if (!ctx || !fn || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_op* op = op_new(ctx, OP_HOST);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->host_fn = fn;
+  op->host_user = user;
+  op->host_N = N;
+  *out = op;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_set_post_apply(hfmi_op* op, hfmi_post_apply_fn fn, void* user) {
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "null op");
+  op->post_fn = fn;
+  op->post_user = user;
+  return HFMI_OK;
+}
+extern "C" int hfmi_op_destroy(hfmi_op* op) {
+  if (!op) return HFMI_OK;
+  if (op->gamma_inv) {
+    (void)hipStreamSynchronize(op->ctx->stream);
+    (void)hipFree(op->gamma_inv);
+  }
+  delete op;
+  return HFMI_OK;
+}
+
+// Y = M^{-1} W for an SPD CSR matrix: Jacobi-preconditioned CG run on all vectors at once (independent
+// recurrences, shared SpMM); per-vector scalars stay on the device, the host only polls convergence.
+static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
+  hfmi_ctx* ctx = op->ctx;
+  hfmi_csr* M = const_cast<hfmi_csr*>(op->csr);
+  const int64_t N = W->N;
+  const int k = W->nvec;
+  if (M->nrows != N) HFMI_FAIL(HFMI_ERR_INVALID, "csr_pcg: matrix has %lld rows, block vectors have %lld", (long long)M->nrows, (long long)N);
+  if (!M->inv_diag) {
+    HIP_TRY(hipMalloc((void**)&M->inv_diag, (size_t)N * sizeof(double)));
+    HFMI_TRY(launch_csr_diag_inv(ctx, M));
+  }
+  hfmi_block *R, *Z, *P, *AP;
+  HFMI_TRY(ctx_tmp_block(ctx, 8, N, k, &R));
+  HFMI_TRY(ctx_tmp_block(ctx, 9, N, k, &Z));
+  HFMI_TRY(ctx_tmp_block(ctx, 10, N, k, &P));
+  HFMI_TRY(ctx_tmp_block(ctx, 11, N, k, &AP));
+  void* sc = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)5 * k * sizeof(double), &sc));
+  double* rz = (double*)sc;       // r.z
+  double* rz_new = rz + k;
+  double* pap = rz + 2 * k;
+  double* rr = rz + 3 * k;
+  double* bb = rz + 4 * k;
+  std::vector<double> h_rr(k), h_bb(k);
+  // x0 = 0, r = b
+  HFMI_TRY(launch_fill(ctx, Y->p, N, k, Y->ld, 0.0, false));
+  HFMI_TRY(launch_copy(ctx, R->p, R->ld, W->p, W->ld, N, k));
+  HFMI_TRY(launch_col_dots(ctx, W->p, W->ld, W->p, W->ld, N, k, bb));
+  HFMI_TRY(read_back(ctx, bb, k, h_bb.data()));
+  HFMI_TRY(launch_diag_scale(ctx, Z->p, Z->ld, R->p, R->ld, M->inv_diag, N, k));
+  HFMI_TRY(launch_copy(ctx, P->p, P->ld, Z->p, Z->ld, N, k));
+  HFMI_TRY(launch_col_dots(ctx, R->p, R->ld, Z->p, Z->ld, N, k, rz));
+  int it = 0;
+  bool done = false;
+  for (; it < op->max_iter && !done; ++it) {
+    HFMI_TRY(launch_csr_spmm(ctx, M, P->p, P->ld, AP->p, AP->ld, k, false));
+    HFMI_TRY(launch_col_dots(ctx, P->p, P->ld, AP->p, AP->ld, N, k, pap));
+    HFMI_TRY(launch_col_axpy_dev(ctx, Y->p, Y->ld, P->p, P->ld, N, k, rz, pap, 1.0));
+    HFMI_TRY(launch_col_axpy_dev(ctx, R->p, R->ld, AP->p, AP->ld, N, k, rz, pap, -1.0));
+    HFMI_TRY(launch_diag_scale(ctx, Z->p, Z->ld, R->p, R->ld, M->inv_diag, N, k));
+    HFMI_TRY(launch_col_dots(ctx, R->p, R->ld, Z->p, Z->ld, N, k, rz_new));
+    HFMI_TRY(launch_col_xpby_dev(ctx, P->p, P->ld, Z->p, Z->ld, N, k, rz_new, rz));
+    HIP_TRY(hipMemcpyAsync(rz, rz_new, (size_t)k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if ((it & 3) == 3 || it + 1 == op->max_iter) {
+      HFMI_TRY(launch_col_dots(ctx, R->p, R->ld, R->p, R->ld, N, k, rr));
+      HFMI_TRY(read_back(ctx, rr, k, h_rr.data()));
+      done = true;
+      for (int j = 0; j < k; ++j)
+        if (h_rr[j] > op->rel_tol * op->rel_tol * h_bb[j]) done = false;
+    }
+  }
+  op->last_iters = it;
+  if (!done) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "csr_pcg: no convergence to %.1e in %d iterations", op->rel_tol, op->max_iter);
+  return HFMI_OK;
+}
+
+static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double beta);
+
+static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double beta) {
+  hfmi_ctx* ctx = op->ctx;
+  const int k = W->nvec;
+  switch (op->kind) {
+    case OP_SNAPSHOT_GRAM:
+    case OP_JTJ: {
+      const hfmi_block& X = op->X;
+      if (X.N != W->N) HFMI_FAIL(HFMI_ERR_INVALID, "operator acts on vectors of length %lld, got %lld", (long long)X.N, (long long)W->N);
+      const int m = X.nvec;
+      const int ldg = (int)round_up(k, 16);
+      void* G = nullptr;
+      HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)m * ldg * sizeof(double), &G));
+      // G (m x k) = scale * X^T W ; then Y = X G
+      HFMI_TRY(launch_tsgemm_tn(ctx, X.p, X.ld, m, W->p, W->ld, k, X.N, op->scale, 0.0, (double*)G, ldg, 1, 0));
+      if (op->kind == OP_JTJ && op->gamma_inv)
+        HFMI_TRY(launch_gamma_apply(ctx, (double*)G, ldg, op->ndata, op->q, k, op->gamma_inv, (int)round_up(op->q, 16)));
+      HFMI_TRY(launch_tsgemm_nn(ctx, X.p, X.ld, m, (const double*)G, ldg, k, 1.0, beta, Y->p, Y->ld, X.N));
+      return HFMI_OK;
+    }
+    case OP_JJT: {
+      // Y (q x k) = scale * sum_i J_i (J_i^T W): per sample  H_i (N x k) = J_i^T-as-block * W ; Y += J_i^T H_i
+      const hfmi_block& J = op->X;
+      const int q = op->q;
+      if (W->N != q) HFMI_FAIL(HFMI_ERR_INVALID, "JJT acts on vectors of length %d, got %lld", q, (long long)W->N);
+      hfmi_block* H = nullptr;
+      HFMI_TRY(ctx_tmp_block(ctx, 12, J.N, k, &H));
+      // W as a small row-major (q x k) matrix: W block is column-major q x k with ld -> transpose into WS_G
+      const int ldw = (int)round_up(k, 16);
+      void* Ws = nullptr;
+      HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)q * ldw * sizeof(double), &Ws));
+      HIP_TRY(hipMemsetAsync(Ws, 0, (size_t)q * ldw * sizeof(double), ctx->stream));
+      HFMI_TRY(launch_block_to_dense_ld(ctx, W->p, W->ld, (double*)Ws, ldw, q, k));
+      for (int i = 0; i < op->ndata; ++i) {
+        const double* Ji = J.p + (int64_t)i * q * J.ld;
+        HFMI_TRY(launch_tsgemm_nn(ctx, Ji, J.ld, q, (const double*)Ws, ldw, k, 1.0, 0.0, H->p, H->ld, J.N));
+        // Y[o][j] (+)= scale * <J_i row o, H_j>  -> column-major q x k output: rs = 1, cs = ld
+        HFMI_TRY(launch_tsgemm_tn(ctx, Ji, J.ld, q, H->p, H->ld, k, J.N, op->scale, (i == 0) ? beta : 1.0, Y->p, 1, Y->ld, 0));
+      }
+      return HFMI_OK;
+    }
+    case OP_DENSE_SYM: {
+      const hfmi_block& C = op->X;
+      if (C.N != W->N) HFMI_FAIL(HFMI_ERR_INVALID, "operator acts on vectors of length %lld, got %lld", (long long)C.N, (long long)W->N);
+      // Y = C W with C symmetric: Y[t][j] = <C_t, W_j>  (column-major output)
+      return launch_tsgemm_tn(ctx, C.p, C.ld, C.nvec, W->p, W->ld, k, C.N, 1.0, beta, Y->p, 1, Y->ld, 0);
+    }
+    case OP_CSR: {
+      if (op->csr->ncols != W->N || op->csr->nrows != Y->N) HFMI_FAIL(HFMI_ERR_INVALID, "csr operator / block shape mismatch");
+      if (beta != 0.0 && beta != 1.0) HFMI_TRY(launch_scale(ctx, Y->p, Y->ld, Y->N, k, beta));
+      return launch_csr_spmm(ctx, op->csr, W->p, W->ld, Y->p, Y->ld, k, beta != 0.0);
+    }
+    case OP_CSR_PCG: {
+      if (beta != 0.0) {
+        hfmi_block* T = nullptr;
+        HFMI_TRY(ctx_tmp_block(ctx, 13, W->N, k, &T));
+        HFMI_TRY(pcg_solve(op, W, T));
+        if (beta != 1.0) HFMI_TRY(launch_scale(ctx, Y->p, Y->ld, Y->N, k, beta));
+        return launch_axpy(ctx, Y->p, Y->ld, 1.0, T->p, T->ld, Y->N, k);
+      }
+      return pcg_solve(op, W, Y);
+    }
+    case OP_COMPOSE3: {
+      hfmi_block *T1, *T2;
+      HFMI_TRY(ctx_tmp_block(ctx, 14, W->N, k, &T1));
+      HFMI_TRY(ctx_tmp_block(ctx, 15, W->N, k, &T2));
+      hfmi_block v1 = *T1, v2 = *T2;
+      v1.nvec = k;
+      v2.nvec = k;
+      HFMI_TRY(hfmi_op_apply(op->a, W, &v1, 0));
+      HFMI_TRY(hfmi_op_apply(op->b, &v1, &v2, 0));
+      if (beta == 0.0) return hfmi_op_apply(op->c, &v2, Y, 0);
+      HFMI_TRY(hfmi_op_apply(op->c, &v2, &v1, 0));
+      if (beta != 1.0) HFMI_TRY(launch_scale(ctx, Y->p, Y->ld, Y->N, k, beta));
+      return launch_axpy(ctx, Y->p, Y->ld, 1.0, v1.p, v1.ld, Y->N, k);
+    }
+    case OP_HOST: {
+      const int64_t N = W->N;
+      if (op->host_N > 0 && op->host_N != N) HFMI_FAIL(HFMI_ERR_INVALID, "host operator acts on vectors of length %lld, got %lld", (long long)op->host_N, (long long)N);
+      std::vector<double> hw((size_t)N * k), hy((size_t)Y->N * k, 0.0);
+      HFMI_TRY(hfmi_block_download(W, hw.data(), HFMI_LAYOUT_VECTORS));
+      const int rc = op->host_fn(op->host_user, hw.data(), hy.data(), N, k);
+      if (rc != 0) HFMI_FAIL(HFMI_ERR_CALLBACK, "host operator callback returned %d", rc);
+      if (beta == 0.0) return hfmi_block_upload(Y, hy.data(), HFMI_LAYOUT_VECTORS);
+      hfmi_block* T = nullptr;
+      HFMI_TRY(ctx_tmp_block(ctx, 13, Y->N, k, &T));
+      hfmi_block v = *T;
+      v.nvec = k;
+      HFMI_TRY(hfmi_block_upload(&v, hy.data(), HFMI_LAYOUT_VECTORS));
+      if (beta != 1.0) HFMI_TRY(launch_scale(ctx, Y->p, Y->ld, Y->N, k, beta));
+      return launch_axpy(ctx, Y->p, Y->ld, 1.0, v.p, v.ld, Y->N, k);
+    }
+  }
+  HFMI_FAIL(HFMI_ERR_INVALID, "unknown operator kind");
+}
+
+extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, int accumulate) {
+  if (!op || !W || !Y) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (W->nvec != Y->nvec) HFMI_FAIL(HFMI_ERR_INVALID, "x and y have non-matching number of vectors (%d vs %d)", W->nvec, Y->nvec);
+  if (W->p == Y->p) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: input and output blocks must not alias");
+  HIP_TRY(hipSetDevice(op->ctx->device));
+  if (accumulate && op->post_fn) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: accumulate with a post-apply hook is ambiguous");
+  HFMI_TRY(op_apply_raw(op, W, Y, accumulate ? 1.0 : 0.0));
+  if (op->post_fn) {
+    const int rc = op->post_fn(op->post_user, Y);
+    if (rc != 0) HFMI_FAIL(HFMI_ERR_CALLBACK, "post-apply hook returned %d", rc);
+  }
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ QR
+static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* passes_out) {
+  hfmi_ctx* ctx = Q->ctx;
+  const int64_t N = Q->N;
+  const int k = Q->nvec;
+  if (k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "borth_qr: at most %d vectors (got %d)", SM_MAXK, k);
+  hfmi_block* BZ = nullptr;
+  hfmi_block bz_view;
+  if (B) {
+    if (BQ) {
+      BZ = BQ;
+    } else {
+      HFMI_TRY(ctx_tmp_block(ctx, 4, N, k, &BZ));
+      bz_view = *BZ;
+      bz_view.nvec = k;
+      BZ = &bz_view;
+    }
+  }
+  const double u = 1.1102230246251565e-16;
+  const double shift_rel = 11.0 * ((double)N * k + (double)k * (k + 1)) * u;
+  const double pivot_tol = 100.0 * k * sqrt((double)N) * u;
+  int passes = 0;
+  const int max_passes = 6;
+  for (;;) {
+    const hfmi_block* right = Q;
+    if (B) {
+      HFMI_TRY(hfmi_op_apply(B, Q, BZ, 0));
+      right = BZ;
+    }
+    HFMI_TRY(launch_tsgemm_tn(ctx, Q->p, Q->ld, k, right->p, right->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_GRAM), SM_LD, 1, 0));
+    const int rtot_mode = want_r ? (passes == 0 ? 1 : 2) : 0;
+    HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, shift_rel, pivot_tol));
+    hfmi_status_words st;
+    HFMI_TRY(read_status(ctx, &st));
+    if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
+    HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
+    ++passes;
+    // The input of this pass had orthonormality defect st.gram_dev (column-scaled).  If it was already
+    // small and no shift was needed, the output is orthonormal to round-off: done.
+    if (passes >= 2 && !st.shifted && st.gram_dev < 1e-2) break;
+    if (passes >= max_passes) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: no convergence in %d Cholesky-QR passes (defect %.2e)", passes, st.gram_dev);
+  }
+  if (B && BQ) HFMI_TRY(hfmi_op_apply(B, Q, BQ, 0));
+  if (passes_out) *passes_out = passes;
+  return HFMI_OK;
+}
+
+// Column-by-column Gram-Schmidt with the reference's re-orthogonalisation rule (hippylib
+// MultiVector._mgs_stable / _mgs_reortho as restated in oracle/hippylib_restated.py): each sweep projects
+// column j against all previous columns at once (classical GS per sweep; with the "twice is enough"
+// repetition this is as stable as the modified variant) and repeats while 10 eps t < ||q|| < t/10.
+static int qr_mgs(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* R_host /* k*k or null */, int* passes_out) {
+  hfmi_ctx* ctx = Q->ctx;
+  const int64_t N = Q->N;
+  const int k = Q->nvec;
+  const double eps = 2.220446049250313e-16;
+  hfmi_block* BZ = nullptr;
+  hfmi_block bz_view;
+  if (B) {
+    if (BQ) BZ = BQ;
+    else {
+      HFMI_TRY(ctx_tmp_block(ctx, 4, N, k, &BZ));
+      bz_view = *BZ;
+      bz_view.nvec = k;
+      BZ = &bz_view;
+    }
+  }
+  std::vector<double> R((size_t)k * k, 0.0), s(k);
+  void* dv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)(k + 16) * 16 * sizeof(double), &dv));
+  double* dsmall = (double*)dv;  // device scratch: coefficient column (ld 16) / scalars
+  int total_sweeps = 0;
+  for (int j = 0; j < k; ++j) {
+    hfmi_block qj = *Q;
+    qj.p = Q->p + (int64_t)j * Q->ld;
+    qj.nvec = 1;
+    hfmi_block bqj = qj;
+    if (B) {
+      bqj = *BZ;
+      bqj.p = BZ->p + (int64_t)j * BZ->ld;
+      bqj.nvec = 1;
+      HFMI_TRY(hfmi_op_apply(B, &qj, &bqj, 0));
+    }
+    double t2 = 0.0;
+    HFMI_TRY(launch_col_dots(ctx, bqj.p, bqj.ld, qj.p, qj.ld, N, 1, dsmall));
+    HFMI_TRY(read_back(ctx, dsmall, 1, &t2));
+    double t = sqrt(std::max(t2, 0.0));
+    double tt = t;
+    bool again = true;
+    while (again) {
+      ++total_sweeps;
+      if (j > 0) {
+        // s = (B Q_prev)^T q_j
+        const double* left = B ? BZ->p : Q->p;
+        const int64_t ldl = B ? BZ->ld : Q->ld;
+        HFMI_TRY(launch_tsgemm_tn(ctx, left, ldl, j, qj.p, qj.ld, 1, N, 1.0, 0.0, dsmall, 16, 1, 0));
+        std::vector<double> tmp((size_t)j * 16);
+        HFMI_TRY(read_back(ctx, dsmall, (size_t)j * 16, tmp.data()));
+        for (int i = 0; i < j; ++i) {
+          s[i] = tmp[(size_t)i * 16];
+          R[(size_t)i * k + j] += s[i];
+        }
+        // q_j -= Q_prev s   (the device copy of s already sits in dsmall with ld 16)
+        HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, j, dsmall, 16, 1, -1.0, 1.0, qj.p, qj.ld, N));
+      }
+      if (B) HFMI_TRY(hfmi_op_apply(B, &qj, &bqj, 0));
+      double tt2 = 0.0;
+      HFMI_TRY(launch_col_dots(ctx, bqj.p, bqj.ld, qj.p, qj.ld, N, 1, dsmall));
+      HFMI_TRY(read_back(ctx, dsmall, 1, &tt2));
+      tt = sqrt(std::max(tt2, 0.0));
+      if (tt > t * 10.0 * eps && tt < t / 10.0) {
+        again = true;
+        t = tt;
+      } else {
+        again = false;
+        if (tt < 10.0 * eps * t) tt = 0.0;
+      }
+    }
+    R[(size_t)j * k + j] = tt;
+    const double inv = (fabs(tt * eps) > 0.0) ? 1.0 / tt : 0.0;
+    HFMI_TRY(launch_scale(ctx, qj.p, qj.ld, N, 1, inv));
+    if (B) HFMI_TRY(launch_scale(ctx, bqj.p, bqj.ld, N, 1, inv));
+  }
+  if (R_host) memcpy(R_host, R.data(), (size_t)k * k * sizeof(double));
+  if (passes_out) *passes_out = total_sweeps;
+  return HFMI_OK;
+}
+
+extern "C" int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int method, int* passes) {
+  if (!Q) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
+  if (BQ) HFMI_TRY(check_same_shape(Q, BQ, "borth_qr"));
+  if (BQ && !B) HFMI_FAIL(HFMI_ERR_INVALID, "borth_qr: BQ requested without B");
+  hfmi_ctx* ctx = Q->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int k = Q->nvec;
+  if (method == HFMI_QR_MGS) return qr_mgs(Q, B, BQ, host_R, passes);
+  if (method != HFMI_QR_CHOL && method != HFMI_QR_AUTO) HFMI_FAIL(HFMI_ERR_INVALID, "borth_qr: unknown method %d", method);
+  hfmi_block* save = nullptr;
+  if (method == HFMI_QR_AUTO) {  // keep the input so that a breakdown can fall back to Gram-Schmidt
+    HFMI_TRY(ctx_tmp_block(ctx, 5, Q->N, k, &save));
+    HFMI_TRY(launch_copy(ctx, save->p, save->ld, Q->p, Q->ld, Q->N, k));
+  }
+  int s = qr_chol(Q, B, BQ, host_R != nullptr, passes);
+  if (s == HFMI_ERR_NUMERIC && method == HFMI_QR_AUTO) {
+    HFMI_TRY(launch_copy(ctx, Q->p, Q->ld, save->p, save->ld, Q->N, k));
+    return qr_mgs(Q, B, BQ, host_R, passes);
+  }
+  if (s != HFMI_OK) return s;
+  if (host_R) {
+    std::vector<double> tmp((size_t)k * SM_LD);
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_RTOT), (size_t)k * SM_LD, tmp.data()));
+    for (int i = 0; i < k; ++i) memcpy(host_R + (size_t)i * k, tmp.data() + (size_t)i * SM_LD, (size_t)k * sizeof(double));
+  }
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ Rayleigh-Ritz
+extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d, double* host_V) {
+  if (!ctx || !host_T || !host_d) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_small: k=%d out of range [1,%d]", k, SM_MAXK);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HFMI_TRY(upload_small(ctx, host_T, k, k, sm_ptr(ctx, SM_T), SM_LD));
+  void* dv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
+  HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, sort_by_abs));
+  hfmi_status_words st;
+  HFMI_TRY(read_status(ctx, &st));
+  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig_small: Jacobi did not converge (off-diagonal %.2e)", st.offdiag);
+  HFMI_TRY(read_back(ctx, (const double*)dv, k, host_d));
+  if (host_V) {
+    std::vector<double> tmp((size_t)k * SM_LD);
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_V), (size_t)k * SM_LD, tmp.data()));
+    for (int i = 0; i < k; ++i) memcpy(host_V + (size_t)i * k, tmp.data() + (size_t)i * SM_LD, (size_t)k * sizeof(double));
+  }
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ fused double pass
+static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* Omega, int r, int s, int flags,
+                            double* host_d, hfmi_block* U) {
+  if (!A || !Omega || !host_d || !U) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = Omega->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int64_t N = Omega->N;
+  const int k = Omega->nvec;
+  if (k < r) HFMI_FAIL(HFMI_ERR_INVALID, "double_pass: Omega has %d vectors, need at least the rank %d", k, r);
+  if (r < 1) HFMI_FAIL(HFMI_ERR_INVALID, "double_pass: rank must be positive");
+  if (U->N != N || U->nvec != r) HFMI_FAIL(HFMI_ERR_INVALID, "double_pass: U must be %lld x %d", (long long)N, r);
+  if (k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "double_pass: at most %d probe vectors (got %d)", SM_MAXK, k);
+  if (s < 1) HFMI_FAIL(HFMI_ERR_INVALID, "double_pass: s must be >= 1");
+  hfmi_block *Qb, *Yb;
+  HFMI_TRY(ctx_tmp_block(ctx, 0, N, k, &Qb));
+  HFMI_TRY(ctx_tmp_block(ctx, 1, N, k, &Yb));
+  hfmi_block Q = *Qb, Y = *Yb;
+  Q.nvec = k;
+  Y.nvec = k;
+  // power iterations: Q <- (B^-1) A Q, starting from Omega (never modified)
+  const hfmi_block* cur = Omega;
+  for (int it = 0; it < s; ++it) {
+    if (Binv) {
+      HFMI_TRY(hfmi_op_apply(A, cur, &Y, 0));
+      HFMI_TRY(hfmi_op_apply(Binv, &Y, &Q, 0));
+      cur = &Q;
+    } else {
+      hfmi_block* dst = (cur == &Q) ? &Y : &Q;
+      HFMI_TRY(hfmi_op_apply(A, cur, dst, 0));
+      cur = dst;
+    }
+  }
+  hfmi_block* Qp = const_cast<hfmi_block*>(cur);           // holds the block to orthogonalise
+  hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
+  const int method = (flags & 2) ? HFMI_QR_MGS : HFMI_QR_AUTO;
+  HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, method, nullptr));
+  HFMI_TRY(hfmi_op_apply(A, Qp, AQ, 0));
+  // T = (AQ)^T Q, small eigensolve, U = Q V[:, :r]
+  HFMI_TRY(launch_tsgemm_tn(ctx, AQ->p, AQ->ld, k, Qp->p, Qp->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_T), SM_LD, 1, 0));
+  void* dv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
+  HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1));
+  HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_V), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
+  hfmi_status_words st;
+  HFMI_TRY(read_status(ctx, &st));
+  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: Jacobi eigensolve did not converge (off-diagonal %.2e)", st.offdiag);
+  return read_back(ctx, (const double*)dv, r, host_d);
+}
+
+extern "C" int hfmi_double_pass(hfmi_op* A, const hfmi_block* Omega, int r, int s, int flags, double* host_d, hfmi_block* U) {
+  return double_pass_impl(A, nullptr, nullptr, Omega, r, s, flags, host_d, U);
+}
+extern "C" int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* Omega, int r, int s, int flags,
+                                  double* host_d, hfmi_block* U) {
+  if (!B || !Binv) HFMI_FAIL(HFMI_ERR_INVALID, "double_pass_g: B and Binv are required");
+  return double_pass_impl(A, B, Binv, Omega, r, s, flags, host_d, U);
+}
+
+// ------------------------------------------------------------------ instrumentation
+extern "C" int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, int reps, double* host_C, double* avg_ms) {
+  if (!A || !B) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (A->N != B->N) HFMI_FAIL(HFMI_ERR_INVALID, "bench_tsgemm_tn: vector lengths differ");
+  hfmi_ctx* ctx = A->ctx;
+  void* out = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)A->nvec * round_up(B->nvec, 16) * sizeof(double), &out));
+  const int ldc = (int)round_up(B->nvec, 16);
+  HFMI_TRY(launch_tsgemm_tn(ctx, A->p, A->ld, A->nvec, B->p, B->ld, B->nvec, A->N, 1.0, 0.0, (double*)out, ldc, 1, nsplit));
+  if (reps > 0) {
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i)
+      HFMI_TRY(launch_tsgemm_tn(ctx, A->p, A->ld, A->nvec, B->p, B->ld, B->nvec, A->N, 1.0, 0.0, (double*)out, ldc, 1, nsplit));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (avg_ms) *avg_ms = ms / reps;
+  }
+  if (host_C) {
+    std::vector<double> tmp((size_t)A->nvec * ldc);
+    HFMI_TRY(read_back(ctx, (const double*)out, tmp.size(), tmp.data()));
+    for (int i = 0; i < A->nvec; ++i) memcpy(host_C + (size_t)i * B->nvec, tmp.data() + (size_t)i * ldc, (size_t)B->nvec * sizeof(double));
+  }
+  return HFMI_OK;
+}
+extern "C" int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms) {
+  if (!A || !host_S || !Y) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = A->ctx;
+  const int m = A->nvec, r = Y->nvec;
+  const int ld = (int)round_up(r, 16);
+  void* S = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)m * ld * sizeof(double), &S));
+  HFMI_TRY(upload_small(ctx, host_S, m, r, (double*)S, ld));
+  HFMI_TRY(launch_tsgemm_nn(ctx, A->p, A->ld, m, (const double*)S, ld, r, 1.0, 0.0, Y->p, Y->ld, A->N));
+  if (reps > 0) {
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i)
+      HFMI_TRY(launch_tsgemm_nn(ctx, A->p, A->ld, m, (const double*)S, ld, r, 1.0, 0.0, Y->p, Y->ld, A->N));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (avg_ms) *avg_ms = ms / reps;
+  }
+  return HFMI_OK;
+}
+extern "C" int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbs) {
+  if (!ctx || !mfma_f64_tflops || !fma_f64_tflops || !hbm_copy_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_bench_peaks(ctx, mfma_f64_tflops, fma_f64_tflops, hbm_copy_gbs);
+}

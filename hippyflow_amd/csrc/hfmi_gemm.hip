@@ -1,0 +1,529 @@
+// FP64 tall-skinny contractions on gfx950 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Two shapes carry every operator application, Gram matrix and back-transform on the
+// double-pass path (DESIGN.md section "kernels"):
+//
+//   tsgemm_tn :  C (m x k)  = A^T B     A: N x m, B: N x k   -- reduction over the long axis N
+//                (X W in the snapshot-Gram / Jacobian-Gram apply, Q^T B Q, (AQ)^T Q, C W)
+//   tsgemm_nn :  Y (N x r)  = A S       A: N x m, S: m x r   -- long axis preserved
+//                (X^T G, Q R^{-1}, U = Q V)
+//
+// All blocks are column-major with every vector contiguous along N, so in tsgemm_tn BOTH
+// operands are contiguous along the reduction index: an MFMA k-step may use any 4 reduction
+// indices as long as A and B agree, which lets each lane fetch 16 contiguous bytes (2 doubles)
+// per operand per two k-steps straight from HBM -- no transposition through LDS.  The operand
+// shared by the 4 waves of a workgroup (B in tn, S in nn) is staged through LDS; the streamed
+// operand goes HBM -> VGPR directly with a register prefetch ring.  One wave per SIMD holds a
+// (16*MT) x (16*NT) fp64 accumulator tile (up to 40 MFMA tiles = 320 VGPRs).
+//
+// MFMA fragment maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&15][kk = l>>4] and
+// B[kk = l>>4][j = l&15]; it receives D[row = (l>>4) + 4*reg][col = l&15], reg = 0..3.
+#include "hfmi_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// XCD-aware block id remap (8 XCDs, block b runs on XCD b % 8): consecutive logical ids land on the
+// same XCD so that workgroups sharing the LDS-staged operand also share an L2.  Bijective for any total.
+__device__ __forceinline__ int64_t round_up_dev(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int fl = total >> 3, rem = total & 7;
+  return xcd * fl + (xcd < rem ? xcd : rem) + slot;
+}
+
+// =====================================================================================
+// tsgemm_tn
+// =====================================================================================
+constexpr int TN_BK = 32;   // reduction indices per LDS stage
+constexpr int TN_LDB = 34;  // LDS leading dimension (doubles): 16-byte aligned rows, spreads banks
+
+// Preconditions (guaranteed by the block layout, hfmi.h): lda, ldb multiples of 32 doubles, rows N..ld-1 of
+// every vector are zero, so the reduction runs over whole 32-row stages with NO masks or branches in the loop:
+// every load below is unconditional (clamped addresses), which is what lets the prefetches stay in flight.
+template <int MT, int NT, bool TR>
+__global__ __launch_bounds__(256, 1) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
+                                                      const double* __restrict__ B, int64_t ldb, int k,
+                                                      int64_t Npad, int64_t chunk, int nrb, int nsplit,
+                                                      double* __restrict__ part, int mpad, int kpad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][TN_LDB]
+  constexpr int COLS = NT * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kk = lane >> 4;
+
+  const int logical = xcd_remap(blockIdx.x, nrb * nsplit);
+  const int sp = logical / nrb, rb = logical % nrb;
+  const int64_t t_begin = (int64_t)sp * chunk;
+  int64_t t_end = t_begin + chunk;
+  if (t_end > Npad) t_end = Npad;
+  const int nstages = (int)((t_end - t_begin) / TN_BK);
+  const int64_t t_last = t_end - 8;  // last iteration base that is safe to fetch
+  const int rowbase = rb * (64 * MT) + wave * (16 * MT);
+
+  const double* a_ptr[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = rowbase + mt * 16 + r16;
+    if (row > m - 1) row = m - 1;
+    a_ptr[mt] = A + (int64_t)row * lda + kk * 2;
+  }
+  // B stage: COLS * 16 chunks of 16 bytes, NT per thread
+  const double* b_ptr[NT];
+#pragma unroll
+  for (int qd = 0; qd < NT; ++qd) {
+    const int c = tid + 256 * qd;
+    int col = c >> 4;
+    if (col > k - 1) col = k - 1;
+    b_ptr[qd] = B + (int64_t)col * ldb + (c & 15) * 2;
+  }
+
+  d4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 breg[NT];
+  auto stage_load = [&](int64_t ts) {
+#pragma unroll
+    for (int qd = 0; qd < NT; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + ts);
+  };
+  auto stage_store = [&](double* L) {
+#pragma unroll
+    for (int qd = 0; qd < NT; ++qd) {
+      const int c = tid + 256 * qd;
+      *reinterpret_cast<d2*>(L + (c >> 4) * TN_LDB + (c & 15) * 2) = breg[qd];
+    }
+  };
+  auto load_a = [&](d2(&dst)[MT], int64_t t) {
+    if (t > t_last) t = t_last;  // wave-uniform clamp: the prefetch past the end re-reads valid data
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const d2*>(a_ptr[mt] + t);
+  };
+  auto ldsb = [&](d2(&bf)[NT], const double* L, int it) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      bf[nt] = *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * TN_LDB + it * 8 + kk * 2);
+  };
+  auto mma = [&](const d2(&a)[MT], const d2(&bf)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (TR) {
+          acc[mt][nt] = MFMA_F64(bf[nt].x, a[mt].x, acc[mt][nt]);
+          acc[mt][nt] = MFMA_F64(bf[nt].y, a[mt].y, acc[mt][nt]);
+        } else {
+          acc[mt][nt] = MFMA_F64(a[mt].x, bf[nt].x, acc[mt][nt]);
+          acc[mt][nt] = MFMA_F64(a[mt].y, bf[nt].y, acc[mt][nt]);
+        }
+      }
+    // keep the scheduler from hoisting later iterations' loads above these MFMAs
+    // (it would otherwise blow the register budget and spill the accumulators)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (nstages > 0) {
+    stage_load(t_begin);
+    stage_store(lds);
+    __syncthreads();
+  }
+  d2 a0[MT], a1[MT], bf0[NT], bf1[NT];
+  load_a(a0, t_begin);
+  for (int s = 0; s < nstages; ++s) {
+    const int64_t ts = t_begin + (int64_t)s * TN_BK;
+    const bool has_next = s + 1 < nstages;
+    if (has_next) stage_load(ts + TN_BK);
+    const double* L = lds + (s & 1) * COLS * TN_LDB;
+    ldsb(bf0, L, 0);
+    load_a(a1, ts + 8);
+    ldsb(bf1, L, 1);
+    mma(a0, bf0);
+    load_a(a0, ts + 16);
+    ldsb(bf0, L, 2);
+    mma(a1, bf1);
+    load_a(a1, ts + 24);
+    ldsb(bf1, L, 3);
+    mma(a0, bf0);
+    load_a(a0, ts + 32);
+    mma(a1, bf1);
+    if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * TN_LDB);
+    __syncthreads();
+  }
+
+  double* P = part + (int64_t)sp * mpad * kpad;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (TR) {
+          const int j = nt * 16 + kk + 4 * r;
+          const int i = rowbase + mt * 16 + r16;
+          P[(int64_t)j * mpad + i] = acc[mt][nt][r];
+        } else {
+          const int i = rowbase + mt * 16 + kk + 4 * r;
+          const int j = nt * 16 + r16;
+          P[(int64_t)i * kpad + j] = acc[mt][nt][r];
+        }
+      }
+}
+
+// C[i*rs + j*cs] = scale * sum_sp part[sp][...] + beta * C   (fixed summation order: deterministic)
+__global__ void k_reduce_partials(const double* __restrict__ part, int nsplit, int64_t pstride, int inner_ld, int tr,
+                                  int m, int k, double scale, double beta, double* __restrict__ C, int64_t rs,
+                                  int64_t cs) {
+  const int fast = blockIdx.x * blockDim.x + threadIdx.x;
+  const int fastn = tr ? m : k, slown = tr ? k : m;
+  if (fast >= fastn) return;
+  for (int slow = blockIdx.y; slow < slown; slow += gridDim.y) {
+    const int i = tr ? fast : slow, j = tr ? slow : fast;
+    const double* p = part + (int64_t)slow * inner_ld + fast;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += p[(int64_t)sp * pstride];
+    double* out = C + (int64_t)i * rs + (int64_t)j * cs;
+    *out = (beta != 0.0) ? scale * s + beta * (*out) : scale * s;
+  }
+}
+
+static inline int tn_mt_max(int nt) {
+  static const int t[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
+  return t[nt];
+}
+
+template <int MT, int NT>
+static int tn_launch_inst(hfmi_ctx* ctx, bool tr, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
+                          int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
+  const size_t shmem = (size_t)2 * NT * 16 * TN_LDB * sizeof(double);
+  dim3 grid(nrb * nsplit), block(256);
+  if (tr) {
+    auto kern = k_tsgemm_tn<MT, NT, true>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad,
+                       kpad);
+  } else {
+    auto kern = k_tsgemm_tn<MT, NT, false>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad,
+                       kpad);
+  }
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+template <int NT>
+static int tn_dispatch_mt(hfmi_ctx* ctx, int mt, bool tr, const double* A, int64_t lda, int m, const double* B,
+                          int64_t ldb, int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad,
+                          int kpad) {
+#define TN_CASE(M)                                                                                              \
+  case M:                                                                                                       \
+    if constexpr (M * NT <= 32)                                                                                 \
+      return tn_launch_inst<M, NT>(ctx, tr, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);     \
+    break;
+  switch (mt) {
+    TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7) TN_CASE(8)
+  }
+#undef TN_CASE
+  HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: no instance for MT=%d NT=%d", mt, NT);
+}
+
+// one panel of at most 256 columns of B
+static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
+                    int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req) {
+  const int nt = (k + 15) / 16;
+  const int kpad = nt * 16;
+  const int64_t Npad = round_up(N, TN_BK);
+  if (lda % 32 != 0 || ldb % 32 != 0 || lda < Npad || ldb < Npad)
+    HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: leading dimensions must be multiples of 32 and >= round_up(N,32)");
+  const bool tr = (rs == 1 && cs != 1);  // column-major output: coalesce along i
+  // wave tile height: as tall as the accumulator budget allows, but no taller than the problem needs
+  const int row_tiles = (m + 15) / 16;
+  int mt = tn_mt_max(nt);
+  const int need = (row_tiles + 3) / 4;
+  if (need < mt) mt = need;
+  if (mt < 1) mt = 1;
+  const int rows_per_block = 64 * mt;
+  const int nrb = (m + rows_per_block - 1) / rows_per_block;
+  const int mpad = nrb * rows_per_block;
+  // split the long axis so that the grid fills the chip in (nearly) whole rounds of CUs
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  int nsplit = nsplit_req;
+  if (nsplit <= 0) {
+    const int64_t stages = Npad / TN_BK;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int ns = 1; ns <= 128; ++ns) {
+      if (ns > 1 && stages / ns < 16) break;
+      const int64_t blocks = (int64_t)nrb * ns;
+      const int64_t rounds = (blocks + cus - 1) / cus;
+      const double eff = (double)blocks / (double)(rounds * cus);
+      const double part_ratio = 2.0 * ns * (double)mpad * kpad / ((double)N * (m + k));
+      const double cost = 1.0 / eff + part_ratio;
+      if (cost < best_cost - 1e-12) {
+        best_cost = cost;
+        best = ns;
+      }
+    }
+    nsplit = best;
+  }
+  int64_t chunk = round_up((Npad + nsplit - 1) / nsplit, TN_BK);
+  if (chunk < TN_BK) chunk = TN_BK;
+  nsplit = (int)((Npad + chunk - 1) / chunk);
+  if (nsplit < 1) nsplit = 1;
+  void* partv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nsplit * mpad * kpad * sizeof(double), &partv));
+  double* part = (double*)partv;
+#define TN_NT(NTV)                                                                                             \
+  case NTV:                                                                                                    \
+    HFMI_TRY(tn_dispatch_mt<NTV>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad)); \
+    break;
+  switch (nt) {
+    TN_NT(1) TN_NT(2) TN_NT(3) TN_NT(4) TN_NT(5) TN_NT(6) TN_NT(7) TN_NT(8) TN_NT(9) TN_NT(10) TN_NT(11) TN_NT(12)
+    TN_NT(13) TN_NT(14) TN_NT(15) TN_NT(16)
+    default:
+      HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: panel too wide (%d)", k);
+  }
+#undef TN_NT
+  {
+    const int fastn = tr ? m : k, slown = tr ? k : m;
+    dim3 block(128), grid((fastn + 127) / 128, slown < 32768 ? slown : 32768);
+    hipLaunchKernelGGL(k_reduce_partials, grid, block, 0, ctx->stream, part, nsplit, (int64_t)mpad * kpad,
+                       tr ? mpad : kpad, tr ? 1 : 0, m, k, scale, beta, C, rs, cs);
+    HIP_TRY(hipGetLastError());
+  }
+  return HFMI_OK;
+}
+
+int launch_tsgemm_tn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
+                     int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req) {
+  if (m <= 0 || k <= 0 || N <= 0) return HFMI_OK;
+  for (int k0 = 0; k0 < k; k0 += 256) {
+    const int kp = (k - k0 < 256) ? (k - k0) : 256;
+    HFMI_TRY(tn_panel(ctx, A, lda, m, B + (int64_t)k0 * ldb, ldb, kp, N, scale, beta, C + (int64_t)k0 * cs, rs, cs,
+                      nsplit_req));
+  }
+  return HFMI_OK;
+}
+
+// =====================================================================================
+// tsgemm_nn
+// =====================================================================================
+constexpr int NN_KC = 32;  // reduction indices per LDS stage (8 MFMA k-steps)
+
+// Preconditions: lda multiple of 32 and >= round_up(N,32) (rows beyond N readable); S finite, ld even.
+template <int TT, int NT>
+__global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
+                                                      const double* __restrict__ S, int lds_, int r,
+                                                      double* __restrict__ Y, int64_t ldy, int64_t N) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds = reinterpret_cast<double*>(smem);  // [2][NN_KC][SLD]
+  constexpr int COLS = NT * 16;
+  constexpr int SLD = COLS + ((NT % 2 == 0) ? 16 : 0);  // SLD % 32 == 16: conflict-free ds_read_b64
+  constexpr int TP = TT / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, kk = lane >> 4;
+  const int64_t t0 = (int64_t)blockIdx.x * (64 * TT) + wave * (16 * TT);
+  const int nstages = (m + NN_KC - 1) / NN_KC;
+  const int64_t tmax = round_up_dev(N, 32) - 2;
+
+  // streamed operand: lane (c16, kk) fetches rows t0 + tp*32 + 2*c16 + {0,1} of vector i0 + kk
+  int64_t toff[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    int64_t t = t0 + tp * 32 + 2 * c16;
+    toff[tp] = t > tmax ? tmax : t;  // rows >= N are never stored; keep the address legal
+  }
+  // S stage: NN_KC rows x COLS cols as 16-byte pairs, NT per thread
+  int s_row[NT], s_cp[NT];
+#pragma unroll
+  for (int qd = 0; qd < NT; ++qd) {
+    const int c = tid + 256 * qd;
+    s_row[qd] = c / (COLS / 2);
+    s_cp[qd] = c % (COLS / 2);
+  }
+
+  d4 acc[TT][NT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[tt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 sreg[NT];
+  auto stage_load = [&](int is) {
+#pragma unroll
+    for (int qd = 0; qd < NT; ++qd) {
+      int row = is + s_row[qd];
+      if (row > m - 1) row = m - 1;
+      sreg[qd] = *reinterpret_cast<const d2*>(S + (int64_t)row * lds_ + s_cp[qd] * 2);
+    }
+  };
+  auto stage_store = [&](double* L, int is) {
+#pragma unroll
+    for (int qd = 0; qd < NT; ++qd) {
+      d2 v = sreg[qd];
+      if (is + s_row[qd] >= m) v = d2{0.0, 0.0};  // rows past the reduction length contribute nothing
+      *reinterpret_cast<d2*>(L + s_row[qd] * SLD + s_cp[qd] * 2) = v;
+    }
+  };
+  auto load_a = [&](d2(&dst)[TP], int i0) {
+    int col = i0 + kk;
+    if (col > m - 1) col = m - 1;
+    const double* p = A + (int64_t)col * lda;
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) dst[tp] = *reinterpret_cast<const d2*>(p + toff[tp]);
+  };
+  auto ldss = [&](double(&sf)[NT], const double* L, int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sf[nt] = L[(ks * 4 + kk) * SLD + nt * 16 + c16];
+  };
+  auto mma = [&](const d2(&a)[TP], const double(&sf)[NT]) {
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[2 * tp][nt] = MFMA_F64(sf[nt], a[tp].x, acc[2 * tp][nt]);
+        acc[2 * tp + 1][nt] = MFMA_F64(sf[nt], a[tp].y, acc[2 * tp + 1][nt]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  stage_load(0);
+  stage_store(lds, 0);
+  __syncthreads();
+  // register ring of 4 k-steps for the streamed operand (prefetch distance 3), ping-pong LDS fragments
+  d2 a0[TP], a1[TP], a2[TP], a3[TP];
+  double sf0[NT], sf1[NT];
+  load_a(a0, 0);
+  load_a(a1, 4);
+  load_a(a2, 8);
+  for (int s = 0; s < nstages; ++s) {
+    const int is = s * NN_KC;
+    const bool has_next = s + 1 < nstages;
+    if (has_next) stage_load(is + NN_KC);
+    const double* L = lds + (s & 1) * NN_KC * SLD;
+    ldss(sf0, L, 0);
+    load_a(a3, is + 12);
+    ldss(sf1, L, 1);
+    mma(a0, sf0);
+    load_a(a0, is + 16);
+    ldss(sf0, L, 2);
+    mma(a1, sf1);
+    load_a(a1, is + 20);
+    ldss(sf1, L, 3);
+    mma(a2, sf0);
+    load_a(a2, is + 24);
+    ldss(sf0, L, 4);
+    mma(a3, sf1);
+    load_a(a3, is + 28);
+    ldss(sf1, L, 5);
+    mma(a0, sf0);
+    load_a(a0, is + 32);
+    ldss(sf0, L, 6);
+    mma(a1, sf1);
+    load_a(a1, is + 36);
+    ldss(sf1, L, 7);
+    mma(a2, sf0);
+    load_a(a2, is + 40);
+    mma(a3, sf1);
+    if (has_next) stage_store(lds + ((s + 1) & 1) * NN_KC * SLD, is + NN_KC);
+    __syncthreads();
+  }
+
+  // Raw accumulator stores only: any VALU arithmetic on the accumulators here makes hipcc keep them in
+  // VGPRs across the loop back-edge (256 v_accvgpr copies per stage); scaling/accumulation is done by the caller.
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int j = nt * 16 + kk + 4 * rg;
+      if (j < r) {
+        double* yc = Y + (int64_t)j * ldy;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          const int64_t t = t0 + tp * 32 + 2 * c16;
+          if (t + 1 < N) {
+            *reinterpret_cast<d2*>(yc + t) = d2{acc[2 * tp][nt][rg], acc[2 * tp + 1][nt][rg]};
+          } else if (t < N) {
+            yc[t] = acc[2 * tp][nt][rg];
+          }
+        }
+      }
+    }
+}
+
+template <int TT, int NT>
+static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r,
+                          double* Y, int64_t ldy, int64_t N) {
+  constexpr int SLD = NT * 16 + ((NT % 2 == 0) ? 16 : 0);
+  const size_t shmem = (size_t)2 * NN_KC * SLD * sizeof(double);
+  auto kern = k_tsgemm_nn<TT, NT>;
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  dim3 grid((unsigned)((N + 64 * TT - 1) / (64 * TT))), block(256);
+  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
+                    int64_t ldy, int64_t N) {
+  const int nt = (r + 15) / 16;
+#define NN_CASE(NTV, TTV) \
+  case NTV:               \
+    return nn_launch_inst<TTV, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
+  switch (nt) {
+    NN_CASE(1, 4) NN_CASE(2, 4) NN_CASE(3, 4) NN_CASE(4, 4) NN_CASE(5, 4) NN_CASE(6, 4) NN_CASE(7, 4) NN_CASE(8, 4)
+    NN_CASE(9, 2) NN_CASE(10, 2) NN_CASE(11, 2) NN_CASE(12, 2) NN_CASE(13, 2) NN_CASE(14, 2) NN_CASE(15, 2)
+    NN_CASE(16, 2)
+  }
+#undef NN_CASE
+  HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_nn: panel too wide (%d)", r);
+}
+
+__global__ void k_small_scale_copy(double* __restrict__ dst, const double* __restrict__ src, int rows, int cols, int ld,
+                                   double alpha) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ld) return;
+  for (int i = blockIdx.y; i < rows; i += gridDim.y) dst[(int64_t)i * ld + j] = (j < cols) ? alpha * src[(int64_t)i * ld + j] : 0.0;
+}
+
+// Y = alpha * A * S + beta * Y.  alpha is folded into a scaled copy of the small matrix; beta goes through a
+// scratch block + axpby, so the MFMA kernel itself only ever stores raw accumulators.
+int launch_tsgemm_nn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double alpha,
+                     double beta, double* Y, int64_t ldy, int64_t N) {
+  if (r <= 0 || N <= 0) return HFMI_OK;
+  if (m <= 0) HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_nn: empty reduction");
+  if (lds_ % 2 != 0) HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_nn: small-matrix leading dimension must be even");
+  if (lda % 32 != 0 || lda < round_up(N, 32))
+    HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_nn: leading dimension must be a multiple of 32 and >= round_up(N,32)");
+  if (r > 256 && A == Y) HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_nn: in-place update needs r <= 256");
+  if (alpha != 1.0) {
+    void* sc = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_MISC, (size_t)m * lds_ * sizeof(double), &sc));
+    dim3 block(128), grid((lds_ + 127) / 128, m < 4096 ? m : 4096);
+    hipLaunchKernelGGL(k_small_scale_copy, grid, block, 0, ctx->stream, (double*)sc, S, m, r, lds_, alpha);
+    HIP_TRY(hipGetLastError());
+    S = (const double*)sc;
+  }
+  double* out = Y;
+  int64_t ldo = ldy;
+  if (beta != 0.0) {
+    void* tmp = nullptr;
+    ldo = round_up(N, 32);
+    HFMI_TRY(ctx_ws(ctx, WS_STAGE, (size_t)ldo * r * sizeof(double), &tmp));
+    out = (double*)tmp;
+  }
+  for (int r0 = 0; r0 < r; r0 += 256) {
+    const int rp = (r - r0 < 256) ? (r - r0) : 256;
+    HFMI_TRY(nn_panel(ctx, A, lda, m, S + r0, lds_, rp, out + (int64_t)r0 * ldo, ldo, N));
+  }
+  if (beta != 0.0) {
+    if (beta != 1.0) HFMI_TRY(launch_scale(ctx, Y, ldy, N, r, beta));
+    HFMI_TRY(launch_axpy(ctx, Y, ldy, 1.0, out, ldo, N, r));
+  }
+  return HFMI_OK;
+}

@@ -1,0 +1,163 @@
+// Internal declarations shared by the libhfmi translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "hfmi.h"
+
+// ------------------------------------------------------------------ errors
+void hfmi_set_error(const char* fmt, ...);
+#define HFMI_FAIL(code, ...)      \
+  do {                            \
+    hfmi_set_error(__VA_ARGS__);  \
+    return (code);                \
+  } while (0)
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      hfmi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return HFMI_ERR_HIP;                                                                     \
+    }                                                                                          \
+  } while (0)
+#define HFMI_TRY(expr)        \
+  do {                        \
+    int _s = (expr);          \
+    if (_s != HFMI_OK) return _s; \
+  } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------ objects
+enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_NSLOTS };
+
+struct hfmi_block {
+  hfmi_ctx* ctx;
+  double* p;
+  int64_t N;
+  int nvec;
+  int64_t ld;
+  bool owner;
+};
+
+// Small dense matrices live in one fixed device arena (row-major, ld = SM_LD).
+#define SM_MAXK 256
+#define SM_LD 256
+enum { SM_GRAM = 0, SM_R, SM_RINV, SM_RTOT, SM_T, SM_V, SM_TMP, SM_TMP2, SM_NSLOTS };
+
+struct hfmi_status_words {  // device-resident, read back by the host after small kernels
+  double min_pivot_ratio;   // min_j pivot_j / G_jj
+  double gram_dev;          // || D^-1/2 G D^-1/2 - I ||_F  (orthonormality defect of the input)
+  double offdiag;           // Jacobi: final off-diagonal norm / Frobenius norm
+  int shifted;              // Cholesky needed a diagonal shift
+  int failed;               // breakdown even after shifting / not converged
+  int sweeps;               // Jacobi sweeps used
+  int pad;
+};
+
+struct hfmi_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t ev0, ev1;
+  int num_cus;
+  void* ws[WS_NSLOTS];
+  size_t ws_bytes[WS_NSLOTS];
+  double* small;                  // SM_NSLOTS * SM_MAXK * SM_LD doubles
+  hfmi_status_words* status_dev;  // device
+  hfmi_status_words* status_host; // pinned
+  void* pinned;                   // pinned host staging
+  size_t pinned_bytes;
+  std::vector<hfmi_block*> tmp_blocks;  // cached temporaries for the fused solves
+};
+
+static inline double* sm_ptr(hfmi_ctx* c, int slot) { return c->small + (size_t)slot * SM_MAXK * SM_LD; }
+int ctx_ws(hfmi_ctx* ctx, int slot, size_t bytes, void** out);
+int ctx_pinned(hfmi_ctx* ctx, size_t bytes, void** out);
+int ctx_tmp_block(hfmi_ctx* ctx, int idx, int64_t N, int nvec, hfmi_block** out);
+
+struct hfmi_csr {
+  hfmi_ctx* ctx;
+  int64_t nrows, ncols, nnz;
+  int64_t* indptr;
+  int32_t* indices;
+  double* data;
+  double* inv_diag;  // Jacobi preconditioner (lazy)
+};
+
+enum hfmi_op_kind { OP_SNAPSHOT_GRAM, OP_JTJ, OP_JJT, OP_DENSE_SYM, OP_CSR, OP_CSR_PCG, OP_COMPOSE3, OP_HOST };
+
+struct hfmi_op {
+  hfmi_ctx* ctx;
+  hfmi_op_kind kind;
+  hfmi_block X;          // snapshot / Jacobian / dense block (by value: a view, not owned)
+  int ndata, q;
+  double* gamma_inv;     // device q x q row-major (ld = round_up(q,16)) or null
+  double scale;
+  const hfmi_csr* csr;
+  double rel_tol;
+  int max_iter;
+  int last_iters;
+  hfmi_op *a, *b, *c;
+  hfmi_host_apply_fn host_fn;
+  void* host_user;
+  int64_t host_N;
+  hfmi_post_apply_fn post_fn;
+  void* post_user;
+};
+
+// ------------------------------------------------------------------ kernel launchers (hfmi_gemm.hip)
+// C (m x k) = scale * A^T B (+ beta * C); A: N x m, B: N x k column-major blocks.
+// C is addressed as C[i*rs + j*cs] (device); out_colmajor selects the partial layout that makes
+// the final write coalesced when rs == 1.
+int launch_tsgemm_tn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
+                     int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req);
+// Y (N x r) = alpha * A (N x m) * S (m x r, device row-major, ld = lds, zero padded to 16 cols) + beta * Y
+int launch_tsgemm_nn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds, int r,
+                     double alpha, double beta, double* Y, int64_t ldy, int64_t N);
+
+// ------------------------------------------------------------------ kernel launchers (hfmi_misc.hip)
+int launch_fill(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, double value, bool include_pad);
+int launch_zero_pad(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld);
+int launch_copy(hfmi_ctx* ctx, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t N, int nvec);
+int launch_scale(hfmi_ctx* ctx, double* p, int64_t ld, int64_t N, int nvec, double alpha);
+int launch_axpy(hfmi_ctx* ctx, double* y, int64_t ldy, double alpha, const double* x, int64_t ldx, int64_t N, int nvec);
+int launch_randn(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, uint64_t seed, uint32_t stream, double sigma);
+int launch_philox_raw(hfmi_ctx* ctx, uint32_t* out, int64_t N, int nvec, uint64_t seed, uint32_t stream);
+// dense (N x nvec row-major, contiguous) <-> block
+int launch_dense_to_block(hfmi_ctx* ctx, const double* dense, double* p, int64_t ld, int64_t N, int nvec);
+int launch_block_to_dense(hfmi_ctx* ctx, const double* p, int64_t ld, double* dense, int64_t N, int nvec);
+int launch_block_to_dense_ld(hfmi_ctx* ctx, const double* p, int64_t ld, double* dense, int64_t ldd, int64_t N, int nvec);
+int launch_csr_spmm(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec,
+                    bool accumulate);
+int launch_csr_diag_inv(hfmi_ctx* ctx, hfmi_csr* M);
+// out[j] = <A_j, B_j> for j < nvec (device out)
+int launch_col_dots(hfmi_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t N, int nvec,
+                    double* out);
+// per-column updates used by PCG / MGS (coefficients on device)
+// y_j += sign * (num_j / den_j) * x_j   (den may be null -> coefficient num_j)
+int launch_col_axpy_dev(hfmi_ctx* ctx, double* y, int64_t ldy, const double* x, int64_t ldx, int64_t N, int nvec,
+                        const double* num, const double* den, double sign);
+// p_j = z_j + (num_j/den_j) * p_j
+int launch_col_xpby_dev(hfmi_ctx* ctx, double* p, int64_t ldp, const double* z, int64_t ldz, int64_t N, int nvec,
+                        const double* num, const double* den);
+// z_j = inv_diag .* r_j
+int launch_diag_scale(hfmi_ctx* ctx, double* z, int64_t ldz, const double* r, int64_t ldr, const double* inv_diag,
+                      int64_t N, int nvec);
+// small q x q (row-major) applied to each sample's q x k slab of G in place: G_i <- Gamma G_i
+int launch_gamma_apply(hfmi_ctx* ctx, double* G, int ldg, int ndata, int q, int k, const double* gamma, int ldgam);
+
+// ------------------------------------------------------------------ small dense kernels (hfmi_small.hip)
+// G (k x k, SM slot) = R^T R; writes R (upper), Rinv (upper); if rtot_accumulate, Rtot <- R * Rtot.
+// Status words (min pivot ratio, defect, shifted/failed) land in ctx->status_dev.
+int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
+                    double shift_rel, double pivot_tol);
+// T (k x k) -> eigenvalues (sorted descending) into dvals (device, k), eigenvectors into slot_v (columns).
+int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs);
+int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);
+
+// micro-benchmarks
+int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs);

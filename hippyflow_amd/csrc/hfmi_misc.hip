@@ -1,0 +1,465 @@
+// HBM-bound helper kernels: block fill/copy/axpy, the Philox probe draw, layout conversion,
+// CSR SpMM, per-vector dot products and the fused vector updates of the block PCG, plus the
+// micro-benchmarks that measure the roofline denominators in the same job.
+#include "hfmi_internal.h"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// 2-D elementwise launch geometry: x over row pairs (16 B per lane), y over vectors (grid-stride)
+static inline dim3 ew_grid(int64_t N, int nvec) {
+  const int64_t pairs = (N + 1) / 2;
+  int64_t gx = (pairs + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  int gy = nvec < 1024 ? nvec : 1024;
+  return dim3((unsigned)gx, (unsigned)gy);
+}
+
+__global__ void k_fill(double* __restrict__ p, int64_t rows, int nvec, int64_t ld, double value) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* c = p + (int64_t)j * ld;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < rows; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < rows) *reinterpret_cast<d2*>(c + t) = d2{value, value};
+      else c[t] = value;
+    }
+  }
+}
+__global__ void k_zero_pad(double* __restrict__ p, int64_t N, int nvec, int64_t ld) {
+  const int64_t padn = ld - N;
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* c = p + (int64_t)j * ld + N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padn; t += (int64_t)gridDim.x * blockDim.x) c[t] = 0.0;
+  }
+}
+int launch_fill(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, double value, bool include_pad) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  const int64_t rows = include_pad ? ld : N;
+  hipLaunchKernelGGL(k_fill, ew_grid(rows, nvec), dim3(256), 0, ctx->stream, p, rows, nvec, ld, value);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+int launch_zero_pad(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld) {
+  if (ld <= N || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_zero_pad, dim3(1, nvec < 1024 ? nvec : 1024), dim3(64), 0, ctx->stream, p, N, nvec, ld);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+__global__ void k_copy(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src, int64_t lds, int64_t N, int nvec) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* d = dst + (int64_t)j * ldd;
+    const double* s = src + (int64_t)j * lds;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) *reinterpret_cast<d2*>(d + t) = *reinterpret_cast<const d2*>(s + t);
+      else d[t] = s[t];
+    }
+  }
+}
+int launch_copy(hfmi_ctx* ctx, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t N, int nvec) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_copy, ew_grid(N, nvec), dim3(256), 0, ctx->stream, dst, ldd, src, lds, N, nvec);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+__global__ void k_scale(double* __restrict__ p, int64_t ld, int64_t N, int nvec, double alpha) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* c = p + (int64_t)j * ld;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 v = *reinterpret_cast<d2*>(c + t);
+        v.x *= alpha; v.y *= alpha;
+        *reinterpret_cast<d2*>(c + t) = v;
+      } else c[t] *= alpha;
+    }
+  }
+}
+int launch_scale(hfmi_ctx* ctx, double* p, int64_t ld, int64_t N, int nvec, double alpha) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_scale, ew_grid(N, nvec), dim3(256), 0, ctx->stream, p, ld, N, nvec, alpha);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+__global__ void k_axpy(double* __restrict__ y, int64_t ldy, double alpha, const double* __restrict__ x, int64_t ldx, int64_t N, int nvec) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* yc = y + (int64_t)j * ldy;
+    const double* xc = x + (int64_t)j * ldx;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 v = *reinterpret_cast<d2*>(yc + t);
+        const d2 u = *reinterpret_cast<const d2*>(xc + t);
+        v.x += alpha * u.x; v.y += alpha * u.y;
+        *reinterpret_cast<d2*>(yc + t) = v;
+      } else yc[t] += alpha * xc[t];
+    }
+  }
+}
+int launch_axpy(hfmi_ctx* ctx, double* y, int64_t ldy, double alpha, const double* x, int64_t ldx, int64_t N, int nvec) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_axpy, ew_grid(N, nvec), dim3(256), 0, ctx->stream, y, ldy, alpha, x, ldx, N, nvec);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+// Element map documented in oracle/philox.py (the checker): ctr = (p lo, p hi, column, stream),
+// key = (seed lo, seed hi); rows 2p and 2p+1 of the column come from one counter.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int rnd = 0; rnd < 10; ++rnd) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void k_randn(double* __restrict__ p, int64_t N, int nvec, int64_t ld, uint32_t k0, uint32_t k1, uint32_t stream, double sigma) {
+  const int64_t npairs = (N + 1) / 2;
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* c = p + (int64_t)j * ld;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)j, stream, k0, k1, x);
+      const uint64_t a = (((uint64_t)x[1] << 32) | x[0]) >> 11;
+      const uint64_t b = (((uint64_t)x[3] << 32) | x[2]) >> 11;
+      const double u1 = ((double)a + 0.5) * 0x1.0p-53;
+      const double u2 = ((double)b + 0.5) * 0x1.0p-53;
+      const double rad = sigma * sqrt(-2.0 * log(u1));
+      double sn, cs;
+      sincospi(2.0 * u2, &sn, &cs);
+      const int64_t t = 2 * q;
+      if (t + 1 < N) *reinterpret_cast<d2*>(c + t) = d2{rad * cs, rad * sn};
+      else c[t] = rad * cs;
+    }
+  }
+}
+int launch_randn(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, uint64_t seed, uint32_t stream, double sigma) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_randn, ew_grid(N, nvec), dim3(256), 0, ctx->stream, p, N, nvec, ld, (uint32_t)seed, (uint32_t)(seed >> 32), stream, sigma);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+__global__ void k_philox_raw(uint32_t* __restrict__ out, int64_t npairs, int nvec, uint32_t k0, uint32_t k1, uint32_t stream) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y)
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)j, stream, k0, k1, x);
+      uint32_t* o = out + ((int64_t)j * npairs + q) * 4;
+      o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3];
+    }
+}
+int launch_philox_raw(hfmi_ctx* ctx, uint32_t* out, int64_t N, int nvec, uint64_t seed, uint32_t stream) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_philox_raw, ew_grid(N, nvec), dim3(256), 0, ctx->stream, out, (N + 1) / 2, nvec, (uint32_t)seed, (uint32_t)(seed >> 32), stream);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ dense (N x nvec, row-major) <-> block
+// 32 x 32 tiles through LDS so both sides are read/written in 256-byte runs.
+template <bool TO_BLOCK>
+__global__ void k_transpose(const double* __restrict__ src, double* __restrict__ dst, int64_t ld, int64_t ldd, int64_t N, int nvec) {
+  __shared__ double tile[32][33];
+  const int64_t t0 = (int64_t)blockIdx.x * 32;
+  const int j0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  if (TO_BLOCK) {  // src dense[t*nvec + j], dst block[j*ld + t]
+    for (int r = ty; r < 32; r += 8) {
+      const int64_t t = t0 + r; const int j = j0 + tx;
+      if (t < N && j < nvec) tile[r][tx] = src[t * ldd + j];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int j = j0 + r; const int64_t t = t0 + tx;
+      if (t < N && j < nvec) dst[(int64_t)j * ld + t] = tile[tx][r];
+    }
+  } else {  // src block[j*ld + t], dst dense[t*nvec + j]
+    for (int r = ty; r < 32; r += 8) {
+      const int j = j0 + r; const int64_t t = t0 + tx;
+      if (t < N && j < nvec) tile[r][tx] = src[(int64_t)j * ld + t];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int64_t t = t0 + r; const int j = j0 + tx;
+      if (t < N && j < nvec) dst[t * ldd + j] = tile[tx][r];
+    }
+  }
+}
+int launch_dense_to_block(hfmi_ctx* ctx, const double* dense, double* p, int64_t ld, int64_t N, int nvec) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  dim3 grid((unsigned)((N + 31) / 32), (unsigned)((nvec + 31) / 32));
+  hipLaunchKernelGGL(k_transpose<true>, grid, dim3(256), 0, ctx->stream, dense, p, ld, (int64_t)nvec, N, nvec);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+int launch_block_to_dense_ld(hfmi_ctx* ctx, const double* p, int64_t ld, double* dense, int64_t ldd, int64_t N, int nvec) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  dim3 grid((unsigned)((N + 31) / 32), (unsigned)((nvec + 31) / 32));
+  hipLaunchKernelGGL(k_transpose<false>, grid, dim3(256), 0, ctx->stream, p, dense, ld, ldd, N, nvec);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+int launch_block_to_dense(hfmi_ctx* ctx, const double* p, int64_t ld, double* dense, int64_t N, int nvec) {
+  return launch_block_to_dense_ld(ctx, p, ld, dense, nvec, N, nvec);
+}
+
+// ------------------------------------------------------------------ CSR SpMM: Y[:, j] (+)= M X[:, j]
+// One lane per matrix row (consecutive lanes -> consecutive rows: coalesced Y stores; the gathers of X hit
+// neighbouring rows for FEM matrices), 8 vectors per pass so the row's (index, value) pairs are read once per 8.
+constexpr int SPMM_JB = 8;
+__global__ void k_csr_spmm(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                           const double* __restrict__ data, int64_t nrows, const double* __restrict__ X, int64_t ldx,
+                           double* __restrict__ Y, int64_t ldy, int nvec, int accumulate) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  const int64_t b = indptr[row], e = indptr[row + 1];
+  for (int j0 = blockIdx.y * SPMM_JB; j0 < nvec; j0 += gridDim.y * SPMM_JB) {
+    double acc[SPMM_JB];
+#pragma unroll
+    for (int jj = 0; jj < SPMM_JB; ++jj) acc[jj] = 0.0;
+    for (int64_t z = b; z < e; ++z) {
+      const double v = data[z];
+      const double* xr = X + indices[z];
+#pragma unroll
+      for (int jj = 0; jj < SPMM_JB; ++jj)
+        if (j0 + jj < nvec) acc[jj] += v * xr[(int64_t)(j0 + jj) * ldx];
+    }
+#pragma unroll
+    for (int jj = 0; jj < SPMM_JB; ++jj)
+      if (j0 + jj < nvec) {
+        double* y = Y + (int64_t)(j0 + jj) * ldy + row;
+        *y = accumulate ? *y + acc[jj] : acc[jj];
+      }
+  }
+}
+int launch_csr_spmm(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec, bool accumulate) {
+  if (M->nrows <= 0 || nvec <= 0) return HFMI_OK;
+  int gy = (nvec + SPMM_JB - 1) / SPMM_JB;
+  dim3 grid((unsigned)((M->nrows + 255) / 256), (unsigned)gy);
+  hipLaunchKernelGGL(k_csr_spmm, grid, dim3(256), 0, ctx->stream, M->indptr, M->indices, M->data, M->nrows, X, ldx, Y, ldy, nvec, accumulate ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+__global__ void k_csr_diag_inv(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                               const double* __restrict__ data, int64_t nrows, double* __restrict__ inv_diag) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  double d = 0.0;
+  for (int64_t z = indptr[row]; z < indptr[row + 1]; ++z)
+    if (indices[z] == row) d += data[z];
+  inv_diag[row] = d != 0.0 ? 1.0 / d : 1.0;
+}
+int launch_csr_diag_inv(hfmi_ctx* ctx, hfmi_csr* M) {
+  hipLaunchKernelGGL(k_csr_diag_inv, dim3((unsigned)((M->nrows + 255) / 256)), dim3(256), 0, ctx->stream, M->indptr, M->indices, M->data, M->nrows, M->inv_diag);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ per-vector dot products (deterministic)
+// grid (chunks, vectors): wave-64 shuffle reduction -> LDS across the 4 waves -> one partial per block;
+// a second kernel adds the partials in a fixed order.
+constexpr int DOT_CHUNKS = 64;
+__global__ void k_col_dots_partial(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                   int64_t N, int nvec, double* __restrict__ part) {
+  __shared__ double wsum[4];
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    const double* a = A + (int64_t)j * lda;
+    const double* b = B + (int64_t)j * ldb;
+    double s = 0.0;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        const d2 u = *reinterpret_cast<const d2*>(a + t), v = *reinterpret_cast<const d2*>(b + t);
+        s += u.x * v.x + u.y * v.y;
+      } else s += a[t] * b[t];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)j * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+__global__ void k_col_dots_final(const double* __restrict__ part, int nchunks, int nvec, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nvec) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)j * nchunks + c];
+  out[j] = s;
+}
+int launch_col_dots(hfmi_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t N, int nvec, double* out) {
+  if (nvec <= 0) return HFMI_OK;
+  void* part = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nvec * DOT_CHUNKS * sizeof(double), &part));
+  dim3 grid(DOT_CHUNKS, nvec < 1024 ? nvec : 1024);
+  hipLaunchKernelGGL(k_col_dots_partial, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, N, nvec, (double*)part);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_col_dots_final, dim3((nvec + 63) / 64), dim3(64), 0, ctx->stream, (const double*)part, DOT_CHUNKS, nvec, out);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// y_j += sign * coef_j * x_j,  coef_j = num_j / den_j (den == null: num_j); a zero denominator gives 0 (converged vector)
+__global__ void k_col_axpy_dev(double* __restrict__ y, int64_t ldy, const double* __restrict__ x, int64_t ldx, int64_t N, int nvec,
+                               const double* __restrict__ num, const double* __restrict__ den, double sign) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double coef = num[j];
+    if (den) coef = den[j] != 0.0 ? coef / den[j] : 0.0;
+    coef *= sign;
+    double* yc = y + (int64_t)j * ldy;
+    const double* xc = x + (int64_t)j * ldx;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 v = *reinterpret_cast<d2*>(yc + t);
+        const d2 u = *reinterpret_cast<const d2*>(xc + t);
+        v.x += coef * u.x; v.y += coef * u.y;
+        *reinterpret_cast<d2*>(yc + t) = v;
+      } else yc[t] += coef * xc[t];
+    }
+  }
+}
+int launch_col_axpy_dev(hfmi_ctx* ctx, double* y, int64_t ldy, const double* x, int64_t ldx, int64_t N, int nvec, const double* num, const double* den, double sign) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_col_axpy_dev, ew_grid(N, nvec), dim3(256), 0, ctx->stream, y, ldy, x, ldx, N, nvec, num, den, sign);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+__global__ void k_col_xpby_dev(double* __restrict__ p, int64_t ldp, const double* __restrict__ z, int64_t ldz, int64_t N, int nvec,
+                               const double* __restrict__ num, const double* __restrict__ den) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    const double coef = den[j] != 0.0 ? num[j] / den[j] : 0.0;
+    double* pc = p + (int64_t)j * ldp;
+    const double* zc = z + (int64_t)j * ldz;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 v = *reinterpret_cast<d2*>(pc + t);
+        const d2 u = *reinterpret_cast<const d2*>(zc + t);
+        v.x = u.x + coef * v.x; v.y = u.y + coef * v.y;
+        *reinterpret_cast<d2*>(pc + t) = v;
+      } else pc[t] = zc[t] + coef * pc[t];
+    }
+  }
+}
+int launch_col_xpby_dev(hfmi_ctx* ctx, double* p, int64_t ldp, const double* z, int64_t ldz, int64_t N, int nvec, const double* num, const double* den) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_col_xpby_dev, ew_grid(N, nvec), dim3(256), 0, ctx->stream, p, ldp, z, ldz, N, nvec, num, den);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+__global__ void k_diag_scale(double* __restrict__ z, int64_t ldz, const double* __restrict__ r, int64_t ldr, const double* __restrict__ inv_diag, int64_t N, int nvec) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* zc = z + (int64_t)j * ldz;
+    const double* rc = r + (int64_t)j * ldr;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (int64_t)gridDim.x * blockDim.x) zc[t] = inv_diag[t] * rc[t];
+  }
+}
+int launch_diag_scale(hfmi_ctx* ctx, double* z, int64_t ldz, const double* r, int64_t ldr, const double* inv_diag, int64_t N, int nvec) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_diag_scale, ew_grid(2 * N, nvec), dim3(256), 0, ctx->stream, z, ldz, r, ldr, inv_diag, N, nvec);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// G_i <- Gamma G_i for every sample's q x k slab (noise precision, operatorWrappers.py:107-109).  One
+// workgroup per sample, slab staged in LDS (q*k*8 bytes: 100 x 74 -> 59 KB).
+__global__ void k_gamma_apply(double* __restrict__ G, int ldg, int q, int k, const double* __restrict__ gamma, int ldgam) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* slab = reinterpret_cast<double*>(smem);
+  double* Gi = G + (int64_t)blockIdx.x * q * ldg;
+  for (int e = threadIdx.x; e < q * k; e += blockDim.x) slab[e] = Gi[(int64_t)(e / k) * ldg + (e % k)];
+  __syncthreads();
+  for (int e = threadIdx.x; e < q * k; e += blockDim.x) {
+    const int o = e / k, j = e % k;
+    double s = 0.0;
+    for (int p = 0; p < q; ++p) s += gamma[o * ldgam + p] * slab[p * k + j];
+    Gi[(int64_t)o * ldg + j] = s;
+  }
+}
+int launch_gamma_apply(hfmi_ctx* ctx, double* G, int ldg, int ndata, int q, int k, const double* gamma, int ldgam) {
+  const size_t shmem = (size_t)q * k * sizeof(double);
+  if (shmem > 150 * 1024) HFMI_FAIL(HFMI_ERR_INVALID, "gamma_apply: q*k slab (%zu bytes) exceeds LDS", shmem);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_gamma_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(k_gamma_apply, dim3(ndata), dim3(256), shmem, ctx->stream, G, ldg, q, k, gamma, ldgam);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------ micro-benchmarks (roofline denominators)
+__global__ __launch_bounds__(256, 1) void k_bench_mfma(double* out, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;
+}
+__global__ __launch_bounds__(256, 2) void k_bench_fma(double* out, int iters) {
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+  const double a = 1.0000001, b = 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = fma(acc[i], a, b);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  if (s == 123.456) out[0] = s;
+}
+__global__ void k_bench_copy(const d2* __restrict__ src, d2* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs) {
+  void* buf = nullptr;
+  const size_t bytes = (size_t)2 << 30;  // 1 GiB read + 1 GiB write per copy
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, bytes, &buf));
+  double* out = (double*)buf;
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  float ms = 0.f;
+  // fp64 MFMA: 4 waves/CU (one per SIMD) x 8 independent accumulators
+  const int it1 = 20000;
+  hipLaunchKernelGGL(k_bench_mfma, dim3(cus), dim3(256), 0, ctx->stream, out, 100);
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_bench_mfma, dim3(cus), dim3(256), 0, ctx->stream, out, it1);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *mfma_tflops = (double)cus * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+  // fp64 vector FMA: 8 waves/CU x 16 independent chains
+  const int it2 = 20000;
+  hipLaunchKernelGGL(k_bench_fma, dim3(cus * 2), dim3(256), 0, ctx->stream, out, 100);
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_bench_fma, dim3(cus * 2), dim3(256), 0, ctx->stream, out, it2);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *fma_tflops = (double)cus * 2 * 256 * it2 * 16 * 2.0 / (ms * 1e-3) / 1e12;
+  // HBM copy
+  const int64_t n = (int64_t)(bytes / 2 / sizeof(d2));
+  d2* src = (d2*)buf;
+  d2* dst = src + n;
+  hipLaunchKernelGGL(k_bench_copy, dim3(cus * 8), dim3(256), 0, ctx->stream, src, dst, n);
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL(k_bench_copy, dim3(cus * 8), dim3(256), 0, ctx->stream, src, dst, n);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *copy_gbs = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
+  return HFMI_OK;
+}

@@ -1,0 +1,381 @@
+// Small dense kernels of the Rayleigh-Ritz / Cholesky-QR steps: everything k x k (k <= 256) is done by
+// ONE workgroup with the matrix resident in LDS (k <= 140: k*(k+1)*8 bytes <= 160 KB), fp64 throughout.
+//
+//   k_chol_inv   : G = R^T R (upper), optional diagonal shift on breakdown, R^{-1}, running R product
+//   k_jacobi_eig : parallel cyclic Jacobi (round-robin ordering, one 2x2-block rotation phase per round),
+//                  rotations are logged and replayed on the identity by k_jacobi_vectors (one workgroup
+//                  per eigenvector-matrix row) so the eigenvector update never sits on the critical path.
+#include "hfmi_internal.h"
+
+#define SMALL_THREADS 1024
+#define EPS_D 2.220446049250313e-16
+
+__device__ __forceinline__ double block_sum(double v, double* scratch /* >= 16 doubles, LDS */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; ++w) s += scratch[w];
+  return s;
+}
+__device__ __forceinline__ double block_min(double v, double* scratch) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = scratch[0];
+  const int nw = blockDim.x >> 6;
+  for (int w = 1; w < nw; ++w) s = fmin(s, scratch[w]);
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cholesky + triangular inverse.  M points at the working k x k matrix (LDS when it fits, else a global
+// scratch slot), row-major with leading dimension ldm.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __restrict__ G, int ldg, int k,
+                                                            double* __restrict__ Rout, double* __restrict__ Rinv,
+                                                            double* __restrict__ Rtot, double* __restrict__ Rtmp,
+                                                            int ldo, int rtot_mode, double shift_rel,
+                                                            double pivot_tol, double* __restrict__ gscratch,
+                                                            int use_lds, hfmi_status_words* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
+  double* diag0 = red + 32;                            // k original diagonal entries
+  double* lds_m = diag0 + 256;
+  const int ldm = use_lds ? (k | 1) : ldo;
+  double* M = use_lds ? lds_m : gscratch;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  __shared__ int s_break;
+
+  // diag and orthonormality defect || D^-1/2 G D^-1/2 - I ||_F of the input
+  for (int i = tid; i < k; i += nthr) diag0[i] = G[i * ldg + i];
+  __syncthreads();
+  double dev = 0.0, tr = 0.0;
+  for (int e = tid; e < k * k; e += nthr) {
+    const int i = e / k, j = e % k;
+    const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+    const double dd = diag0[i] * diag0[j];
+    const double x = (dd > 0.0 ? g / sqrt(dd) : 0.0) - (i == j ? 1.0 : 0.0);
+    dev += x * x;
+    if (i == j) tr += g;
+  }
+  dev = block_sum(dev, red);
+  tr = block_sum(tr, red);
+
+  int shifted = 0, failed = 0;
+  double min_ratio = 1e300;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const double shift = attempt ? shift_rel * tr : 0.0;
+    for (int e = tid; e < k * k; e += nthr) {
+      const int i = e / k, j = e % k;
+      double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+      if (i == j) g += shift;
+      M[i * ldm + j] = (j >= i) ? g : 0.0;
+    }
+    if (tid == 0) s_break = 0;
+    __syncthreads();
+    double ratio_local = 1e300;
+    for (int j = 0; j < k; ++j) {
+      const double piv = M[j * ldm + j];
+      const double ref = diag0[j] + shift;
+      if (!(piv > pivot_tol * ref) || !(ref > 0.0)) {  // uniform decision: every thread reads the same words
+        if (tid == 0) s_break = 1;
+        break;
+      }
+      ratio_local = fmin(ratio_local, piv / ref);
+      const double rjj = sqrt(piv);
+      const double inv = 1.0 / rjj;
+      __syncthreads();
+      for (int c = j + tid; c < k; c += nthr) M[j * ldm + c] = (c == j) ? rjj : M[j * ldm + c] * inv;
+      __syncthreads();
+      // trailing update of the upper triangle: M[i][c] -= R[j][i] R[j][c], j < i <= c
+      const int rem = k - j - 1;
+      for (int e = tid; e < rem * rem; e += nthr) {
+        const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+        if (c >= i) M[i * ldm + c] -= M[j * ldm + i] * M[j * ldm + c];
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    if (!s_break) {
+      min_ratio = ratio_local;
+      break;
+    }
+    if (attempt == 0) shifted = 1;
+    else failed = 1;
+    __syncthreads();
+  }
+  if (failed) {
+    if (tid == 0) {
+      status->min_pivot_ratio = 0.0;
+      status->gram_dev = sqrt(dev);
+      status->shifted = shifted;
+      status->failed = 1;
+    }
+    return;
+  }
+  // R out (upper triangle, zeros below)
+  for (int e = tid; e < k * k; e += nthr) {
+    const int i = e / k, j = e % k;
+    Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+  }
+  __syncthreads();
+  // in-place inverse of the upper triangle (dtrti2 ordering): after step j the leading (j+1) block of M holds
+  // the inverse.  x_i = -(sum_{l=i}^{j-1} X[i][l] R[l][j]) / R[j][j] for i < j: one wave per row, lanes split
+  // the dot product; results are parked in diag0 until every wave has finished reading column j.
+  {
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    for (int j = 0; j < k; ++j) {
+      const double xjj = 1.0 / M[j * ldm + j];
+      for (int i = wave; i < j; i += nw) {
+        double s = 0.0;
+        for (int l = i + lane; l < j; l += 64) s += M[i * ldm + l] * M[l * ldm + j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) diag0[i] = -s * xjj;
+      }
+      __syncthreads();
+      for (int i = tid; i < j; i += nthr) M[i * ldm + j] = diag0[i];
+      if (tid == 0) M[j * ldm + j] = xjj;
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < k * k; e += nthr) {
+    const int i = e / k, j = e % k;
+    Rinv[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+  }
+  // running product of the R factors across Cholesky-QR passes: Rtot <- R * Rtot
+  if (rtot_mode == 1) {
+    for (int e = tid; e < k * k; e += nthr) {
+      const int i = e / k, j = e % k;
+      Rtot[i * ldo + j] = Rout[i * ldo + j];
+    }
+  } else if (rtot_mode == 2) {
+    __syncthreads();
+    for (int e = tid; e < k * k; e += nthr) {
+      const int i = e / k, j = e % k;
+      double s = 0.0;
+      if (j >= i)
+        for (int l = i; l <= j; ++l) s += Rout[i * ldo + l] * Rtot[l * ldo + j];
+      Rtmp[i * ldo + j] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * k; e += nthr) {
+      const int i = e / k, j = e % k;
+      Rtot[i * ldo + j] = Rtmp[i * ldo + j];
+    }
+  }
+  if (tid == 0) {
+    status->min_pivot_ratio = min_ratio;
+    status->gram_dev = sqrt(dev);
+    status->shifted = shifted;
+    status->failed = 0;
+  }
+}
+
+int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
+                    double shift_rel, double pivot_tol) {
+  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "chol_inv: k=%d out of range", k);
+  const int use_lds = (k <= 140) ? 1 : 0;
+  const size_t shmem = (32 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
+  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(SMALL_THREADS), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
+                     sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
+                     rtot_mode, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, ctx->status_dev);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+__global__ void k_small_identity(double* M, int ld, int k) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < k * ld) M[e] = ((e / ld) == (e % ld)) ? 1.0 : 0.0;
+}
+int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot) {
+  hipLaunchKernelGGL(k_small_identity, dim3((k * SM_LD + 255) / 256), dim3(256), 0, ctx->stream, sm_ptr(ctx, slot), SM_LD, k);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi eigensolver
+// ------------------------------------------------------------------------------------------------
+// round-robin tournament on n (even) players: round r in [0, n-1), pair p in [0, n/2)
+__device__ __forceinline__ void rr_pair(int n, int r, int p, int& a, int& b) {
+  if (p == 0) {
+    a = n - 1;
+    b = r;
+  } else {
+    a = (r + p) % (n - 1);
+    b = (r - p + (n - 1)) % (n - 1);
+  }
+  if (a > b) {
+    const int t = a;
+    a = b;
+    b = t;
+  }
+}
+
+#define JAC_MAX_SWEEPS 40
+
+__global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __restrict__ T, int ldt, int k,
+                                                              double* __restrict__ gwork, int use_lds,
+                                                              double2* __restrict__ rotlog, double* __restrict__ dvals,
+                                                              int* __restrict__ perm, int sort_by_abs,
+                                                              hfmi_status_words* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);                // 32
+  double2* rot = reinterpret_cast<double2*>(red + 32);          // 128 (c, s) per pair
+  double* Ad = reinterpret_cast<double*>(rot + 128);            // 256 diagonal copy / keys
+  double* lds_a = Ad + 256;
+  const int lda = use_lds ? (k | 1) : SM_LD;
+  double* A = use_lds ? lds_a : gwork;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int n = (k + 1) & ~1;  // players (one dummy if k is odd)
+  const int np = n / 2;
+
+  double fro = 0.0;
+  for (int e = tid; e < k * k; e += nthr) {
+    const int i = e / k, j = e % k;
+    const double v = 0.5 * (T[i * ldt + j] + T[j * ldt + i]);
+    A[i * lda + j] = v;
+    fro += v * v;
+  }
+  fro = block_sum(fro, red);
+  __syncthreads();
+  const double tol2 = EPS_D * EPS_D * fro;
+
+  int sweeps = 0;
+  double off2 = 0.0;
+  for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
+    off2 = 0.0;
+    for (int e = tid; e < k * k; e += nthr) {
+      const int i = e / k, j = e % k;
+      if (j > i) off2 += 2.0 * A[i * lda + j] * A[i * lda + j];
+    }
+    off2 = block_sum(off2, red);
+    __syncthreads();
+    if (off2 <= tol2) break;
+    for (int r = 0; r < n - 1; ++r) {
+      // phase 1: one rotation per pair
+      if (tid < np) {
+        int a, b;
+        rr_pair(n, r, tid, a, b);
+        double c = 1.0, s = 0.0;
+        if (b < k) {
+          const double apq = A[a * lda + b];
+          const double app = A[a * lda + a], aqq = A[b * lda + b];
+          const double g = 100.0 * fabs(apq);
+          if (apq != 0.0 && !(fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq))) {
+            const double theta = 0.5 * (aqq - app) / apq;
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(t * t + 1.0);
+            s = t * c;
+          }
+        }
+        rot[tid] = make_double2(c, s);
+        rotlog[((size_t)sweeps * (n - 1) + r) * np + tid] = make_double2(c, s);
+      }
+      __syncthreads();
+      // phase 2: every 2x2 block (P, Q) <- J_P^T * block * J_Q
+      for (int e = tid; e < np * np; e += nthr) {
+        const int P = e / np, Q = e % np;
+        int p1, q1, p2, q2;
+        rr_pair(n, r, P, p1, q1);
+        rr_pair(n, r, Q, p2, q2);
+        // a dummy player (k odd) has index >= k: its entries read as 0 and are never written; the rotation of
+        // its pair is the identity, so the real member still receives the other pairs' rotations
+        const bool r2 = q1 < k, c2 = q2 < k;
+        const double2 rp = rot[P], rq = rot[Q];
+        const double x11 = A[p1 * lda + p2];
+        const double x12 = c2 ? A[p1 * lda + q2] : 0.0;
+        const double x21 = r2 ? A[q1 * lda + p2] : 0.0;
+        const double x22 = (r2 && c2) ? A[q1 * lda + q2] : 0.0;
+        // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
+        const double y11 = rq.x * x11 - rq.y * x12, y12 = rq.y * x11 + rq.x * x12;
+        const double y21 = rq.x * x21 - rq.y * x22, y22 = rq.y * x21 + rq.x * x22;
+        // rows with J_P
+        double z11 = rp.x * y11 - rp.y * y21, z21 = rp.y * y11 + rp.x * y21;
+        double z12 = rp.x * y12 - rp.y * y22, z22 = rp.y * y12 + rp.x * y22;
+        if (P == Q) {
+          z12 = 0.0;
+          z21 = 0.0;
+        }
+        A[p1 * lda + p2] = z11;
+        if (c2) A[p1 * lda + q2] = z12;
+        if (r2) A[q1 * lda + p2] = z21;
+        if (r2 && c2) A[q1 * lda + q2] = z22;
+      }
+      __syncthreads();
+    }
+  }
+  // eigenvalues, sort descending (rank by counting; ties broken by index -> a permutation)
+  for (int i = tid; i < k; i += nthr) Ad[i] = A[i * lda + i];
+  __syncthreads();
+  for (int i = tid; i < k; i += nthr) {
+    const double ki = sort_by_abs ? fabs(Ad[i]) : Ad[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const double kj = sort_by_abs ? fabs(Ad[j]) : Ad[j];
+      if (kj > ki || (kj == ki && j < i)) ++rank;
+    }
+    perm[rank] = i;
+    dvals[rank] = Ad[i];
+  }
+  if (tid == 0) {
+    status->offdiag = fro > 0.0 ? sqrt(off2 / fro) : 0.0;
+    status->sweeps = sweeps;
+    status->failed = (sweeps >= JAC_MAX_SWEEPS && off2 > tol2) ? 1 : 0;
+  }
+}
+
+// Row i of V = e_i^T * (product of all logged rotations); one workgroup per row, the row lives in LDS.
+__global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restrict__ rotlog, int k,
+                                                        const hfmi_status_words* __restrict__ status,
+                                                        const int* __restrict__ perm, double* __restrict__ V, int ldv) {
+  __shared__ double row[SM_MAXK + 2];
+  const int n = (k + 1) & ~1, np = n / 2;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < n; j += blockDim.x) row[j] = (j == i) ? 1.0 : 0.0;
+  __syncthreads();
+  const int rounds = status->sweeps * (n - 1);
+  for (int rr = 0; rr < rounds; ++rr) {
+    const int r = rr % (n - 1);
+    if (tid < np) {
+      int a, b;
+      rr_pair(n, r, tid, a, b);
+      const double2 cs = rotlog[(size_t)rr * np + tid];
+      const double va = row[a], vb = row[b];
+      row[a] = cs.x * va - cs.y * vb;
+      row[b] = cs.y * va + cs.x * vb;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < k; c += blockDim.x) V[i * ldv + c] = row[perm[c]];
+  for (int c = k + tid; c < ((k + 15) & ~15); c += blockDim.x) V[i * ldv + c] = 0.0;
+}
+
+int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs) {
+  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_eig: k=%d out of range", k);
+  const int use_lds = (k <= 138) ? 1 : 0;
+  const int n = (k + 1) & ~1;
+  const size_t log_bytes = (size_t)JAC_MAX_SWEEPS * (n - 1) * (n / 2) * sizeof(double2) + 1024 * sizeof(int);
+  void* logv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_MISC, log_bytes, &logv));
+  double2* rotlog = (double2*)logv;
+  int* perm = (int*)((char*)logv + (size_t)JAC_MAX_SWEEPS * (n - 1) * (n / 2) * sizeof(double2));
+  const size_t shmem = (32 + 256 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(SMALL_THREADS), shmem, ctx->stream, sm_ptr(ctx, slot_t), SM_LD, k,
+                     sm_ptr(ctx, SM_TMP), use_lds, rotlog, dvals, perm, sort_by_abs, ctx->status_dev);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
+                     sm_ptr(ctx, slot_v), SM_LD);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}

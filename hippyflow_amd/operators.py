@@ -1,0 +1,436 @@
+"""Linear operators behind the reference's duck-typed protocol
+(``mult(x, y)``, optional ``matMvMult(X, Y)``, ``init_vector(x, dim)``),
+each backed by an ``hfmi_op`` (include/hfmi.h) so that its block application is a
+HIP kernel sequence on the GPU.
+
+Reference counterparts (file:line under /root/reference/hippyflow):
+
+* ``LowRankOperator`` / ``SnapshotGramOperator``  hp.LowRankOperator(ones/n, snapshots)      modeling/PODProjector.py:359-361
+* ``MeanJTJfromDataOperator``                     modeling/operatorWrappers.py:55-121
+* ``MeanJJTfromDataOperator``                     JJT summed/averaged: modeling/jacobian.py:169-193, activeSubspaceProjector.py:640-645
+* ``npToDeviceOperator``                          npToDolfinOperator, modeling/operatorWrappers.py:19-52 (symmetric case)
+* ``CsrOperator`` / ``CsrPCGSolver``              prior.M / prior.R and prior.Msolver (used at KLEProjector.py:163-168)
+* ``Solver2Operator``                             hp.Solver2Operator, modeling/KLEProjector.py:103,176
+* ``MassPreconditionedCovarianceOperator``        modeling/KLEProjector.py:47-69
+* ``SummedListOperator``                          modeling/activeSubspaceProjector.py:69-95
+* ``HostCallbackOperator``                        any host black box (FEniCS Jacobian actions, sparse LU):
+                                                  the role of ObservableJacobian/JTJ, modeling/jacobian.py:62-166
+* ``PriorPreconditionedProjector``                modeling/priorPreconditionedProjector.py:19-55
+* ``LowRankRectangularOperator``                  modeling/lowRankRectangularOperator.py:17-66
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .multivector import MultiVector, Vector
+
+
+class DeviceOperator:
+    """Base: owns an hfmi_op handle.  ``matMvMult`` overwrites Y unless ``accumulate=True``
+    (the reference's block operators accumulate into a zero-filled Y,
+    activeSubspaceProjector.py:219-221; overwrite is the intended behaviour)."""
+
+    def __init__(self, ctx, n_range, n_domain=None):
+        self.ctx = ctx or L.Context.default()
+        self._op = C.c_void_p()
+        self._shape = (int(n_range), int(n_range if n_domain is None else n_domain))
+        self._keep = []   # python objects the C side points into
+
+    @property
+    def shape(self):
+        return self._shape
+
+    def mpi_comm(self):
+        from .multivector import _NullComm
+        return _NullComm()
+
+    def init_vector(self, x, dim=0):
+        """dim 0: range, dim 1: domain (jacobian.py:96-115)."""
+        if dim not in (0, 1):
+            raise ValueError("dim must be 0 or 1")
+        x.init(self._shape[dim])
+
+    def matMvMult(self, X, Y, accumulate=False):
+        assert X.nvec() == Y.nvec(), "x and y have non-matching number of vectors"
+        L.call("hfmi_op_apply", self._op, X.handle, Y.handle, 1 if accumulate else 0)
+
+    def mult(self, x, y):
+        L.call("hfmi_op_apply", self._op, x._mv.handle, y._mv.handle, 0)
+
+    def transpmult(self, x, y):   # every operator on this path is self-adjoint
+        self.mult(x, y)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_op", None):
+                L.load().hfmi_op_destroy(self._op)
+                self._op = None
+        except Exception:
+            pass
+
+
+class SnapshotGramOperator(DeviceOperator):
+    """y = scale * X X^T x with X the block of snapshots (one vector per snapshot);
+    ``scale = 1/n`` reproduces hp.LowRankOperator(ones/n, LocalObservables) (PODProjector.py:359-361)."""
+
+    def __init__(self, snapshots, scale=None, ctx=None):
+        if not isinstance(snapshots, MultiVector):
+            snapshots = MultiVector.from_vectors(snapshots, ctx=ctx)
+        super().__init__(ctx or snapshots.ctx, snapshots.size())
+        self.snapshots = snapshots
+        self.scale = 1.0 / snapshots.nvec() if scale is None else float(scale)
+        L.call("hfmi_op_snapshot_gram", self.ctx.handle, snapshots.handle, self.scale, C.byref(self._op))
+
+
+def LowRankOperator(d, U, init_vector=None):
+    """hp.LowRankOperator(d, U, init) for the constant-d case the path uses (d = ones/n)."""
+    d = np.asarray(d, dtype=np.float64)
+    if not np.allclose(d, d.flat[0]):
+        raise NotImplementedError("LowRankOperator: only a constant diagonal is on the hot path (PODProjector.py:359)")
+    return SnapshotGramOperator(U, scale=float(d.flat[0]))
+
+
+class MeanJTJfromDataOperator(DeviceOperator):
+    """y = mean_i J_i^T Gamma^{-1} J_i x from a stored (ndata, q, dM) Jacobian array
+    (operatorWrappers.py:55-121).  ``scale`` defaults to 1/ndata (the np.mean at :114); pass
+    ``scale=1/(ndata*P)`` style values to pre-fold a rank average."""
+
+    def __init__(self, J, prior=None, noise_cov_inv=None, scale=None, ctx=None):
+        if isinstance(J, MultiVector):
+            raise TypeError("pass (J_block, ndata, q) through MeanJTJfromDataOperator.from_block")
+        J = np.asarray(J, dtype=np.float64)
+        assert J.ndim == 3, "J.shape must be (ndata, rank, dM)"
+        ndata, q, dM = J.shape
+        block = MultiVector.from_vectors(J.reshape(ndata * q, dM), ctx=ctx)
+        self._setup(block, ndata, q, noise_cov_inv, scale, prior, ctx)
+
+    @classmethod
+    def from_block(cls, J_block, ndata, q, noise_cov_inv=None, scale=None, prior=None):
+        self = cls.__new__(cls)
+        self._setup(J_block, ndata, q, noise_cov_inv, scale, prior, J_block.ctx)
+        return self
+
+    def _setup(self, block, ndata, q, noise_cov_inv, scale, prior, ctx):
+        DeviceOperator.__init__(self, ctx or block.ctx, block.size())
+        self._J, self.ndata, self.r, self.dM = block, int(ndata), int(q), block.size()
+        self._prior = prior
+        self._noise_cov_inv = None
+        gptr = None
+        if noise_cov_inv is not None:
+            assert hasattr(noise_cov_inv, "__matmul__")
+            self._noise_cov_inv = L.as_f64(np.asarray(noise_cov_inv, dtype=np.float64))
+            assert self._noise_cov_inv.shape == (q, q)
+            gptr = L.ptr(self._noise_cov_inv)
+        self.scale = 1.0 / ndata if scale is None else float(scale)
+        L.call("hfmi_op_jtj", self.ctx.handle, block.handle, int(ndata), int(q), gptr, self.scale, C.byref(self._op))
+
+    @property
+    def J(self):
+        return self._J
+
+    @property
+    def prior(self):
+        return self._prior
+
+    @property
+    def noise_cov_inv(self):
+        return self._noise_cov_inv
+
+
+class MeanJJTfromDataOperator(DeviceOperator):
+    """Output-space counterpart y = mean_i J_i J_i^T x (acts on vectors of length q)."""
+
+    def __init__(self, J, scale=None, ctx=None):
+        if isinstance(J, tuple):
+            block, ndata, q = J
+        else:
+            J = np.asarray(J, dtype=np.float64)
+            ndata, q, dM = J.shape
+            block = MultiVector.from_vectors(J.reshape(ndata * q, dM), ctx=ctx)
+        super().__init__(ctx or block.ctx, q)
+        self._J, self.ndata, self.r = block, int(ndata), int(q)
+        self.scale = 1.0 / ndata if scale is None else float(scale)
+        L.call("hfmi_op_jjt", self.ctx.handle, block.handle, int(ndata), int(q), self.scale, C.byref(self._op))
+
+
+class npToDeviceOperator(DeviceOperator):
+    """Dense SYMMETRIC matrix behind the protocol (npToDolfinOperator, operatorWrappers.py:19-52, for the
+    self-adjoint operators of this path; config 2's explicit covariance)."""
+
+    def __init__(self, npArray, ctx=None):
+        if isinstance(npArray, MultiVector):
+            block = npArray
+        else:
+            npArray = np.asarray(npArray, dtype=np.float64)
+            assert len(npArray.shape) == 2 and npArray.shape[0] == npArray.shape[1]
+            block = MultiVector.from_vectors(npArray, ctx=ctx)      # symmetric: rows == columns
+        super().__init__(ctx or block.ctx, block.size())
+        self.matrix = block
+        L.call("hfmi_op_dense_sym", self.ctx.handle, block.handle, C.byref(self._op))
+
+
+class _Csr:
+    def __init__(self, M, ctx):
+        import scipy.sparse as sp
+        M = sp.csr_matrix(M)
+        M.sort_indices()
+        self.shape = M.shape
+        self.indptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+        self.data = np.ascontiguousarray(M.data, dtype=np.float64)
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        L.call("hfmi_csr_create", ctx.handle, M.shape[0], M.shape[1], int(M.nnz), L.ptr(self.indptr),
+               L.ptr(self.indices), L.ptr(self.data), C.byref(self.handle))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.load().hfmi_csr_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class CsrOperator(DeviceOperator):
+    """Sparse matrix operator y = M x (prior.M, prior.R; the encoder step hp.MatMvMult(B, decoder, encoder))."""
+
+    def __init__(self, M, ctx=None):
+        ctx = ctx or L.Context.default()
+        self.csr = M if isinstance(M, _Csr) else _Csr(M, ctx)
+        super().__init__(ctx, self.csr.shape[0], self.csr.shape[1])
+        L.call("hfmi_op_csr", self.ctx.handle, self.csr.handle, C.byref(self._op))
+
+
+class CsrPCGSolver(DeviceOperator):
+    """Solver object for an SPD sparse matrix (prior.Msolver): ``solve(y, x)`` gives y = M^{-1} x by
+    Jacobi-preconditioned CG on the device; as an operator it IS hp.Solver2Operator(Msolver)."""
+
+    def __init__(self, M, rel_tol=1e-13, max_iter=500, ctx=None):
+        ctx = ctx or L.Context.default()
+        self.csr = M if isinstance(M, _Csr) else _Csr(M, ctx)
+        super().__init__(ctx, self.csr.shape[0])
+        L.call("hfmi_op_csr_pcg", self.ctx.handle, self.csr.handle, float(rel_tol), int(max_iter), C.byref(self._op))
+
+    def solve(self, y, x):
+        self.mult(x, y)
+
+
+class HostCallbackOperator(DeviceOperator):
+    """A host black box plugged into the device solve (FEniCS/hIPPYlib PDE solves stay on the host).
+
+    ``fn`` is one of: a callable mapping an (N, k) array to an (N, k) array; an object with
+    ``matMvMult_np(X) -> Y``; an object with ``solve(y, x)`` or ``mult(x, y)`` on 1-D numpy arrays
+    (applied column by column, like hp.MatMvMult's fallback loop)."""
+
+    def __init__(self, fn, N, ctx=None):
+        super().__init__(ctx, N)
+        self.fn = fn
+        self.error = None
+
+        def _cb(user, w_ptr, y_ptr, n, k):
+            try:
+                W = np.ctypeslib.as_array(w_ptr, shape=(k, n))    # one vector per row
+                Y = np.ctypeslib.as_array(y_ptr, shape=(k, n))
+                if callable(fn) and not hasattr(fn, "mult") and not hasattr(fn, "solve"):
+                    Y[...] = np.asarray(fn(W.T)).T
+                elif hasattr(fn, "matMvMult_np"):
+                    Y[...] = np.asarray(fn.matMvMult_np(W.T)).T
+                elif hasattr(fn, "solve"):
+                    for j in range(k):
+                        fn.solve(Y[j], W[j])
+                else:
+                    for j in range(k):
+                        fn.mult(W[j], Y[j])
+                return 0
+            except Exception as exc:  # never let an exception cross the C boundary
+                self.error = exc
+                return 1
+
+        self._cb = L.HOST_APPLY_FN(_cb)
+        L.call("hfmi_op_host_callback", self.ctx.handle, self._cb, None, int(N), C.byref(self._op))
+
+    def _raise_pending(self):
+        if self.error is not None:
+            exc, self.error = self.error, None
+            raise exc
+
+    def matMvMult(self, X, Y, accumulate=False):
+        try:
+            super().matMvMult(X, Y, accumulate)
+        except L.HfmiError:
+            self._raise_pending()
+            raise
+
+    def mult(self, x, y):
+        try:
+            super().mult(x, y)
+        except L.HfmiError:
+            self._raise_pending()
+            raise
+
+    def solve(self, y, x):
+        self.mult(x, y)
+
+
+class ComposedOperator(DeviceOperator):
+    """y = c(b(a x))."""
+
+    def __init__(self, a, b, c):
+        super().__init__(a.ctx, c.shape[0], a.shape[1])
+        self._keep = [a, b, c]
+        L.call("hfmi_op_compose3", self.ctx.handle, a._op, b._op, c._op, C.byref(self._op))
+
+
+def as_device_operator(obj, N=None, ctx=None):
+    """Coerce the kinds of objects the reference passes as A / B / B^{-1} into device operators."""
+    if isinstance(obj, DeviceOperator):
+        return obj
+    if hasattr(obj, "_device_operator"):
+        return obj._device_operator()
+    try:
+        import scipy.sparse as sp
+        if sp.issparse(obj):
+            return CsrOperator(obj, ctx=ctx)
+    except ImportError:
+        pass
+    if isinstance(obj, np.ndarray) and obj.ndim == 2:
+        return npToDeviceOperator(obj, ctx=ctx)
+    if callable(obj) or hasattr(obj, "mult") or hasattr(obj, "solve") or hasattr(obj, "matMvMult_np"):
+        if N is None:
+            raise ValueError("as_device_operator: vector length needed to wrap a host operator")
+        return HostCallbackOperator(obj, N, ctx=ctx)
+    raise TypeError("cannot use %r as an operator" % (type(obj),))
+
+
+class Solver2Operator:
+    """hp.Solver2Operator(S): ``mult(x, y)`` = ``S.solve(y, x)`` (KLEProjector.py:103)."""
+
+    def __init__(self, solver, mpi_comm=None, init_vector=None):
+        self.solver = solver
+        self._init_vector = init_vector
+
+    def init_vector(self, x, dim):
+        if self._init_vector is not None:
+            self._init_vector(x, dim)
+        elif hasattr(self.solver, "init_vector"):
+            self.solver.init_vector(x, dim)
+        else:
+            raise NotImplementedError("Solver2Operator: no init_vector available")
+
+    def mult(self, x, y):
+        self.solver.solve(y, x)
+
+    def _device_operator(self):
+        s = self.solver
+        return s if isinstance(s, DeviceOperator) else as_device_operator(s, getattr(s, "N", None))
+
+
+class MassPreconditionedCovarianceOperator:
+    """Linear operator M C M (KLEProjector.py:47-69)."""
+
+    def __init__(self, C, M):
+        self.C = C
+        self.M = M
+        self._dev = None
+
+    def mpi_comm(self):
+        return self.M.mpi_comm()
+
+    def init_vector(self, x, dim):
+        self.M.init_vector(x, dim)
+
+    def _device_operator(self):
+        if self._dev is None:
+            Md = as_device_operator(self.M)
+            Cd = as_device_operator(self.C, Md.shape[0], Md.ctx)
+            self._dev = ComposedOperator(Md, Cd, Md)
+        return self._dev
+
+    def mult(self, x, y):
+        self._device_operator().mult(x, y)
+
+    def matMvMult(self, X, Y):
+        self._device_operator().matMvMult(X, Y)
+
+
+class SummedListOperator:
+    """Mean (or sum) of a list of operators of equal dimension (activeSubspaceProjector.py:69-95).
+    The accumulator starts from zero (the reference seeds it with a copy of the incoming y, :83-86,
+    which is only a mean when y arrives zero-filled -- SURVEY.md section 3.6)."""
+
+    def __init__(self, operators, communicator=None, average=True):
+        assert type(operators) is list
+        self.operators = operators
+        self.average = average
+
+    def init_vector(self, x, dim=0):
+        self.operators[0].init_vector(x, dim)
+
+    def mult(self, x, y):
+        temp = Vector(y)
+        temp.zero()
+        for op in self.operators:
+            op.mult(x, y)
+            temp.axpy(1.0, y)
+        y.zero()
+        y.axpy(1.0 / float(len(self.operators)) if self.average else 1.0, temp)
+
+    def matMvMult(self, X, Y):
+        temp = MultiVector(Y)
+        temp.zero()
+        from .multivector import MatMvMult
+        for op in self.operators:
+            MatMvMult(op, X, Y)
+            temp.axpy(1.0, Y)
+        Y.zero()
+        Y.axpy(1.0 / float(len(self.operators)) if self.average else 1.0, temp)
+
+
+class PriorPreconditionedProjector:
+    """y = U U^T C^{-1} x (priorPreconditionedProjector.py:19-55)."""
+
+    def __init__(self, U, Cinv, my_init_vector):
+        self.U = U
+        self.Cinv = Cinv
+        self.my_init_vector = my_init_vector
+        self.Cinvx = Vector(ctx=U.ctx)
+        self.my_init_vector(self.Cinvx, 0)
+
+    def init_vector(self, x, dim):
+        self.my_init_vector(x, dim)
+
+    def mult(self, x, y):
+        self.Cinv.mult(x, self.Cinvx)
+        UtCinvx = self.U.dot_v(self.Cinvx)
+        y.zero()
+        self.U.reduce(y, UtCinvx)
+
+
+class LowRankRectangularOperator:
+    """A = U s V^T (lowRankRectangularOperator.py:17-66)."""
+
+    def __init__(self, U, s, V, U_init_vector=None, V_init_vector=None):
+        self.U, self.s, self.V = U, np.asarray(s, dtype=np.float64), V
+        self.U_init_vector, self.V_init_vector = U_init_vector, V_init_vector
+
+    def init_vector(self, x, dim):
+        if dim == 0:
+            assert self.U_init_vector is not None
+            self.U_init_vector(x)
+        elif dim == 1:
+            assert self.V_init_vector is not None
+            self.V_init_vector(x)
+        else:
+            raise ValueError("dim must be 0 or 1")
+
+    def mult(self, x, y):
+        Vtx = self.V.dot_v(x)
+        y.zero()
+        self.U.reduce(y, self.s * Vtx)
+
+    def transpmult(self, x, y):
+        Utx = self.U.dot_v(x)
+        y.zero()
+        self.V.reduce(y, self.s * Utx)

@@ -1,0 +1,447 @@
+"""Model-based projectors: the callers of the randomized eigensolve (SURVEY.md section 8a a10-a12, 8b
+"Projector classes").  Same class names, constructor arguments, parameter keys/defaults, method
+names, return tuples, stored attributes and saved-file names as the reference:
+
+  ActiveSubspaceProjector / ActiveSubspaceParameterList   hippyflow/modeling/activeSubspaceProjector.py:33-66,252-673
+  KLEProjector / KLEParameterList                         hippyflow/modeling/KLEProjector.py:30-45,72-199
+  PODProjector / PODParameterList                         hippyflow/modeling/PODProjector.py:35-49,52-389
+  PODProjectorFromData                                    hippyflow/modeling/PODProjector.py:666-852
+
+FEniCS/hIPPYlib PDE work stays a host black box.  What the reference obtains by PDE solves is
+supplied here through small duck-typed hooks on the ``observable`` / ``prior`` arguments:
+
+* snapshots (POD):  ``observable.sample_observables(n, prior, noise)`` -> (n, N) array (or a
+  MultiVector with one snapshot per vector) -- the loop of PODProjector.py:343-357;
+* Jacobians (AS):   ``observable.jacobian_data(n)`` -> (n, q, N) array or (MultiVector, n, q) of this
+  rank's linearised samples (the materialised form of Js, activeSubspaceProjector.py:389),
+  or ``observable.jtj_host_operator()`` / ``jjt_host_operator()`` -> a host operator
+  (``matMvMult_np``) for the serialized black-box route (:163-248);
+* prior:            ``R`` (sparse matrix or operator) and ``Rsolver`` (``solve(y, x)``), or ``Hlr``;
+                    ``M`` (sparse), optional ``Msolver``; for KLE either ``Rsolver`` or an explicit
+                    covariance operator ``C``.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _lib as L
+from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
+from .multivector import MatMvMult, MultiVector, Vector
+from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
+                        MeanJJTfromDataOperator, MeanJTJfromDataOperator, SnapshotGramOperator, Solver2Operator,
+                        as_device_operator)
+from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
+from .utilities import mv_to_dense
+
+
+class ParameterList(object):
+    """hp.ParameterList: {name: [default, help]} with item access on the values."""
+
+    def __init__(self, data):
+        self.data = data
+
+    def __getitem__(self, key):
+        if key in self.data:
+            return self.data[key][0]
+        raise ValueError(key)
+
+    def __setitem__(self, key, value):
+        if key in self.data:
+            self.data[key][0] = value
+        else:
+            raise ValueError(key)
+
+    def __contains__(self, key):
+        return key in self.data
+
+    def keys(self):
+        return self.data.keys()
+
+    def showMe(self, indent=""):
+        for k in sorted(self.data.keys()):
+            print(indent, "---")
+            print(indent, k, "(default):", self.data[k][0])
+            print(indent, self.data[k][1])
+
+
+def ActiveSubspaceParameterList():
+    """activeSubspaceProjector.py:33-66 (same keys, same defaults)."""
+    parameters = {}
+    parameters['samples_per_process'] = [64, 'Number of samples per process']
+    parameters['jacobian_data_per_process'] = [512, 'Number of samples per process']
+    parameters['error_test_samples'] = [50, 'Number of samples for error test']
+    parameters['rank'] = [128, 'Rank of subspace']
+    parameters['jacobian_rank'] = [128, 'Rank of Jacobians generated']
+    parameters['control_jacobian_rank'] = [None, 'Rank of control Jacobians generated']
+    parameters['oversampling'] = [10, 'Oversampling parameter for randomized algorithms']
+    parameters['double_loop_samples'] = [20, 'Number of samples used in double loop MC approximation']
+    parameters['verbose'] = [True, 'Boolean for printing']
+    parameters['input_decoder_name'] = ['_input_decoder', 'string for naming']
+    parameters['output_decoder_name'] = ['_output_decoder', 'string for naming']
+    parameters['initialize_samples'] = [False, 'Boolean for the initialization of samples']
+    parameters['serialized_sampling'] = [True, 'Boolean for the serialization of sampling on a process']
+    parameters['observable_constructor'] = [None, 'observable constructor function, assumed to take a mesh, and kwargs']
+    parameters['observable_kwargs'] = [{}, 'kwargs used when instantiating multiple local instances of observables']
+    parameters['output_directory'] = [None, 'output directory for saving arrays and plots']
+    parameters['plot_label_suffix'] = ['', 'suffix for plot label']
+    parameters['save_and_plot'] = [True, 'Boolean for saving data and plots (only False for unit testing)']
+    parameters['store_Omega'] = [False, 'Boolean for storing Gaussian random matrix (only True for unit testing)']
+    parameters['ms_given'] = [False, 'Boolean for passing ms into serialized AS construction (only True for unit testing)']
+    return ParameterList(parameters)
+
+
+def PODParameterList():
+    """PODProjector.py:35-49."""
+    parameters = {}
+    parameters['sample_per_process'] = [100, 'Number of samples per process']
+    parameters['data_per_process'] = [250, 'Number of data per process']
+    parameters['rank'] = [20, 'Rank of subspace']
+    parameters['oversampling'] = [10, 'Oversampling parameter for randomized algorithms']
+    parameters['verbose'] = [True, 'Boolean for printing']
+    parameters['output_directory'] = [None, 'output directory for saving arrays and plots']
+    parameters['plot_label_suffix'] = ['', 'suffix for plot label']
+    return ParameterList(parameters)
+
+
+def KLEParameterList():
+    """KLEProjector.py:30-45."""
+    parameters = {}
+    parameters['error_test_samples'] = [50, 'Number of samples for error test']
+    parameters['rank'] = [128, 'Rank of subspace']
+    parameters['oversampling'] = [10, 'Oversampling parameter for randomized algorithms']
+    parameters['verbose'] = [True, 'Boolean for printing']
+    parameters['output_directory'] = ['./data/', 'output directory for saving arrays and plots']
+    parameters['plot_label_suffix'] = ['', 'suffix for plot label']
+    parameters['save_and_plot'] = [True, 'save and plot or not']
+    parameters['input_decoder_name'] = ['KLE_decoder', 'string for naming']
+    return ParameterList(parameters)
+
+
+def _is_root():
+    return int(os.environ.get("RANK", "0")) == 0
+
+
+def _save(directory, name, array):
+    os.makedirs(directory, exist_ok=True)
+    np.save(os.path.join(directory, name), array)
+
+
+def _draw_omega(N, nvec, collective, ctx, stored=None):
+    """Probe block: every rank draws the same Philox stream (replaces rank-0 draw + bcast,
+    activeSubspaceProjector.py:433-443); a stored Omega (unit-test path) is broadcast from rank 0."""
+    if stored is not None:
+        Omega = MultiVector(stored)
+        collective.bcast(Omega, root=0)
+        return Omega
+    Omega = MultiVector(int(N), int(nvec), ctx=ctx)
+    parRandom.normal(1., Omega)
+    return Omega
+
+
+# =====================================================================================
+# Active subspace
+# =====================================================================================
+class ActiveSubspaceProjector:
+    """Projectors from the sample-averaged GN Hessian E[J^T J] (input) and E[J J^T] (output)."""
+
+    def __init__(self, observable, prior, control_distribution=None, mesh_constructor_comm=None,
+                 collective=NullCollective(), parameters=ActiveSubspaceParameterList(), ctx=None):
+        self.parameters = parameters
+        self.observable = observable
+        self.prior = prior
+        self.control_distribution = control_distribution
+        self.mesh_constructor_comm = mesh_constructor_comm
+        self.collective = collective
+        self.ctx = ctx or L.Context.default()
+        self.Js = None            # (block, ndata, q) once materialised
+        self.d_GN = None
+        self.V_GN = None
+        self.d_GN_noprior = None
+        self.V_GN_noprior = None
+        self.prior_preconditioned = None
+        self.d_NG = None
+        self.U_NG = None
+        self.Omega_GN = None
+        self.Omega_NG = None
+
+    # ---- data source -----------------------------------------------------------------
+    def _initialize_batched_samples(self):
+        """Materialise this rank's Jacobians in HBM (counterpart of :347-397)."""
+        n = self.parameters['samples_per_process']
+        data = self.observable.jacobian_data(n)
+        if isinstance(data, tuple):
+            block, ndata, q = data
+        else:
+            data = np.asarray(data, dtype=np.float64)
+            ndata, q, dM = data.shape
+            block = MultiVector.from_vectors(data.reshape(ndata * q, dM), ctx=self.ctx)
+        assert ndata == n, "observable returned %d samples, samples_per_process is %d" % (ndata, n)
+        self.Js = (block, int(ndata), int(q))
+
+    def _local_operator(self, operation):
+        """The per-rank averaged operator.  Batched: device kernels over stored Jacobians.
+        Serialized: the observable's host black box, re-applied every pass."""
+        if self.parameters['serialized_sampling'] and not self.parameters['ms_given'] and \
+                hasattr(self.observable, 'jtj_host_operator'):
+            host = self.observable.jtj_host_operator() if operation == 'JTJ' else self.observable.jjt_host_operator()
+            n = self.observable.input_dimension() if operation == 'JTJ' else self.observable.output_dimension()
+            return HostCallbackOperator(host, n, ctx=self.ctx)
+        if self.Js is None:
+            self._initialize_batched_samples()
+        block, ndata, q = self.Js
+        if operation == 'JTJ':
+            return MeanJTJfromDataOperator.from_block(block, ndata, q, prior=self.prior)
+        return MeanJJTfromDataOperator((block, ndata, q))
+
+    # ---- public API ------------------------------------------------------------------
+    def construct_input_subspace(self, prior_preconditioned=True, name_suffix=None):
+        if self.parameters['serialized_sampling']:
+            return self._construct_serialized_jacobian_subspace(prior_preconditioned=prior_preconditioned, operation='JTJ',
+                                                                name_suffix=name_suffix)
+        return self._construct_input_subspace_batched(prior_preconditioned=prior_preconditioned, name_suffix=name_suffix)
+
+    def construct_output_subspace(self, name_suffix=None):
+        if self.parameters['serialized_sampling']:
+            return self._construct_serialized_jacobian_subspace(operation='JJT', name_suffix=name_suffix)
+        return self._construct_output_subspace_batched(name_suffix=name_suffix)
+
+    def _construct_input_subspace_batched(self, prior_preconditioned=True, name_suffix=None):
+        return self._construct(operation='JTJ', prior_preconditioned=prior_preconditioned, name_suffix=name_suffix,
+                               wrapper=CollectiveOperator)
+
+    def _construct_output_subspace_batched(self, name_suffix=None):
+        return self._construct(operation='JJT', prior_preconditioned=False, name_suffix=name_suffix, wrapper=CollectiveOperator)
+
+    def _construct_serialized_jacobian_subspace(self, prior_preconditioned=True, operation='JTJ', name_suffix=None):
+        return self._construct(operation=operation, prior_preconditioned=prior_preconditioned and operation == 'JTJ',
+                               name_suffix=name_suffix, wrapper=MatrixMultCollectiveOperator)
+
+    def _construct(self, operation, prior_preconditioned, name_suffix, wrapper):
+        t0 = time.time()
+        local_op = self._local_operator(operation)
+        # This averaging assumes every process has an equal number of samples (reference :429-430,509-510)
+        average_op = wrapper(local_op, self.collective, mpi_op='avg')
+        N = local_op.shape[0]
+        nvec = self.parameters['rank'] + self.parameters['oversampling']
+        stored = self.Omega_GN if operation == 'JTJ' else self.Omega_NG
+        Omega = _draw_omega(N, nvec, self.collective, self.ctx, stored=stored)
+        if self.parameters['store_Omega'] and stored is None:
+            if operation == 'JTJ':
+                self.Omega_GN = Omega
+            else:
+                self.Omega_NG = Omega
+
+        if operation == 'JTJ':
+            if prior_preconditioned:
+                if hasattr(self.prior, "R"):
+                    B, Binv = self.prior.R, self.prior.Rsolver
+                else:
+                    B, Binv = self.prior.Hlr, self.prior.Hlr
+                self.d_GN, self.V_GN = doublePassG(average_op, B, Binv, Omega, self.parameters['rank'], s=1)
+                as_decoder = self.V_GN
+                as_encoder = MultiVector(as_decoder)
+                MatMvMult(as_device_operator(B, N, self.ctx), as_decoder, as_encoder)
+            else:
+                self.d_GN, self.V_GN = doublePass(average_op, Omega, self.parameters['rank'], s=1)
+                as_decoder = self.V_GN
+                as_encoder = MultiVector(as_decoder)
+            self.prior_preconditioned = prior_preconditioned
+            self._input_subspace_construction_time = time.time() - t0
+            result = (self.d_GN, as_decoder, as_encoder)
+        else:
+            self.d_NG, self.U_NG = doublePass(average_op, Omega, self.parameters['rank'], s=1)
+            output_decoder = self.U_NG
+            output_encoder = MultiVector(output_decoder)
+            self._output_subspace_construction_time = time.time() - t0
+            result = (self.d_NG, output_decoder, output_encoder)
+
+        if self.parameters['verbose'] and _is_root():
+            which = 'Input' if operation == 'JTJ' else 'Output'
+            print((which + ' subspace construction took ' + str(time.time() - t0)[:5] + ' s').center(80))
+        if self.parameters['save_and_plot'] and _is_root() and self.parameters['output_directory'] is not None:
+            name = 'AS_' + str(int(self.parameters['samples_per_process'] * self.collective.size()))
+            if name_suffix is not None:
+                assert type(name_suffix) is str
+                name += name_suffix
+            out = self.parameters['output_directory']
+            if operation == 'JTJ':
+                _save(out, name + self.parameters['input_decoder_name'], mv_to_dense(self.V_GN))
+                _save(out, name + '_d_GN', self.d_GN)
+            else:
+                _save(out, name + self.parameters['output_decoder_name'], mv_to_dense(self.U_NG))
+                _save(out, name + '_d_NG', self.d_NG)
+        return result
+
+
+# =====================================================================================
+# KLE
+# =====================================================================================
+class KLEProjector:
+    """Input subspace from the prior covariance alone (KLEProjector.py:72-199)."""
+
+    def __init__(self, prior, mesh_constructor_comm=None, collective=None, parameters=KLEParameterList(), ctx=None):
+        self.prior = prior
+        self.mesh_constructor_comm = mesh_constructor_comm
+        self.collective = collective if collective is not None else NullCollective()
+        self.parameters = parameters
+        self.ctx = ctx or L.Context.default()
+        self.noise = None
+        self.M = as_device_operator(prior.M, ctx=self.ctx)
+        self.N = self.M.shape[0]
+        if hasattr(prior, "C") and prior.C is not None:
+            self.C = as_device_operator(prior.C, self.N, self.ctx)          # explicit covariance (config 2)
+        else:
+            self.C = as_device_operator(Solver2Operator(prior.Rsolver), self.N, self.ctx)   # :103
+        self.d_KLE = None
+        self.V_KLE = None
+        self.M_orthogonal = None
+
+    def _Msolver(self):
+        ms = getattr(self.prior, "Msolver", None)
+        if ms is None:
+            ms = CsrPCGSolver(self.M.csr, ctx=self.ctx)
+        return ms
+
+    def random_input_projector(self):
+        """A random orthonormal projection basis (:114-128)."""
+        Omega = MultiVector(self.N, self.parameters['rank'] + self.parameters['oversampling'], ctx=self.ctx)
+        parRandom.normal(1., Omega)
+        Omega.orthogonalize()
+        return Omega
+
+    def construct_input_subspace(self, orthogonality='mass'):
+        t0 = time.time()
+        assert hasattr(self.prior, 'M')
+        KLE_Operator = MassPreconditionedCovarianceOperator(self.C, self.M)
+        Omega = _draw_omega(self.N, self.parameters['rank'] + self.parameters['oversampling'], self.collective, self.ctx)
+        if orthogonality.lower() == 'mass':
+            self.d_KLE, self.V_KLE = doublePassG(KLE_Operator, self.M, self._Msolver(), Omega, self.parameters['rank'], s=1)
+            self.M_orthogonal = True
+            kle_decoder = self.V_KLE
+            kle_encoder = MultiVector(kle_decoder)
+            MatMvMult(self.M, kle_decoder, kle_encoder)
+        elif orthogonality.lower() == 'identity':
+            self.d_KLE, self.V_KLE = doublePass(self.C, Omega, self.parameters['rank'], s=1)
+            self.M_orthogonal = False
+            kle_decoder = self.V_KLE
+            kle_encoder = MultiVector(kle_decoder)
+        elif orthogonality.lower() == 'prior':
+            raise NotImplementedError("orthogonality='prior' is the SLEPc Krylov-Schur route of the reference "
+                                      "(KLEProjector.py:285-334): a different algorithm, out of scope (SURVEY.md section 2.1 #3)")
+        else:
+            raise ValueError(orthogonality)
+        self._subspace_construction_time = time.time() - t0
+        if self.parameters['verbose'] and _is_root():
+            print('Construction of input subspace took ', self._subspace_construction_time, 's')
+        if _is_root() and self.parameters['save_and_plot'] and self.parameters['output_directory'] is not None:
+            _save(self.parameters['output_directory'], self.parameters['input_decoder_name'], mv_to_dense(self.V_KLE))
+            _save(self.parameters['output_directory'], 'KLE_d', self.d_KLE)
+        return self.d_KLE, kle_decoder, kle_encoder
+
+
+# =====================================================================================
+# POD
+# =====================================================================================
+class PODProjector:
+    """Output projector from sampled observables: dominant eigenpairs of E[q q^T] by a randomized
+    double pass over the snapshot-Gram operator (PODProjector.py:331-389)."""
+
+    def __init__(self, observable, prior, control_distribution=None, mesh_constructor_comm=None, collective=None,
+                 parameters=PODParameterList(), ctx=None):
+        self.parameters = parameters
+        self.observable = observable
+        self.prior = prior
+        self.control_distribution = control_distribution
+        self.mesh_constructor_comm = mesh_constructor_comm
+        self.collective = collective if collective is not None else NullCollective()   # the reference forgets the import (:77)
+        self.ctx = ctx or L.Context.default()
+        self.d = None
+        self.U_MV = None
+        self.LocalObservables = None
+
+    def set_snapshots(self, snapshots):
+        """Precomputed local snapshots: (n, N) array (q_data layout, :224-225) or a MultiVector."""
+        self.LocalObservables = snapshots if isinstance(snapshots, MultiVector) else MultiVector.from_vectors(snapshots, ctx=self.ctx)
+
+    def construct_subspace(self):
+        t0 = time.time()
+        if self.LocalObservables is None:
+            n = self.parameters['sample_per_process']
+            self.set_snapshots(self.observable.sample_observables(n, self.prior, None))     # the loop at :343-357
+        X = self.LocalObservables
+        LocalPODOperator = SnapshotGramOperator(X, scale=1.0 / X.nvec())                      # :359-361
+        GlobalPODOperator = CollectiveOperator(LocalPODOperator, self.collective, mpi_op='avg')  # :363
+        Omega_POD = _draw_omega(X.size(), self.parameters['rank'] + self.parameters['oversampling'], self.collective, self.ctx)
+        self.d, self.U_MV = doublePass(GlobalPODOperator, Omega_POD, self.parameters['rank'], s=1)   # :376
+        self._subspace_construction_time = time.time() - t0
+        if self.parameters['verbose'] and _is_root():
+            print('Construction of POD subspace took ', self._subspace_construction_time, 's')
+        if _is_root() and self.parameters['output_directory'] is not None:
+            _save(self.parameters['output_directory'], 'POD_projector', mv_to_dense(self.U_MV))
+            _save(self.parameters['output_directory'], 'POD_d', self.d)
+
+
+def weighted_l2_norm_vector(x, W):
+    """PODProjector.py:658-661."""
+    Wx = W @ x
+    norm2 = np.einsum('ij,ij->j', Wx, x)
+    return np.sqrt(norm2)
+
+
+class PODProjectorFromData:
+    """Deterministic mass-weighted POD from a snapshot matrix (PODProjector.py:666-852).
+    ``method='hep'`` (n << N) runs on the device: the n x n Gram matrix X^T M X and the back-transform
+    phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is the Jacobi kernel
+    (n <= 256) -- same steps as :812-833.  'ghep' / 'inverse_ghep' (ARPACK Lanczos on the host in the
+    reference) are not provided: there is no CPU path in this package."""
+
+    def __init__(self, Vh=None, M_output=None, ctx=None):
+        import scipy.sparse as sp
+        self.Vh = Vh
+        if M_output is None:
+            raise ValueError("PODProjectorFromData: pass the output mass matrix as a scipy sparse matrix "
+                             "(the reference assembles it with FEniCS, PODProjector.py:681-690)")
+        self.M_csr = sp.csr_matrix(M_output)
+        self.ctx = ctx or L.Context.default()
+
+    def construct_subspace(self, u_data, u_rank, shifted=True, method='hep', verify=False):
+        n_data, dim_u = u_data.shape
+        assert u_rank <= n_data, "number of samples needs to be greater than rank of projector"
+        if shifted:
+            u_shift = np.mean(u_data, axis=0)
+            u_data = u_data - u_shift
+        else:
+            u_shift = np.zeros(u_data.shape[1])
+        if method == 'hep':
+            if n_data > 256:
+                raise NotImplementedError("hep on the device handles up to 256 snapshots (one-workgroup eigensolve); "
+                                          "use PODProjector (randomized) for larger snapshot sets")
+            X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector
+            Mop = CsrOperator(self.M_csr, ctx=self.ctx)
+            MX = MultiVector(X.size(), X.nvec(), ctx=self.ctx)
+            Mop.matMvMult(X, MX)
+            UtMU = X.dot_mv(MX)                                        # :818
+            s, U = sym_eig_small(UtMU, ctx=self.ctx)                   # descending; :821-823
+            d = s[:u_rank] / n_data
+            U = np.ascontiguousarray(U[:, :u_rank])
+            from .multivector import MvDSmatMult
+            phi_mv = MultiVector(X.size(), u_rank, ctx=self.ctx)
+            Mphi_mv = MultiVector(X.size(), u_rank, ctx=self.ctx)
+            MvDSmatMult(X, U, phi_mv)                                  # :826
+            Mop.matMvMult(phi_mv, Mphi_mv)
+            norms = np.sqrt(np.diag(phi_mv.dot_mv(Mphi_mv)))           # weighted_l2_norm_vector, :829
+            MvDSmatMult(X, np.ascontiguousarray(U / norms), phi_mv)    # phi / ||phi||_M
+            Mop.matMvMult(phi_mv, Mphi_mv)                             # :830
+            phi, Mphi = phi_mv.to_dense(), Mphi_mv.to_dense()
+        elif method in ('ghep', 'inverse_ghep'):
+            raise NotImplementedError("method=%r is an ARPACK Lanczos iteration on the host in the reference "
+                                      "(PODProjector.py:743-810); the device path provides 'hep' (n <= 256 snapshots) "
+                                      "and the randomized PODProjector" % method)
+        else:
+            raise ValueError("Unavailable method")
+        if verify:
+            r = u_rank - 1 if shifted else u_rank
+            phi_orth_error = np.linalg.norm(phi[:, :r].T @ self.M_csr @ phi[:, :r] - np.eye(r))
+            print(f"Basis Orthogonality error: {phi_orth_error}")
+        return d, phi, Mphi, u_shift

@@ -1,0 +1,176 @@
+"""Randomized double-pass eigensolvers and the probe draw: the device counterparts of the hippylib
+entry points hippyflow calls (hippylib is absent from /root/reference; call sites:
+modeling/PODProjector.py:376, modeling/KLEProjector.py:163-164,177,
+modeling/activeSubspaceProjector.py:449-463,556-577,654).
+
+``doublePass(A, Omega, k, s=1)``             -> (d, U),   U^T U = I
+``doublePassG(A, B, Binv, Omega, k, s=1)``   -> (d, U),   U^T B U = I,  A U ~ B U diag(d)
+``parRandom.normal(sigma, out)``             -> N(0, sigma^2) fill of a Vector / MultiVector
+
+Two execution routes, same arithmetic:
+* fused: when A (and B, Binv) are device operators -- possibly wrapped in a CollectiveOperator --
+  one call to ``hfmi_double_pass[_g]`` keeps every intermediate in HBM; the rank average is a
+  post-apply hook that all-reduces the result block in place (RCCL over xGMI);
+* generic: any object with the reference's ``mult`` / ``matMvMult`` protocol; the steps
+  (MatMvMult, (B-)orthogonalize, dot_mv, small eigensolve, MvDSmatMult) are each a C-ABI call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .collectives import CollectiveOperator, MatrixMultCollectiveOperator
+from .multivector import MatMvMult, MultiVector, MvDSmatMult, Vector
+from .operators import DeviceOperator, Solver2Operator, as_device_operator
+
+
+class _ParRandom:
+    """hp.parRandom stand-in: counter-based Philox4x32-10 + Box-Muller on the device.  The state is
+    (seed, stream); every ``normal`` call consumes one stream, so that all ranks that make the same
+    sequence of calls draw identical numbers (no broadcast needed)."""
+
+    def __init__(self, seed=1):
+        self.seed = int(seed)
+        self.stream = 0
+
+    def reseed(self, seed, stream=0):
+        self.seed, self.stream = int(seed), int(stream)
+
+    def normal(self, sigma, out):
+        mv = out._mv if isinstance(out, Vector) else out
+        L.call("hfmi_randn_fill", mv.handle, C.c_uint64(self.seed & (2 ** 64 - 1)), C.c_uint32(self.stream & 0xFFFFFFFF), float(sigma))
+        self.stream += 1
+
+    def normal_perturb(self, sigma, out):
+        tmp = MultiVector(out._mv if isinstance(out, Vector) else out)
+        self.normal(sigma, tmp)
+        (out._mv if isinstance(out, Vector) else out).axpy(1.0, tmp)
+
+
+parRandom = _ParRandom()
+
+
+def sym_eig_small(T, sort_by_abs=False, ctx=None):
+    """np.linalg.eigh(T) + descending sort, on the device (one-workgroup Jacobi)."""
+    T = L.as_f64(T)
+    k = T.shape[0]
+    d, V = np.empty(k), np.empty((k, k))
+    L.call("hfmi_sym_eig_small", (ctx or L.Context.default()).handle, L.ptr(T), k, 1 if sort_by_abs else 0, L.ptr(d), L.ptr(V))
+    return d, V
+
+
+def _unwrap_collective(A):
+    """(local device operator, collective, mpi_op) if A is a (possibly wrapped) device operator."""
+    if isinstance(A, (CollectiveOperator, MatrixMultCollectiveOperator)):
+        local = A.local_op
+        dev = local if isinstance(local, DeviceOperator) else (local._device_operator() if hasattr(local, "_device_operator") else None)
+        return dev, A.collective, A.mpi_op
+    if isinstance(A, DeviceOperator):
+        return A, None, None
+    if hasattr(A, "_device_operator"):
+        return A._device_operator(), None, None
+    return None, None, None
+
+
+class _PostApplyHook:
+    """All-reduce of the operator's result block, called from inside the fused C solve."""
+
+    def __init__(self, dev_op, collective, mpi_op):
+        self.error = None
+
+        def _cb(user, block_handle):
+            try:
+                mv = MultiVector(ctx=dev_op.ctx, _handle=C.c_void_p(block_handle), _borrowed=True)
+                collective.allReduce(mv, mpi_op)
+                return 0
+            except Exception as exc:
+                self.error = exc
+                return 1
+
+        self.cb = L.POST_APPLY_FN(_cb)
+        self.dev_op = dev_op
+
+    def __enter__(self):
+        L.call("hfmi_op_set_post_apply", self.dev_op._op, self.cb, None)
+        return self
+
+    def __exit__(self, *exc):
+        L.call("hfmi_op_set_post_apply", self.dev_op._op, L.POST_APPLY_FN(), None)
+        return False
+
+
+def _fused(A_dev, collective, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs):
+    d = np.empty(k)
+    U = MultiVector(Omega.size(), k, ctx=Omega.ctx)
+    flags = (1 if sort_by_abs else 0) | (2 if use_mgs else 0)
+
+    def run():
+        if B_dev is None:
+            L.call("hfmi_double_pass", A_dev._op, Omega.handle, int(k), int(s), flags, L.ptr(d), U.handle)
+        else:
+            L.call("hfmi_double_pass_g", A_dev._op, B_dev._op, Binv_dev._op, Omega.handle, int(k), int(s), flags, L.ptr(d), U.handle)
+
+    if collective is not None and collective.size() > 1:
+        hook = _PostApplyHook(A_dev, collective, mpi_op)
+        with hook:
+            try:
+                run()
+            except L.HfmiError:
+                if hook.error is not None:
+                    raise hook.error
+                raise
+    else:
+        run()
+    return d, U
+
+
+def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True):
+    """Randomized double pass for the dominant k eigenpairs of a Hermitian operator A.
+    Omega: MultiVector with nvec >= k Gaussian probe vectors (not modified)."""
+    nvec = Omega.nvec()
+    assert nvec >= k
+    A_dev, coll, mpi_op = _unwrap_collective(A)
+    if fused and A_dev is not None:
+        return _fused(A_dev, coll, mpi_op, None, None, Omega, k, s, sort_by_abs, use_mgs)
+    Q = MultiVector(Omega)
+    Y = MultiVector(Omega.size(), nvec, ctx=Omega.ctx)
+    for _ in range(s):
+        MatMvMult(A, Q, Y)
+        Q.swap(Y)
+    Q.orthogonalize(L.QR_MGS if use_mgs else L.QR_AUTO)
+    AQ = MultiVector(Omega.size(), nvec, ctx=Omega.ctx)
+    MatMvMult(A, Q, AQ)
+    T = AQ.dot_mv(Q)
+    d, V = sym_eig_small(T, sort_by_abs, Omega.ctx)
+    d = d[:k].copy()
+    U = MultiVector(Omega.size(), k, ctx=Omega.ctx)
+    MvDSmatMult(Q, np.ascontiguousarray(V[:, :k]), U)
+    return d, U
+
+
+def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True):
+    """Randomized double pass for A u = lambda B u (B SPD), U^T B U = I.
+    ``Binv`` is a solver object (``solve(y, x)``) as in the reference, or an operator."""
+    nvec = Omega.nvec()
+    assert nvec >= k
+    N = Omega.size()
+    A_dev, coll, mpi_op = _unwrap_collective(A)
+    if fused and A_dev is not None:
+        B_dev = as_device_operator(B, N, Omega.ctx)
+        Binv_dev = as_device_operator(Binv, N, Omega.ctx)
+        return _fused(A_dev, coll, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs)
+    Binv_op = Binv if (hasattr(Binv, "mult") and not hasattr(Binv, "solve")) else Solver2Operator(Binv)
+    Ybar = MultiVector(N, nvec, ctx=Omega.ctx)
+    Q = MultiVector(Omega)
+    for _ in range(s):
+        MatMvMult(A, Q, Ybar)
+        MatMvMult(Binv_op, Ybar, Q)
+    Q.Borthogonalize(B, L.QR_MGS if use_mgs else L.QR_AUTO)
+    AQ = MultiVector(N, nvec, ctx=Omega.ctx)
+    MatMvMult(A, Q, AQ)
+    T = AQ.dot_mv(Q)
+    d, V = sym_eig_small(T, sort_by_abs, Omega.ctx)
+    d = d[:k].copy()
+    U = MultiVector(N, k, ctx=Omega.ctx)
+    MvDSmatMult(Q, np.ascontiguousarray(V[:, :k]), U)
+    return d, U

@@ -1,0 +1,192 @@
+/*
+ * hfmi.h -- C ABI of libhfmi.so, the MI355X (gfx950) device layer under the
+ * hippyflow model-based projectors' randomized double-pass eigensolve.
+ *
+ * The reference (hippyflow, /root/reference) has no FFI of its own: its boundary
+ * is a set of duck-typed Python protocols over the
+ * third-party hippylib package, whose only native pieces are a C++ MultiVector
+ * and a C++ mt19937 "parRandom" compiled by dolfin.  Each entry point below
+ * names the reference call site / hippylib symbol it stands in for.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns 0 on
+ *     success or a negative hfmi_status; hfmi_last_error() gives the text.
+ *   - all arithmetic is IEEE fp64.
+ *   - one hfmi_ctx per GPU; a context (and the objects made from it) is not
+ *     thread-safe; independent contexts may be used from different threads or
+ *     processes.  All work is enqueued on the context's HIP stream.
+ *   - a BLOCK is hippylib's MultiVector: nvec vectors of length N, each vector
+ *     contiguous in HBM (column-major N x nvec with leading dimension ld,
+ *     ld % 16 == 0, 128-byte aligned columns, rows N..ld-1 kept at zero).
+ *     Snapshot matrices (n snapshots of length N; PODProjector.py:340-357) and
+ *     stacked Jacobians ((ndata*q) rows of length N; operatorWrappers.py:62-64)
+ *     are blocks too: one vector per snapshot / per Jacobian row.
+ *   - host arrays are caller-owned, dense, C-ordered fp64.
+ */
+#ifndef HFMI_H
+#define HFMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFMI_VERSION 100
+
+typedef enum {
+  HFMI_OK = 0,
+  HFMI_ERR_INVALID = -1,      /* bad argument / shape mismatch (the reference asserts) */
+  HFMI_ERR_HIP = -2,          /* a HIP runtime call failed */
+  HFMI_ERR_NO_DEVICE = -3,    /* no usable gfx950 device */
+  HFMI_ERR_NUMERIC = -4,      /* breakdown (e.g. Gram matrix not SPD after shifting) */
+  HFMI_ERR_CALLBACK = -5,     /* a host callback operator returned non-zero */
+  HFMI_ERR_NOT_CONVERGED = -6 /* iterative kernel hit its iteration cap */
+} hfmi_status;
+
+/* host <-> block layouts */
+#define HFMI_LAYOUT_VECTORS 0 /* host (nvec, N): one vector per row  -- u_data / q_data / J (PODProjector.py:224-225) */
+#define HFMI_LAYOUT_DENSE 1   /* host (N, nvec): mv_to_dense layout  -- utilities/mv_utilities.py:31-41 */
+
+typedef struct hfmi_ctx hfmi_ctx;
+typedef struct hfmi_block hfmi_block;
+typedef struct hfmi_csr hfmi_csr;
+typedef struct hfmi_op hfmi_op;
+
+/* ---------------------------------------------------------------- context */
+const char* hfmi_last_error(void);
+int hfmi_version(void);
+int hfmi_device_count(int* count);
+int hfmi_ctx_create(int device, hfmi_ctx** out);
+int hfmi_ctx_destroy(hfmi_ctx* ctx);
+/* adopt an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int hfmi_ctx_set_stream(hfmi_ctx* ctx, void* hip_stream);
+int hfmi_ctx_get_stream(hfmi_ctx* ctx, void** hip_stream);
+int hfmi_ctx_synchronize(hfmi_ctx* ctx);
+int hfmi_ctx_device_info(hfmi_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
+/* HIP-event timer on the context's stream (bench.py measures kernels with it) */
+int hfmi_timer_start(hfmi_ctx* ctx);
+int hfmi_timer_stop(hfmi_ctx* ctx, double* milliseconds); /* synchronises */
+
+/* ---------------------------------------------------------------- blocks
+ * hippylib MultiVector(vector, nvec) and its copy constructor. */
+int hfmi_block_create(hfmi_ctx* ctx, int64_t N, int nvec, hfmi_block** out); /* zero-filled */
+/* wrap device memory owned by the caller (e.g. a torch tensor): ld % 16 == 0, ld >= N,
+ * dptr 128-byte aligned, rows N..ld-1 zero. */
+int hfmi_block_wrap(hfmi_ctx* ctx, double* dptr, int64_t N, int nvec, int64_t ld, hfmi_block** out);
+/* view of vectors [first, first+count) of a block (MultiVector.__getitem__) */
+int hfmi_block_view(hfmi_block* parent, int first, int count, hfmi_block** out);
+int hfmi_block_destroy(hfmi_block* b);
+int hfmi_block_info(const hfmi_block* b, int64_t* N, int* nvec, int64_t* ld, double** dptr);
+int hfmi_block_upload(hfmi_block* b, const double* host, int layout);
+int hfmi_block_download(const hfmi_block* b, double* host, int layout);
+int hfmi_block_zero(hfmi_block* b);                                 /* MultiVector.zero */
+int hfmi_block_copy(hfmi_block* dst, const hfmi_block* src);        /* copy constructor */
+int hfmi_block_scale(hfmi_block* b, double alpha);                  /* vector *= alpha */
+int hfmi_block_axpy(hfmi_block* y, double alpha, const hfmi_block* x); /* vector.axpy, all vectors */
+int hfmi_block_norms(const hfmi_block* b, double* host_norms);      /* MultiVector.norm("l2") */
+
+/* a1: the probe draw -- hp.parRandom.normal(sigma, Omega)
+ * (activeSubspaceProjector.py:433-443,536-551; PODProjector.py:365-374;
+ * KLEProjector.py:151-160).  Counter-based Philox4x32-10 + Box-Muller: every GPU
+ * regenerates the same Omega from (seed, stream), replacing collective.bcast. */
+int hfmi_randn_fill(hfmi_block* b, uint64_t seed, uint32_t stream, double sigma);
+/* the raw 32-bit stream behind it (bit-exact parity test): out[nvec][ceil(N/2)][4] */
+int hfmi_philox_raw(hfmi_block* shape_of, uint64_t seed, uint32_t stream, uint32_t* host_out);
+
+/* MultiVector.dot_mv / dot_v: out[i*nvecB + j] = <A_i, B_j>  (row-major nvecA x nvecB) */
+int hfmi_block_dot(const hfmi_block* A, const hfmi_block* B, double* host_out);
+/* MvDSmatMult / MultiVector.reduce: Y = alpha * A * S + beta * Y, S host (nvecA x nvecY) row-major */
+int hfmi_block_gemm_small(const hfmi_block* A, const double* host_S, double alpha, double beta, hfmi_block* Y);
+
+/* ---------------------------------------------------------------- sparse
+ * CSR matrix (prior.M, prior.R; PODProjectorFromData.M_csr, PODProjector.py:695-697). */
+int hfmi_csr_create(hfmi_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr,
+                    const int32_t* indices, const double* data, hfmi_csr** out);
+int hfmi_csr_destroy(hfmi_csr* m);
+
+/* ---------------------------------------------------------------- operators
+ * The reference's linear-operator protocol (mult / matMvMult / init_vector;
+ * SURVEY.md section 8b) as a tagged object.  apply = hp.MatMvMult(A, W, Y). */
+
+/* a2: hp.LowRankOperator(ones/n, snapshots)  -> Y = scale * X (X^T W)
+ *     (PODProjector.py:359-361).  X: block, one vector per snapshot. */
+int hfmi_op_snapshot_gram(hfmi_ctx* ctx, const hfmi_block* X, double scale, hfmi_op** out);
+/* a3: sample-averaged Jacobian Gram  Y = scale * sum_i J_i^T Gamma^{-1} J_i W
+ *     (MeanJTJfromDataOperator.mult, operatorWrappers.py:95-114; JTJ summed by
+ *     SummedListOperator / SeriallySampledJacobianOperator,
+ *     activeSubspaceProjector.py:82-95,163-248).  J: block of ndata*q vectors
+ *     (row o of sample i is vector i*q+o); gamma_inv host q x q or NULL. */
+int hfmi_op_jtj(hfmi_ctx* ctx, const hfmi_block* J, int ndata, int q, const double* host_gamma_inv,
+                double scale, hfmi_op** out);
+/*     output-space counterpart  Y = scale * sum_i J_i J_i^T W  (JJT, jacobian.py:169-193;
+ *     activeSubspaceProjector.py:625-673); acts on blocks of length q. */
+int hfmi_op_jjt(hfmi_ctx* ctx, const hfmi_block* J, int ndata, int q, double scale, hfmi_op** out);
+/* a4: explicit dense symmetric operator (config 2 covariance; npToDolfinOperator,
+ *     operatorWrappers.py:19-52).  C: block of N vectors of length N (symmetric). */
+int hfmi_op_dense_sym(hfmi_ctx* ctx, const hfmi_block* C, hfmi_op** out);
+/* a4/a9: sparse operator  Y = M W  (prior.M.mult, prior.R.mult; hp.MatMvMult(B, decoder, encoder)) */
+int hfmi_op_csr(hfmi_ctx* ctx, const hfmi_csr* M, hfmi_op** out);
+/*     solver object for an SPD CSR matrix: Y = M^{-1} W by Jacobi-preconditioned block CG
+ *     (prior.Msolver behind hp.Solver2Operator, KLEProjector.py:163-164) */
+int hfmi_op_csr_pcg(hfmi_ctx* ctx, const hfmi_csr* M, double rel_tol, int max_iter, hfmi_op** out);
+/*     Y = c (b (a W))  (MassPreconditionedCovarianceOperator M C M, KLEProjector.py:47-69) */
+int hfmi_op_compose3(hfmi_ctx* ctx, hfmi_op* a, hfmi_op* b, hfmi_op* c, hfmi_op** out);
+/*     host black box (FEniCS PDE solves, sparse LU ...): W and Y in HFMI_LAYOUT_VECTORS
+ *     (k, N) host arrays; return non-zero to abort.  This is how any object with the
+ *     reference's mult/matMvMult protocol plugs into the device solve. */
+typedef int (*hfmi_host_apply_fn)(void* user, const double* W_host, double* Y_host, int64_t N, int k);
+int hfmi_op_host_callback(hfmi_ctx* ctx, hfmi_host_apply_fn fn, void* user, int64_t N, hfmi_op** out);
+/*     average of a device operator over the ranks of a communicator is done by the
+ *     caller between applies (CollectiveOperator, collectiveOperator.py:31-38): a
+ *     post-apply hook called with the result block, e.g. an RCCL all-reduce. */
+typedef int (*hfmi_post_apply_fn)(void* user, hfmi_block* Y);
+int hfmi_op_set_post_apply(hfmi_op* op, hfmi_post_apply_fn fn, void* user);
+int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, int accumulate);
+int hfmi_op_destroy(hfmi_op* op);
+
+/* ---------------------------------------------------------------- QR (a7)
+ * MultiVector.orthogonalize() / Borthogonalize(B): thin QR with Q^T B Q = I,
+ * R upper triangular with positive diagonal (unique, so Q equals the
+ * reference's MGS Q to round-off).  B, BQ, host_R may be NULL.
+ * method: HFMI_QR_CHOL = (shifted) Cholesky-QR, repeated until orthonormal;
+ *         HFMI_QR_MGS  = column-by-column Gram-Schmidt with the reference's
+ *         Rutishauser re-orthogonalisation test (dependent columns zeroed). */
+#define HFMI_QR_CHOL 0
+#define HFMI_QR_MGS 1
+#define HFMI_QR_AUTO 2 /* CHOL, falling back to MGS on breakdown */
+int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int method, int* passes);
+
+/* ---------------------------------------------------------------- Rayleigh-Ritz (a8)
+ * np.linalg.eigh(T) + descending sort: symmetric k x k (host, row-major; the
+ * symmetric part is used), eigenvalues descending (by |d| if sort_by_abs),
+ * eigenvectors in the columns of V (row-major k x k).  One-workgroup parallel
+ * cyclic Jacobi in LDS. */
+int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,
+                       double* host_V);
+
+/* ---------------------------------------------------------------- full solves (a5, a6)
+ * hp.doublePass(A, Omega, r, s) / hp.doublePassG(A, B, Binv, Omega, r, s):
+ * Omega has k >= r vectors and is not modified; on return host_d[r] holds the
+ * eigenvalues (descending) and U (r vectors) the (B-)orthonormal eigenvectors.
+ * Everything stays on the device between the first apply and the final U.
+ * flags: bit 0 = sort by |d|;  bit 1 = use HFMI_QR_MGS. */
+int hfmi_double_pass(hfmi_op* A, const hfmi_block* Omega, int r, int s, int flags, double* host_d,
+                     hfmi_block* U);
+int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* Omega, int r, int s,
+                       int flags, double* host_d, hfmi_block* U);
+
+/* ---------------------------------------------------------------- instrumentation
+ * Kernel-level entry points used by bench.py / the parity tests:
+ *   C (nvecA x nvecB, device partial-summed, returned on host) = A^T B with an explicit split count
+ *   (0 = library default) and the average kernel time of `reps` back-to-back launches. */
+int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, int reps, double* host_C,
+                         double* avg_ms);
+int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms);
+/* fp64 MFMA / fp64 FMA / HBM-copy micro-benchmarks (peak denominators measured in the same job) */
+int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFMI_H */
