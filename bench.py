@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: randomized double-pass eigensolve throughput (GDoF*rank/s) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload as|pod|kle] [--quick]
+
+One "step" = one full double pass (Omega already in HBM -> eigenvalues on the host, eigenvectors in
+HBM) over one synthetic workload whose operator data is resident in HBM.  The default workload is
+BASELINE config 4 (ActiveSubspaceProjector: 512 Monte-Carlo Jacobian samples of 100 x 2e5, r=64, p=10):
+it is the configuration the metric's "1/2/4/8 GPU" clause is quoted on, it fits one GPU at N=1 (82 GB of
+Jacobians in 288 GB of HBM) and it is the one path with a real exchange step, so the SAME total work is
+timed at every N (strong scaling): the samples are sharded 512/N per rank and the block J^T J Omega is
+all-reduced (RCCL over xGMI) once per operator application.
+
+For N > 1 the driver launches this file through ``python -m torch.distributed.run`` (one rank per GPU).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet, dense FP64 matrix (= FP64 vector) peak
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="as", choices=["as", "pod", "kle"])
+    ap.add_argument("--quick", action="store_true", help="1/8-size problem (smoke / profiling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def build_workload(args, hf, rank, world):
+    from hippyflow_amd import workloads
+    scale = 8 if args.quick else 1
+    if args.workload == "as":
+        N, ns_total, q, r, p = 200000 // scale, 512, 100, 64, 10
+        assert ns_total % world == 0
+        ns_local = ns_total // world
+        wl = workloads.as_workload(N, ns_local, q=q, latent=q, rate=0.06, seed=4, first_sample=rank * ns_local, ns_total=ns_total)
+        desc = {"workload": "config4 ActiveSubspaceProjector: mean J^T J, %d samples x (%d x %d), r=%d, p=%d" % (ns_total, q, N, r, p),
+                "N": N, "samples_total": ns_total, "samples_per_gpu": ns_local, "outputs": q, "rank": r, "oversampling": p,
+                "parallelism": "sample-parallel x%d, one all-reduce(avg) of the N x k block per operator application" % world}
+        op = wl.operator
+        B = Binv = None
+    elif args.workload == "pod":
+        N, n, r, p = 500000 // scale, 2048, 128, 10
+        assert n % world == 0
+        wl = workloads.pod_workload(N, n, latent=256, rate=0.05, seed=3)
+        if world > 1:
+            raise SystemExit("pod workload: single GPU only in this bench")
+        desc = {"workload": "config3 PODProjector: %d snapshots x N=%d, r=%d, p=%d" % (n, N, r, p), "N": N, "snapshots": n,
+                "rank": r, "oversampling": p, "parallelism": "single GPU"}
+        op = wl.operator
+        B = Binv = None
+    else:
+        nx, ny, r, p = 400, 250 // scale, 64, 20
+        wl = workloads.kle_workload(nx, ny, latent=256, rate=0.08, seed=2)
+        N = wl.N
+        if world > 1:
+            raise SystemExit("kle workload: replicas only (KLEProjector.py:148-149); run at --gpus 1")
+        desc = {"workload": "config2 KLEProjector(mass): dense covariance N=%d, r=%d, p=%d" % (N, r, p), "N": N, "rank": r,
+                "oversampling": p, "parallelism": "single GPU"}
+        op = hf.MassPreconditionedCovarianceOperator(wl.C_operator, wl.M_operator)
+        B = wl.M_operator
+        Binv = hf.CsrPCGSolver(wl.M_operator.csr)
+    return wl, op, B, Binv, N, r, p, desc
+
+
+def host_reference(args, wl, Omega_host, r, hf_o, hp_o):
+    """The oracle on the SAME inputs, evaluated in factored form on the host (see workloads.py)."""
+    from hippyflow_amd import workloads
+    if args.workload == "as":
+        P = wl.P.to_dense()
+        H = workloads.as_reduced_matrix(4, wl.ns_total, wl.q, wl.latent, 0.06)
+        apply_A = lambda W: np.asfortranarray(P @ (H @ (P.T @ W)))
+        return hp_o.double_pass_blas3(apply_A, Omega_host, r)
+    if args.workload == "pod":
+        apply_A = workloads.pod_host_apply(wl, wl.W0.to_dense())
+        return hp_o.double_pass_blas3(apply_A, Omega_host, r)
+    import scipy.sparse.linalg as spla
+    F, lam, M = wl.F_host, wl.lam, wl.M
+    lu = spla.splu(M.tocsc())
+    apply_A = lambda W: np.asfortranarray(M @ (F @ (lam[:, None] * (F.T @ (M @ W)))))
+    return hp_o.double_pass_blas3(apply_A, Omega_host, r, apply_B=lambda W: M @ W, apply_Binv=lambda W: np.asfortranarray(lu.solve(np.ascontiguousarray(W))))
+
+
+def cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o):
+    """CPU port of the reference path (BLAS-3 "best-effort" form) on a bounded sample."""
+    cores = os.cpu_count() or 1
+    k = Omega_host.shape[1]
+    if args.workload == "as":
+        ns_s = 4
+        Jh = wl.J.view(0, ns_s * wl.q).to_vectors().reshape(ns_s, wl.q, N)     # dense Jacobians of 4 samples
+        W = Omega_host
+        t0 = time.perf_counter()
+        Y = hf_o.mean_jtj_block(Jh, W)
+        t_apply = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Q, _ = hp_o._qr_posdiag(Y)
+        T = Y.T @ Q
+        np.linalg.eigh(0.5 * (T + T.T))
+        U = Q @ T[:, :r]
+        t_rest = time.perf_counter() - t0
+        t_full = 2.0 * t_apply * (wl.ns_total / ns_s) + t_rest
+        sample = "dense BLAS-3 mean-JtJ apply timed on %d of %d samples (full N=%d, k=%d) and scaled linearly in samples, + QR/Rayleigh-Ritz at full size" % (ns_s, wl.ns_total, N, k)
+    elif args.workload == "pod":
+        n_s = 256
+        Xh = wl.X.view(0, n_s).to_vectors()
+        t0 = time.perf_counter()
+        Y = hf_o.snapshot_gram_block(Xh, Omega_host)
+        t_apply = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Q, _ = hp_o._qr_posdiag(Y)
+        T = Y.T @ Q
+        np.linalg.eigh(0.5 * (T + T.T))
+        t_rest = time.perf_counter() - t0
+        t_full = 2.0 * t_apply * (wl.n / n_s) + t_rest
+        sample = "BLAS-3 snapshot-Gram apply timed on %d of %d snapshots and scaled linearly, + QR/Rayleigh-Ritz at full size" % (n_s, wl.n)
+    else:
+        rows = 4000
+        Ch = wl.C.view(0, rows).to_vectors()
+        t0 = time.perf_counter()
+        _ = Ch @ Omega_host
+        t_apply = time.perf_counter() - t0
+        t_full = 2.0 * t_apply * (N / rows)
+        sample = "dense C*Omega timed on %d of %d rows and scaled linearly (sparse M, M^-1 and QR not included)" % (rows, N)
+    return {"value": N * r / t_full / 1e9, "unit": "GDoF*rank/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds_full_estimate": t_full}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import hippyflow_amd as hf
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        collective = hf.TorchCollective()
+    else:
+        collective = hf.NullCollective()
+    if hf.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU (libhfmi has no CPU path)")
+    ctx = hf.Context.default()
+
+    wl, op, B, Binv, N, r, p, desc = build_workload(args, hf, rank, world)
+    k = r + p
+    A = hf.CollectiveOperator(op, collective, mpi_op="avg") if world > 1 else op
+    hf.parRandom.reseed(1)
+    Omega = hf.MultiVector(N, k)
+    hf.parRandom.normal(1.0, Omega)          # identical on every rank (counter-based RNG): no broadcast
+
+    def step():
+        if B is None:
+            return hf.doublePass(A, Omega, r, s=1)
+        return hf.doublePassG(A, B, Binv, Omega, r, s=1)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        d, U = step()
+    barrier()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d, U = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = N * r / (elapsed / args.steps) / 1e9
+    out = {"metric": "randomized-SVD throughput (GDoF*rank/s)", "value": value, "unit": "GDoF*rank/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded latent-factor model, generated in HBM)",
+           "config": desc}
+
+    # roofline of the dominant kernel, from per-launch HIP events recorded inside the timed region
+    dom = max(prof, key=lambda kname: prof[kname]["ms"])
+    pk = prof[dom]
+    if pk["launches"] > 0 and pk["ms"] > 0:
+        avg_ms = pk["ms"] / pk["launches"]
+        tflops = pk["flops"] / pk["launches"] / (avg_ms * 1e-3) / 1e12
+        gbs = pk["bytes"] / pk["launches"] / (avg_ms * 1e-3) / 1e9
+        ai = pk["flops"] / pk["bytes"]
+        ridge = FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if ai >= ridge:
+            out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None}
+        else:
+            out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": None}
+        out["roofline"].update({"kernel": dom, "avg_launch_ms": avg_ms, "launches_per_step": pk["launches"] / args.steps,
+                                "algorithmic_flops_per_launch": pk["flops"] / pk["launches"],
+                                "algorithmic_bytes_per_launch": pk["bytes"] / pk["launches"],
+                                "arithmetic_intensity_flop_per_byte": ai, "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                "fp64_mfma_frac": tflops / FP64_MFMA_PEAK_TFLOPS})
+        out["kernels"] = {kname: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None}
+                          for kname, v in prof.items()}
+    try:
+        out["device_peaks_measured"] = ctx.bench_peaks()
+    except Exception as exc:   # the micro-benchmark is informative only
+        out["device_peaks_measured"] = {"error": str(exc)}
+
+    from oracle import hippyflow_restated as hf_o
+    from oracle import hippylib_restated as hp_o
+    Omega_host = np.asfortranarray(Omega.to_dense())
+    if not args.no_check:
+        t0 = time.perf_counter()
+        d_ref, U_ref = host_reference(args, wl, Omega_host, r, hf_o, hp_o)
+        Ud = np.asfortranarray(U.to_dense())
+        lead = max(1, r // 2)
+        if B is None:
+            angle = hp_o.principal_angle(Ud[:, :lead], U_ref[:, :lead])
+        else:
+            angle = hp_o.principal_angle(Ud[:, :lead], U_ref[:, :lead], lambda W: wl.M @ W)
+        out["parity"] = {"eig_rel_err_vs_oracle": hp_o.eig_rel_err(d, d_ref), "principal_angle_rad_leading_%d" % lead: angle,
+                         "eigenvalue_range": [float(d[0]), float(d[-1])], "oracle_seconds": time.perf_counter() - t0,
+                         "note": "oracle = CPU restatement of the reference path on the same Omega and the same operator (factored form)"}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,8 @@ SIGNATURES = {
     "hfmi_bench_tsgemm_tn": [_P, _P, C.c_int, C.c_int, _P, _D],
     "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
     "hfmi_bench_peaks": [_P, _D, _D, _D],
+    "hfmi_profile_begin": [_P],
+    "hfmi_profile_end": [_P, _D, C.POINTER(C.c_int64), _D, _D],
 }
 NON_STATUS = {"hfmi_last_error": (C.c_char_p, []), "hfmi_version": (C.c_int, [])}
 
@@ -180,6 +182,16 @@ class Context:
         a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
         call("hfmi_bench_peaks", self.handle, C.byref(a), C.byref(b), C.byref(c))
         return {"mfma_f64_tflops": a.value, "fma_f64_tflops": b.value, "hbm_copy_gbs": c.value}
+
+    def profile_begin(self):
+        call("hfmi_profile_begin", self.handle)
+
+    def profile_end(self):
+        """{kernel class: {ms, launches, flops, bytes}} for the MFMA kernels launched since profile_begin."""
+        ms, n, fl, by = (C.c_double * 2)(), (C.c_int64 * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
+        call("hfmi_profile_end", self.handle, ms, n, fl, by)
+        names = ("k_tsgemm_tn", "k_tsgemm_nn")
+        return {names[i]: {"ms": ms[i], "launches": int(n[i]), "flops": fl[i], "bytes": by[i]} for i in range(2)}
 
     def close(self):
         if self.handle:

@@ -83,6 +83,7 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   }
   c->pinned = nullptr;
   c->pinned_bytes = 0;
+  c->profiling = false;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
@@ -982,6 +983,55 @@ extern "C" int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const h
 }
 
 // ------------------------------------------------------------------ instrumentation
+int prof_start(hfmi_ctx* ctx, int kind, double flops, double bytes) {
+  if (!ctx->profiling) return -1;
+  hfmi_ctx::prof_rec r;
+  r.kind = kind;
+  r.flops = flops;
+  r.bytes = bytes;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+  (void)hipEventRecord(r.e0, ctx->stream);
+  ctx->prof.push_back(r);
+  return (int)ctx->prof.size() - 1;
+}
+int prof_stop(hfmi_ctx* ctx, int idx) {
+  if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream);
+  return HFMI_OK;
+}
+extern "C" int hfmi_profile_begin(hfmi_ctx* ctx) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  for (auto& r : ctx->prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->prof.clear();
+  ctx->profiling = true;
+  return HFMI_OK;
+}
+extern "C" int hfmi_profile_end(hfmi_ctx* ctx, double* ms2, int64_t* launches2, double* flops2, double* bytes2) {
+  if (!ctx || !ms2 || !launches2 || !flops2 || !bytes2) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  ctx->profiling = false;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 2; ++i) {
+    ms2[i] = 0.0;
+    launches2[i] = 0;
+    flops2[i] = 0.0;
+    bytes2[i] = 0.0;
+  }
+  for (auto& r : ctx->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.kind >= 0 && r.kind < 2) {
+      ms2[r.kind] += ms;
+      launches2[r.kind] += 1;
+      flops2[r.kind] += r.flops;
+      bytes2[r.kind] += r.bytes;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->prof.clear();
+  return HFMI_OK;
+}
 extern "C" int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, int reps, double* host_C, double* avg_ms) {
   if (!A || !B) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   if (A->N != B->N) HFMI_FAIL(HFMI_ERR_INVALID, "bench_tsgemm_tn: vector lengths differ");

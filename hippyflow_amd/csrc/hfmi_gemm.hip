@@ -278,6 +278,8 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   void* partv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nsplit * mpad * kpad * sizeof(double), &partv));
   double* part = (double*)partv;
+  // algorithmic work of this launch: flops 2 N m k, bytes 8 (N m + N k + m k)
+  const int pidx = prof_start(ctx, 0, 2.0 * (double)N * m * k, 8.0 * ((double)N * m + (double)N * k + (double)m * k));
 #define TN_NT(NTV)                                                                                             \
   case NTV:                                                                                                    \
     HFMI_TRY(tn_dispatch_mt<NTV>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad)); \
@@ -289,6 +291,7 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
       HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: panel too wide (%d)", k);
   }
 #undef TN_NT
+  prof_stop(ctx, pidx);
   {
     const int fastn = tr ? m : k, slown = tr ? k : m;
     dim3 block(128), grid((fastn + 127) / 128, slown < 32768 ? slown : 32768);
@@ -519,7 +522,9 @@ int launch_tsgemm_nn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   }
   for (int r0 = 0; r0 < r; r0 += 256) {
     const int rp = (r - r0 < 256) ? (r - r0) : 256;
+    const int pidx = prof_start(ctx, 1, 2.0 * (double)N * m * rp, 8.0 * ((double)N * m + (double)N * rp + (double)m * rp));
     HFMI_TRY(nn_panel(ctx, A, lda, m, S + r0, lds_, rp, out + (int64_t)r0 * ldo, ldo, N));
+    prof_stop(ctx, pidx);
   }
   if (beta != 0.0) {
     if (beta != 1.0) HFMI_TRY(launch_scale(ctx, Y, ldy, N, r, beta));

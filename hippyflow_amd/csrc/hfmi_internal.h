@@ -72,7 +72,13 @@ struct hfmi_ctx {
   void* pinned;                   // pinned host staging
   size_t pinned_bytes;
   std::vector<hfmi_block*> tmp_blocks;  // cached temporaries for the fused solves
+  // optional per-launch event timing of the two MFMA kernel classes
+  bool profiling;
+  struct prof_rec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+  std::vector<prof_rec> prof;
 };
+int prof_start(hfmi_ctx* ctx, int kind, double flops, double bytes);  // returns record index or -1
+int prof_stop(hfmi_ctx* ctx, int idx);
 
 static inline double* sm_ptr(hfmi_ctx* c, int slot) { return c->small + (size_t)slot * SM_MAXK * SM_LD; }
 int ctx_ws(hfmi_ctx* ctx, int slot, size_t bytes, void** out);

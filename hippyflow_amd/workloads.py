@@ -1,0 +1,142 @@
+"""Seeded synthetic inputs of the BASELINE configs, generated directly in HBM.
+
+No datasets or PDE solvers exist in this environment, so each workload is built from a latent
+factorisation whose operator spectrum is known in closed form:
+
+* POD   (configs 1, 3):  snapshots X = U0 diag(sigma) W0^T with W0 (N x c) orthonormal in HBM (device QR of a
+  Philox Gaussian block) and U0 (n x c) orthonormal (host QR) => (1/n) X^T X = W0 diag(sigma^2/n) W0^T.
+* AS    (config 4):      J_i = A_i P^T, P (N x c) orthonormal, A_i = G_i diag(s) with G_i Gaussian keyed by the
+  GLOBAL sample index (any rank regenerates exactly its own shard) => mean J^T J = P H P^T,
+  H = mean A_i^T A_i (c x c).
+* KLE   (config 2):      explicit dense covariance C = F diag(lam) F^T (N x N in HBM, 80 GB at N = 1e5) with
+  F orthonormal, and the consistent P1 mass matrix of an nx x ny grid (CSR, 7 nnz/row).
+
+The latent factors are kept so that tests and bench.py can evaluate the SAME operator on the host in
+factored form (a few N x c products) -- that is what makes an oracle check affordable at full size.
+"""
+import numpy as np
+
+from . import _lib as L
+from .multivector import MultiVector, MvDSmatMult
+from .operators import CsrOperator, MeanJTJfromDataOperator, SnapshotGramOperator, npToDeviceOperator
+from .randomized import _ParRandom
+
+
+class Workload:
+    pass
+
+
+def _orthonormal_block(N, c, seed, stream, ctx):
+    """N x c block with orthonormal columns: device QR of a Philox Gaussian draw (c <= 256)."""
+    rnd = _ParRandom(seed)
+    rnd.stream = stream
+    W = MultiVector(int(N), int(c), ctx=ctx)
+    rnd.normal(1.0, W)
+    W.orthogonalize(L.QR_CHOL)
+    return W
+
+
+def _expand(W0, S, ctx):
+    """block (N x m) = W0 (N x c) * S (c x m), m arbitrary (panels of 256 inside the library)."""
+    out = MultiVector(W0.size(), int(S.shape[1]), ctx=ctx)
+    MvDSmatMult(W0, np.ascontiguousarray(S), out)
+    return out
+
+
+def pod_workload(N, n, latent=256, rate=0.05, seed=3, ctx=None):
+    """n snapshots of length N; exact eigenvalues of (1/n) X^T X are sigma_j^2 / n."""
+    ctx = ctx or L.Context.default()
+    c = int(min(latent, n, 256))
+    wl = Workload()
+    wl.N, wl.n, wl.latent = int(N), int(n), c
+    wl.W0 = _orthonormal_block(N, c, seed, 100, ctx)
+    rng = np.random.default_rng(seed)
+    U0, _ = np.linalg.qr(rng.standard_normal((n, c)))
+    wl.sigma = np.exp(-rate * np.arange(c))
+    wl.U0 = U0
+    S = (U0 * wl.sigma).T                               # c x n
+    wl.X = _expand(wl.W0, S, ctx)                       # one snapshot per vector
+    wl.operator = SnapshotGramOperator(wl.X, scale=1.0 / n)
+    wl.exact_eigenvalues = wl.sigma ** 2 / n
+    return wl
+
+
+def pod_host_apply(wl, W0_host):
+    """Same operator on the host in factored form: W -> W0 diag(sigma^2/n) (W0^T W) up to the (exactly
+    orthonormal in exact arithmetic) U0 factor, which is kept: (1/n) W0 S S^T W0^T."""
+    S = (wl.U0 * wl.sigma).T
+    H = S @ S.T / wl.n
+    return lambda W: np.asfortranarray(W0_host @ (H @ (W0_host.T @ W)))
+
+
+def as_workload(N, ns_local, q=100, latent=100, rate=0.06, seed=4, first_sample=0, ns_total=None, ctx=None,
+                noise_cov_inv=None):
+    """ns_local Jacobian samples (global indices first_sample ...) of shape q x N, stored as one block of
+    ns_local*q vectors.  ``scale`` of the returned operator is 1/ns_local (the per-rank mean); the rank
+    average is the collective's job."""
+    ctx = ctx or L.Context.default()
+    c = int(latent)
+    wl = Workload()
+    wl.N, wl.ns_local, wl.q, wl.latent = int(N), int(ns_local), int(q), c
+    wl.first_sample = int(first_sample)
+    wl.ns_total = int(ns_total if ns_total is not None else ns_local)
+    wl.P = _orthonormal_block(N, c, seed, 200, ctx)
+    wl.s = np.exp(-rate * np.arange(c))
+    wl.A = np.stack([sample_factor(seed, first_sample + i, q, c) * wl.s[None, :] for i in range(ns_local)])   # (ns, q, c)
+    S = wl.A.reshape(ns_local * q, c).T                 # c x (ns*q): column i*q+o = row o of A_i
+    wl.J = _expand(wl.P, S, ctx)
+    wl.operator = MeanJTJfromDataOperator.from_block(wl.J, ns_local, q, noise_cov_inv=noise_cov_inv)
+    return wl
+
+
+def sample_factor(seed, global_index, q, c):
+    """Gaussian q x c factor of sample ``global_index`` (numpy Philox keyed by (seed, index))."""
+    bitgen = np.random.Philox(key=[int(seed), int(global_index)])
+    return np.random.Generator(bitgen).standard_normal((q, c))
+
+
+def as_reduced_matrix(seed, ns_total, q, c, rate):
+    """H = (1/ns_total) sum_i A_i^T A_i over ALL samples: mean J^T J = P H P^T."""
+    s = np.exp(-rate * np.arange(c))
+    H = np.zeros((c, c))
+    for i in range(ns_total):
+        A = sample_factor(seed, i, q, c) * s[None, :]
+        H += A.T @ A
+    return H / ns_total
+
+
+def grid_mass_matrix(nx, ny):
+    """Consistent P1 mass matrix of an nx x ny structured triangulation of the unit square (CSR, <= 7 nnz/row)."""
+    import scipy.sparse as sp
+    hx, hy = 1.0 / (nx - 1), 1.0 / (ny - 1)
+    area = 0.5 * hx * hy
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    v00, v10, v01, v11 = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([v00, v10, v11], 1), np.stack([v00, v11, v01], 1)])
+    rows, cols, vals = [], [], []
+    for a in range(3):
+        for b in range(3):
+            rows.append(tris[:, a])
+            cols.append(tris[:, b])
+            vals.append(np.full(len(tris), area / 6.0 if a == b else area / 12.0))
+    M = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nx * ny, nx * ny))
+    return M.tocsr()
+
+
+def kle_workload(nx, ny, latent=256, rate=0.08, seed=2, ctx=None):
+    """Explicit dense covariance C = F diag(lam) F^T on N = nx*ny points and the grid mass matrix."""
+    ctx = ctx or L.Context.default()
+    N = nx * ny
+    c = int(min(latent, 256))
+    wl = Workload()
+    wl.N, wl.latent = N, c
+    wl.F = _orthonormal_block(N, c, seed, 300, ctx)
+    wl.lam = np.exp(-rate * np.arange(c))
+    Fh = wl.F.to_dense()                                # N x c on the host (for the factored oracle as well)
+    wl.F_host = Fh
+    S = (Fh * wl.lam).T                                 # c x N
+    wl.C = _expand(wl.F, S, ctx)                        # N x N symmetric, column j = C[:, j]
+    wl.M = grid_mass_matrix(nx, ny)
+    wl.C_operator = npToDeviceOperator(wl.C)
+    wl.M_operator = CsrOperator(wl.M, ctx=ctx)
+    return wl

@@ -185,6 +185,12 @@ int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, i
 int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms);
 /* fp64 MFMA / fp64 FMA / HBM-copy micro-benchmarks (peak denominators measured in the same job) */
 int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbs);
+/* per-kernel-class HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from
+ * the timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by
+ * events on the context's stream.  end() synchronises and returns, for class 0 (tsgemm_tn) and
+ * class 1 (tsgemm_nn): total milliseconds, launches, algorithmic flops and algorithmic bytes. */
+int hfmi_profile_begin(hfmi_ctx* ctx);
+int hfmi_profile_end(hfmi_ctx* ctx, double* ms2, int64_t* launches2, double* flops2, double* bytes2);
 
 #ifdef __cplusplus
 }

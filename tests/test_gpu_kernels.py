@@ -1,0 +1,284 @@
+"""GPU parity tests, kernel level: every libhfmi primitive against numpy / the oracle on seeded inputs.
+All calls go through the C ABI (ctypes).  Run on the MI355X box: ``pytest -m gpu``."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+hf = pytest.importorskip("hippyflow_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    if hf.device_count() < 1:
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    return hf.Context.default()
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+# ------------------------------------------------------------------ layouts
+@pytest.mark.parametrize("N,k", [(1, 1), (5, 3), (33, 2), (4225, 30), (1000, 257)])
+def test_upload_download_roundtrip(ctx, N, k):
+    rng = np.random.default_rng(N + k)
+    dense = rng.standard_normal((N, k))
+    mv = hf.MultiVector.from_dense(dense)
+    assert mv.nvec() == k and mv.size() == N and mv.leading_dimension() % 32 == 0
+    np.testing.assert_array_equal(mv.to_dense(), dense)
+    np.testing.assert_array_equal(mv.to_vectors(), dense.T)
+    mv2 = hf.MultiVector.from_vectors(dense.T.copy())
+    np.testing.assert_array_equal(mv2.to_dense(), dense)
+    # views and the vector protocol
+    j = k // 2
+    np.testing.assert_array_equal(mv[j].get_local(), dense[:, j])
+    v = hf.Vector()
+    v.init(N)
+    v.set_local(np.arange(N, dtype=float))
+    mv[j].axpy(2.0, v)
+    np.testing.assert_allclose(mv.to_dense()[:, j], dense[:, j] + 2.0 * np.arange(N), rtol=1e-15)
+    assert abs(mv[j].inner(v) - (dense[:, j] + 2.0 * np.arange(N)) @ np.arange(N)) <= 1e-12 * max(1.0, N ** 3)
+    cp = hf.MultiVector(mv)
+    cp.scale(0.5)
+    np.testing.assert_allclose(cp.to_dense(), 0.5 * mv.to_dense(), rtol=1e-15)
+    np.testing.assert_allclose(mv.norm(), np.linalg.norm(mv.to_dense(), axis=0), rtol=1e-13)
+    cp.zero()
+    assert not cp.to_dense().any()
+
+
+def test_swap_and_copy_semantics(ctx):
+    a = hf.MultiVector.from_dense(np.ones((10, 2)))
+    b = hf.MultiVector.from_dense(2 * np.ones((10, 2)))
+    a.swap(b)
+    assert a.to_dense()[0, 0] == 2.0 and b.to_dense()[0, 0] == 1.0
+
+
+# ------------------------------------------------------------------ Philox / probe draw (a1)
+def test_philox_stream_bit_exact_and_normals(ctx):
+    import ctypes as C
+    from hippyflow_amd import _lib as L
+    from oracle import philox
+    N, k, seed, stream = 1001, 7, 0x1234567890ABCDEF, 3
+    mv = hf.MultiVector(N, k)
+    raw = np.empty((k, (N + 1) // 2, 4), dtype=np.uint32)
+    L.call("hfmi_philox_raw", mv.handle, C.c_uint64(seed), C.c_uint32(stream), L.ptr(raw))
+    np.testing.assert_array_equal(raw, philox.raw_block(N, k, seed, stream))       # integer stream: bit-exact
+    L.call("hfmi_randn_fill", mv.handle, C.c_uint64(seed), C.c_uint32(stream), 1.5)
+    ref = philox.randn_block(N, k, seed, stream, sigma=1.5)
+    # fp64 log / sincos differ from libm by a few ulp; |z| <= ~9 so 1e-13 absolute is ~50 ulp
+    np.testing.assert_allclose(mv.to_dense(), ref, rtol=0, atol=1e-13)
+
+
+def test_parRandom_is_reproducible_across_contexts(ctx):
+    hf.parRandom.reseed(42)
+    a = hf.MultiVector(3001, 5)
+    hf.parRandom.normal(1.0, a)
+    hf.parRandom.reseed(42)
+    b = hf.MultiVector(3001, 5)
+    hf.parRandom.normal(1.0, b)
+    np.testing.assert_array_equal(a.to_dense(), b.to_dense())
+    c = hf.MultiVector(3001, 5)
+    hf.parRandom.normal(1.0, c)          # next stream: independent draw
+    assert abs(np.corrcoef(a.to_dense()[:, 0], c.to_dense()[:, 0])[0, 1]) < 0.1
+    Z = a.to_dense()
+    assert abs(Z.mean()) < 0.05 and abs(Z.std() - 1) < 0.05
+
+
+# ------------------------------------------------------------------ tall-skinny contractions
+TN_SHAPES = [(1, 1, 1), (3, 2, 7), (9, 13, 100), (16, 16, 32), (17, 33, 1000), (30, 30, 4225), (138, 138, 4225),
+             (256, 30, 4225), (64, 74, 20011), (300, 260, 1000), (500, 84, 3000), (2048, 138, 20000), (700, 5, 50000)]
+
+
+@pytest.mark.parametrize("m,k,N", TN_SHAPES)
+def test_block_dot_matches_numpy(ctx, m, k, N):
+    """dot_mv = A^T B (tsgemm_tn): asymmetric random operands catch transposed fragment maps."""
+    rng = np.random.default_rng(m * 1000 + k)
+    A = rng.standard_normal((N, m)) * np.logspace(0, -3, m)[None, :]
+    B = rng.standard_normal((N, k)) + 0.1
+    got = hf.MultiVector.from_dense(A).dot_mv(hf.MultiVector.from_dense(B))
+    ref = A.T @ B
+    scale = np.linalg.norm(A, axis=0)[:, None] * np.linalg.norm(B, axis=0)[None, :]
+    assert np.max(np.abs(got - ref) / scale) < 1e-13
+
+
+def test_block_dot_is_deterministic(ctx):
+    rng = np.random.default_rng(0)
+    A = hf.MultiVector.from_dense(rng.standard_normal((50000, 40)))
+    g1, g2 = A.dot_mv(A), A.dot_mv(A)
+    np.testing.assert_array_equal(g1, g2)         # fixed split-reduction order
+
+
+NN_SHAPES = [(1, 1, 1), (7, 3, 2), (100, 9, 13), (4225, 30, 20), (4225, 256, 30), (20011, 74, 64), (1000, 300, 260),
+             (50000, 138, 128), (3000, 2048, 138), (999, 5, 1)]
+
+
+@pytest.mark.parametrize("N,m,r", NN_SHAPES)
+def test_gemm_small_matches_numpy(ctx, N, m, r):
+    """MvDSmatMult / reduce = A S (tsgemm_nn), with alpha/beta."""
+    rng = np.random.default_rng(N + m + r)
+    A = rng.standard_normal((N, m))
+    S = rng.standard_normal((m, r)) * np.logspace(0, -2, r)[None, :]
+    Y0 = rng.standard_normal((N, r))
+    Amv, Y = hf.MultiVector.from_dense(A), hf.MultiVector.from_dense(Y0)
+    hf.MvDSmatMult(Amv, S, Y)
+    ref = A @ S
+    assert rel(Y.to_dense(), ref) < 1e-13
+    # accumulate form through the C ABI: Y = 0.5 A S - 2 Y
+    import ctypes as C
+    from hippyflow_amd import _lib as L
+    Y2 = hf.MultiVector.from_dense(Y0)
+    L.call("hfmi_block_gemm_small", Amv.handle, L.ptr(np.ascontiguousarray(S)), 0.5, -2.0, Y2.handle)
+    assert rel(Y2.to_dense(), 0.5 * ref - 2.0 * Y0) < 1e-13
+    # padding rows of the result stay zero (later reductions run over them unmasked)
+    if r <= 256:
+        assert abs(Y.dot_mv(Y) - ref.T @ ref).max() <= 1e-11 * max(1.0, np.abs(ref.T @ ref).max())
+
+
+def test_reduce_and_dot_v(ctx):
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((777, 6))
+    x = rng.standard_normal(777)
+    Umv = hf.MultiVector.from_dense(U)
+    xv = hf.Vector()
+    xv.init(777)
+    xv.set_local(x)
+    np.testing.assert_allclose(Umv.dot_v(xv), U.T @ x, rtol=1e-12, atol=1e-12)
+    y = hf.Vector()
+    y.init(777)
+    y.set_local(np.ones(777))
+    alpha = rng.standard_normal(6)
+    Umv.reduce(y, alpha)
+    np.testing.assert_allclose(y.get_local(), 1.0 + U @ alpha, rtol=1e-12, atol=1e-12)
+
+
+def test_shape_mismatch_raises(ctx):
+    a, b = hf.MultiVector(10, 2), hf.MultiVector(11, 2)
+    with pytest.raises(hf.HfmiError):
+        a.dot_mv(b)
+    with pytest.raises(AssertionError):
+        hf.MatMvMult(hf.SnapshotGramOperator(np.ones((3, 10))), a, hf.MultiVector(10, 3))
+
+
+# ------------------------------------------------------------------ sparse
+def _fem(N):
+    h = 1.0 / (N - 1)
+    main = np.full(N, 4 * h / 6)
+    main[[0, -1]] = 2 * h / 6
+    M = sp.diags([np.full(N - 1, h / 6), main, np.full(N - 1, h / 6)], [-1, 0, 1], format="csr")
+    kd = np.full(N, 2 / h)
+    kd[[0, -1]] = 1 / h
+    K = sp.diags([np.full(N - 1, -1 / h), kd, np.full(N - 1, -1 / h)], [-1, 0, 1], format="csr")
+    return M, K
+
+
+@pytest.mark.parametrize("N,k", [(50, 1), (1000, 9), (4225, 30)])
+def test_csr_spmm_and_pcg(ctx, N, k):
+    rng = np.random.default_rng(N)
+    M, K = _fem(N)
+    A = (M + 0.01 * K).tocsr()
+    X = rng.standard_normal((N, k))
+    op = hf.CsrOperator(A)
+    Xmv, Y = hf.MultiVector.from_dense(X), hf.MultiVector(N, k)
+    op.matMvMult(Xmv, Y)
+    assert rel(Y.to_dense(), A @ X) < 1e-14
+    op.matMvMult(Xmv, Y, accumulate=True)
+    assert rel(Y.to_dense(), 2 * (A @ X)) < 1e-14
+    solver = hf.CsrPCGSolver(M, rel_tol=1e-13)
+    Z = hf.MultiVector(N, k)
+    solver.matMvMult(Xmv, Z)
+    import scipy.sparse.linalg as spla
+    ref = spla.splu(M.tocsc()).solve(X)
+    assert rel(Z.to_dense(), ref) < 1e-10
+
+
+# ------------------------------------------------------------------ QR (a7)
+@pytest.mark.parametrize("N,k,cond", [(300, 20, 1e0), (4225, 30, 1e3), (4225, 30, 1e9), (20000, 138, 1e5), (1000, 200, 1e2)])
+def test_orthogonalize_matches_reference_mgs(ctx, N, k, cond):
+    from oracle import hippylib_restated as hp_o
+    rng = np.random.default_rng(k)
+    Z = rng.standard_normal((N, k)) @ np.diag(np.logspace(0, -np.log10(cond), k)) @ np.linalg.qr(rng.standard_normal((k, k)))[0]
+    Zf = np.asfortranarray(Z)
+    Q = hf.MultiVector.from_dense(Z)
+    R = Q.orthogonalize()
+    Qd = Q.to_dense()
+    assert np.linalg.norm(Qd.T @ Qd - np.eye(k)) / np.sqrt(k) < 1e-13, "orthonormality"
+    assert np.allclose(np.tril(R, -1), 0) and np.all(np.diag(R) > 0)
+    assert rel(Qd @ R, Z) < 1e-12, "QR = Z"
+    if N * k <= 4225 * 30:
+        Qo = Zf.copy(order="F")
+        Ro = hp_o.mgs_reortho(Qo)
+        # thin QR with positive diagonal is unique: the Cholesky-QR Q equals the reference's MGS Q
+        assert np.abs(Qd - Qo).max() < 1e-8 * cond ** 0.5 + 1e-12
+        assert rel(R, Ro) < 1e-9
+    if cond >= 1e9:
+        assert Q.last_qr_passes >= 3      # shifted / repeated passes were needed
+
+
+def test_orthogonalize_mgs_method_and_rank_deficiency(ctx):
+    from hippyflow_amd import _lib as L
+    from oracle import hippylib_restated as hp_o
+    rng = np.random.default_rng(7)
+    Z = rng.standard_normal((500, 6))
+    Z[:, 3] = Z[:, 0] - 2 * Z[:, 1]                     # numerically dependent column
+    Qo = np.asfortranarray(Z.copy())
+    Ro = hp_o.mgs_reortho(Qo)
+    for method in (L.QR_MGS, L.QR_AUTO):               # AUTO: Cholesky breaks down -> falls back to MGS
+        Q = hf.MultiVector.from_dense(Z)
+        R = Q.orthogonalize(method)
+        Qd = Q.to_dense()
+        assert R[3, 3] == 0.0 and not Qd[:, 3].any()    # the reference zeroes the dependent column
+        np.testing.assert_allclose(np.abs(Qd), np.abs(Qo), atol=1e-10)
+        np.testing.assert_allclose(R, Ro, atol=1e-10)
+
+
+@pytest.mark.parametrize("method", ["chol", "mgs"])
+def test_Borthogonalize(ctx, method):
+    from hippyflow_amd import _lib as L
+    from oracle import hippylib_restated as hp_o
+    rng = np.random.default_rng(11)
+    N, k = 2000, 25
+    M, K = _fem(N)
+    B = (M + 1e-3 * K).tocsr()
+    Z = rng.standard_normal((N, k)) @ np.diag(np.logspace(0, -4, k))
+    Q = hf.MultiVector.from_dense(Z)
+    BQ, R = Q.Borthogonalize(B, L.QR_CHOL if method == "chol" else L.QR_MGS)
+    Qd = Q.to_dense()
+    assert np.linalg.norm(Qd.T @ (B @ Qd) - np.eye(k)) / np.sqrt(k) < 1e-12
+    assert rel(BQ.to_dense(), B @ Qd) < 1e-12
+    assert rel(Qd @ R, Z) < 1e-11
+    Qo = np.asfortranarray(Z.copy())
+    BQo, Ro = hp_o.mgs_stable(Qo, hp_o.SparseOperator(B))
+    assert np.abs(Qd - Qo).max() < 1e-9 and rel(R, Ro) < 1e-9
+
+
+# ------------------------------------------------------------------ small eigensolve (a8)
+@pytest.mark.parametrize("k", [1, 2, 5, 30, 31, 74, 84, 137, 138, 200, 256])
+def test_sym_eig_small_matches_eigh(ctx, k):
+    rng = np.random.default_rng(k)
+    Qm = np.linalg.qr(rng.standard_normal((k, k)))[0]
+    lam = np.exp(-0.25 * np.arange(k)) * np.where(np.arange(k) % 7 == 3, -1.0, 1.0)   # decaying, some negative
+    T = (Qm * lam) @ Qm.T
+    T = 0.5 * (T + T.T)
+    d, V = hf.sym_eig_small(T)
+    w = np.linalg.eigvalsh(T)[::-1]
+    assert np.max(np.abs(d - w)) < 1e-14 * k * np.abs(w).max()
+    assert np.all(np.diff(d) <= 0)
+    assert np.linalg.norm(V.T @ V - np.eye(k)) < 1e-13 * k
+    assert np.linalg.norm(T @ V - V * d) < 1e-13 * k * np.abs(w).max()
+    d_abs, _ = hf.sym_eig_small(T, sort_by_abs=True)
+    assert np.all(np.diff(np.abs(d_abs)) <= 0)
+
+
+def test_sym_eig_small_graded_relative_accuracy(ctx):
+    """Jacobi resolves tiny eigenvalues of a graded PSD matrix to high relative accuracy."""
+    rng = np.random.default_rng(3)
+    k = 40
+    G = rng.standard_normal((200, k)) @ np.diag(np.logspace(0, -6, k))
+    T = G.T @ G
+    d, _ = hf.sym_eig_small(T)
+    w = np.linalg.svd(G, compute_uv=False) ** 2
+    assert np.max(np.abs(d - w) / w) < 1e-9

@@ -1,0 +1,421 @@
+"""GPU parity tests, path level: operators, the randomized double pass and the projector classes against the
+oracle (same Omega, same operator samples) and the golden vectors produced by the reference's own code.
+
+Tolerances: eigenvalue relative error and subspace angle as stated per test (north star: eigenvalue
+rel-err < 1e-6 vs the reference path); invariants with the tolerances of the reference's tests
+(hippyflow/test/test_KLEProjector.py:92-129,183-217; test_derivativeSubspace.py:92-102;
+test_PODProjector.py:154-208)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+hf = pytest.importorskip("hippyflow_amd")
+from oracle import hippyflow_restated as hf_o   # noqa: E402
+from oracle import hippylib_restated as hp_o    # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    if hf.device_count() < 1:
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    return hf.Context.default()
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def _fem(N):
+    h = 1.0 / (N - 1)
+    main = np.full(N, 4 * h / 6)
+    main[[0, -1]] = 2 * h / 6
+    M = sp.diags([np.full(N - 1, h / 6), main, np.full(N - 1, h / 6)], [-1, 0, 1], format="csr")
+    kd = np.full(N, 2 / h)
+    kd[[0, -1]] = 1 / h
+    K = sp.diags([np.full(N - 1, -1 / h), kd, np.full(N - 1, -1 / h)], [-1, 0, 1], format="csr")
+    return M, K
+
+
+def _snapshots(n, N, rate, seed):
+    rng = np.random.default_rng(seed)
+    U0, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    W0, _ = np.linalg.qr(rng.standard_normal((N, n)))
+    return (U0 * np.exp(-rate * np.arange(n))) @ W0.T
+
+
+def _csr(g, N):
+    return sp.csr_matrix((g["M_data"], g["M_indices"], g["M_indptr"]), shape=(N, N))
+
+
+# ------------------------------------------------------------------ operators (a2, a3, a4, a9)
+def test_snapshot_gram_operator(ctx):
+    X = _snapshots(40, 3001, 0.2, 0)
+    W = np.random.default_rng(1).standard_normal((3001, 9))
+    op = hf.SnapshotGramOperator(X)
+    Y = hf.MultiVector(3001, 9)
+    op.matMvMult(hf.MultiVector.from_dense(W), Y)
+    assert rel(Y.to_dense(), hf_o.snapshot_gram_block(X, W)) < 1e-13
+    # column protocol: mult(x, y) on vectors
+    x, y = hf.Vector(), hf.Vector()
+    op.init_vector(x, 1)
+    op.init_vector(y, 0)
+    x.set_local(W[:, 0])
+    op.mult(x, y)
+    assert rel(y.get_local(), hf_o.snapshot_gram_block(X, W[:, :1])[:, 0]) < 1e-13
+    lro = hf.LowRankOperator(np.ones(40) / 40, hf.MultiVector.from_vectors(X))
+    lro.matMvMult(hf.MultiVector.from_dense(W), Y)
+    assert rel(Y.to_dense(), hf_o.snapshot_gram_block(X, W)) < 1e-13
+
+
+def test_mean_jtj_operator_matches_reference_golden(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mean_jtj.npz"))
+    J, x = g["J"], g["x"]
+    for gamma, want in ((None, g["y"]), (g["Gamma_inv"], g["y_gamma"])):
+        op = hf.MeanJTJfromDataOperator(J, prior=None, noise_cov_inv=gamma)
+        assert (op.ndata, op.r, op.dM) == J.shape
+        Y = hf.MultiVector(J.shape[2], x.shape[1])
+        op.matMvMult(hf.MultiVector.from_dense(x), Y)
+        np.testing.assert_allclose(Y.to_dense(), want, rtol=1e-12, atol=1e-12)   # reference's own output
+        xv, yv = hf.Vector(), hf.Vector()
+        op.init_vector(xv, 1)
+        op.init_vector(yv, 0)
+        xv.set_local(x[:, 2])
+        op.mult(xv, yv)
+        np.testing.assert_allclose(yv.get_local(), want[:, 2], rtol=1e-12, atol=1e-12)
+
+
+def test_mean_jtj_jjt_larger(ctx):
+    rng = np.random.default_rng(2)
+    J = rng.standard_normal((12, 20, 2500)) * np.exp(-0.1 * np.arange(20))[None, :, None]
+    W = rng.standard_normal((2500, 17))
+    Y = hf.MultiVector(2500, 17)
+    hf.MeanJTJfromDataOperator(J).matMvMult(hf.MultiVector.from_dense(W), Y)
+    assert rel(Y.to_dense(), hf_o.mean_jtj_block(J, W)) < 1e-13
+    Wq = rng.standard_normal((20, 6))
+    Yq = hf.MultiVector(20, 6)
+    hf.MeanJJTfromDataOperator(J).matMvMult(hf.MultiVector.from_dense(Wq), Yq)
+    assert rel(Yq.to_dense(), hf_o.mean_jjt_block(J, Wq)) < 1e-13
+
+
+def test_dense_sym_and_mcm_operator(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kle_and_consumers.npz"))
+    N = g["x"].shape[0]
+    M = _csr(g, N)
+    C = hf.npToDeviceOperator(g["Cov"])
+    op = hf.MassPreconditionedCovarianceOperator(C, hf.CsrOperator(M))
+    x, y = hf.Vector(), hf.Vector()
+    op.init_vector(x, 0)
+    op.init_vector(y, 0)
+    x.set_local(g["x"])
+    op.mult(x, y)
+    np.testing.assert_allclose(y.get_local(), g["mcm"], rtol=1e-12)                 # reference's own output
+    # consumers of the eigenvectors
+    U = hf.MultiVector.from_dense(g["U"])
+    ppp = hf.PriorPreconditionedProjector(U, hf.CsrOperator(M), lambda v, dim: v.init(N))
+    ppp.mult(x, y)
+    np.testing.assert_allclose(y.get_local(), g["prior_precond_proj"], rtol=1e-11, atol=1e-13)
+    V = hf.MultiVector.from_dense(g["V"])
+    lrr = hf.LowRankRectangularOperator(U, g["s"], V)
+    x13, y13 = hf.Vector(), hf.Vector()
+    x13.init(13)
+    y13.init(13)
+    x13.set_local(g["x13"])
+    lrr.mult(x13, y)
+    np.testing.assert_allclose(y.get_local(), g["lowrank_mult"], rtol=1e-11, atol=1e-13)
+    lrr.transpmult(x, y13)
+    np.testing.assert_allclose(y13.get_local(), g["lowrank_transpmult"], rtol=1e-11, atol=1e-13)
+
+
+def test_dense_sym_large(ctx):
+    rng = np.random.default_rng(3)
+    N, k = 3000, 84
+    A = rng.standard_normal((N, N))
+    Cm = A @ A.T / N + np.eye(N)
+    W = rng.standard_normal((N, k))
+    Y = hf.MultiVector(N, k)
+    hf.npToDeviceOperator(Cm).matMvMult(hf.MultiVector.from_dense(W), Y)
+    assert rel(Y.to_dense(), Cm @ W) < 1e-13
+
+
+def test_host_callback_and_summed_list(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "operators.npz"))
+    Js, x13 = g["Js"], g["x13"]
+    ops = [hf.HostCallbackOperator(hp_o.DenseOperator(Ji.T @ Ji), 13) for Ji in Js]
+    x, y = hf.Vector(), hf.Vector()
+    x.init(13)
+    y.init(13)
+    x.set_local(x13)
+    ops[0].mult(x, y)
+    np.testing.assert_allclose(y.get_local(), g["jtj"], rtol=1e-12)
+    hf.SummedListOperator(ops, average=True).mult(x, y)
+    np.testing.assert_allclose(y.get_local(), g["summed_avg"], rtol=1e-12)          # reference's own output
+
+    class Boom:
+        def mult(self, x, y):
+            raise ValueError("boom")
+
+    with pytest.raises(ValueError):
+        hf.HostCallbackOperator(Boom(), 13).mult(x, y)
+
+
+def test_collective_operator_null(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "collectives.npz"))
+    nc = hf.NullCollective()
+    assert nc.size() == int(g["null_size"]) and nc.rank() == int(g["null_rank"])
+    with pytest.raises(NotImplementedError):
+        nc.allReduce(1.0, "max")
+    X = _snapshots(8, 500, 0.3, 4)
+    op = hf.CollectiveOperator(hf.SnapshotGramOperator(X), nc, mpi_op="avg")
+    W = np.random.default_rng(5).standard_normal((500, 4))
+    Y = hf.MultiVector(500, 4)
+    hf.MatMvMult(op, hf.MultiVector.from_dense(W), Y)
+    assert rel(Y.to_dense(), hf_o.snapshot_gram_block(X, W)) < 1e-13
+
+
+# ------------------------------------------------------------------ double pass (a5, a6)
+def _check_eigs(d, U, d_ref, U_ref, tol_d, tol_angle, lead, apply_B=None):
+    assert hp_o.eig_rel_err(d, d_ref) < tol_d, "eigenvalues: %g" % hp_o.eig_rel_err(d, d_ref)
+    ang = hp_o.principal_angle(np.asfortranarray(U[:, :lead]), np.asfortranarray(U_ref[:, :lead]), apply_B)
+    assert ang < tol_angle, "subspace angle %g" % ang
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_double_pass_config1_vs_oracle(ctx, fused):
+    """Config 1 shape: N=4225, 256 snapshots, r=20, p=10, sigma_j = exp(-0.35 j)."""
+    n, N, r, p = 256, 4225, 20, 10
+    X = _snapshots(n, N, 0.35, 0)
+    Omega = np.asfortranarray(np.random.default_rng(1).standard_normal((N, r + p)))
+    d_ref, U_ref = hp_o.double_pass(hf_o.SnapshotGramOperator(X), Omega, r, s=1)
+    op = hf.SnapshotGramOperator(X)
+    d, U = hf.doublePass(op, hf.MultiVector.from_dense(Omega), r, s=1, fused=fused)
+    Ud = U.to_dense()
+    # same Omega, same operator: agreement far below the 1e-6 target (lambda_20/lambda_1 = 1.7e-6)
+    _check_eigs(d, Ud, d_ref, U_ref, 1e-8, 1e-6, 12)
+    assert np.linalg.norm(Ud.T @ Ud - np.eye(r)) / np.sqrt(r) < 1e-10            # test_KLEProjector.py:183-196
+    AU = hf_o.snapshot_gram_block(X, Ud)
+    assert np.linalg.norm(AU - Ud * d) / np.linalg.norm(AU) < 1e-4                # :198-217
+    exact = np.linalg.eigvalsh(X @ X.T / n)[::-1][:r]
+    assert hp_o.eig_rel_err(d, exact) < 1e-5                                      # randomization error only
+
+
+def test_double_pass_mgs_route_and_power_iterations(ctx):
+    X = _snapshots(60, 2000, 0.3, 2)
+    Omega = np.asfortranarray(np.random.default_rng(3).standard_normal((2000, 25)))
+    op = hf.SnapshotGramOperator(X)
+    for s in (1, 2):
+        d_ref, U_ref = hp_o.double_pass(hf_o.SnapshotGramOperator(X), Omega, 15, s=s)
+        d, U = hf.doublePass(op, hf.MultiVector.from_dense(Omega), 15, s=s, use_mgs=True)
+        _check_eigs(d, U.to_dense(), d_ref, U_ref, 1e-7, 1e-6, 8)
+        d2, U2 = hf.doublePass(op, hf.MultiVector.from_dense(Omega), 15, s=s)
+        _check_eigs(d2, U2.to_dense(), d_ref, U_ref, 1e-7, 1e-6, 8)
+
+
+def test_rank_deficient_snapshot_set(ctx):
+    """Fewer snapshots than probe vectors: A has rank n < k; the reference's MGS zeroes dependent
+    columns and the trailing Ritz values are 0."""
+    X = _snapshots(12, 900, 0.2, 5)
+    Omega = np.asfortranarray(np.random.default_rng(6).standard_normal((900, 20)))
+    d_ref, _ = hp_o.double_pass(hf_o.SnapshotGramOperator(X), Omega, 16, s=1)
+    d, U = hf.doublePass(hf.SnapshotGramOperator(X), hf.MultiVector.from_dense(Omega), 16, s=1)
+    np.testing.assert_allclose(d[:12], d_ref[:12], rtol=1e-8)
+    assert np.all(np.abs(d[12:]) < 1e-12 * d[0])
+
+
+@pytest.mark.parametrize("binv", ["pcg", "host_lu"])
+def test_double_pass_g_kle_mass(ctx, binv):
+    """KLE 'mass' mode: M C M v = lambda M v (KLEProjector.py:146-168) with the reference test's
+    invariants (test_KLEProjector.py:91-129) and oracle parity on the same Omega."""
+    rng = np.random.default_rng(4)
+    N, r, p = 1500, 24, 10
+    M, K = _fem(N)
+    A = (M + 0.02 * K).toarray()
+    R = A @ np.diag(1.0 / np.asarray(M.sum(axis=1)).ravel()) @ A
+    Cm = np.linalg.inv(R)
+    Cm = 0.5 * (Cm + Cm.T)
+    Omega = np.asfortranarray(rng.standard_normal((N, r + p)))
+    KLE_o = hf_o.MassPreconditionedCovarianceOperator(hp_o.DenseOperator(Cm), hp_o.SparseOperator(M))
+    d_ref, V_ref = hp_o.double_pass_g(KLE_o, hp_o.SparseOperator(M), hp_o.SparseLUSolver(M), Omega, r, s=1)
+    Mop = hf.CsrOperator(M)
+    KLE = hf.MassPreconditionedCovarianceOperator(hf.npToDeviceOperator(Cm), Mop)
+    Msolver = hf.CsrPCGSolver(M) if binv == "pcg" else hp_o.SparseLUSolver(M)      # device CG or host black box
+    d, V = hf.doublePassG(KLE, Mop, Msolver, hf.MultiVector.from_dense(Omega), r, s=1)
+    Vd = V.to_dense()
+    _check_eigs(d, Vd, d_ref, V_ref, 1e-7, 1e-5, 10, lambda W: M @ W)
+    assert np.linalg.norm(Vd.T @ (M @ Vd) - np.eye(r)) / np.sqrt(r) < 1e-10
+    MCMV = M @ (Cm @ (M @ Vd))
+    assert np.linalg.norm(MCMV - (M @ Vd) * d) / np.linalg.norm(MCMV) < 1e-4
+    # generic (host-orchestrated) route gives the same answer
+    d2, V2 = hf.doublePassG(KLE, Mop, Msolver, hf.MultiVector.from_dense(Omega), r, s=1, fused=False)
+    _check_eigs(d2, V2.to_dense(), d_ref, V_ref, 1e-7, 1e-5, 10, lambda W: M @ W)
+
+
+# ------------------------------------------------------------------ projectors
+@pytest.mark.parametrize("shifted", [True, False])
+def test_pod_from_data_hep_matches_reference_golden(ctx, golden_dir, shifted):
+    g = np.load(os.path.join(golden_dir, "pod_from_data.npz"))
+    N, r = int(g["N"]), int(g["r"])
+    M = _csr(g, N)
+    d, phi, Mphi, shift = hf.PODProjectorFromData(None, M).construct_subspace(g["u_data"].copy(), r, shifted=shifted, method="hep")
+    tag = "hep_%d" % int(shifted)
+    np.testing.assert_allclose(shift, g["shift_" + tag], atol=1e-14)
+    np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-7, atol=1e-12 * g["d_" + tag][0])
+    cos = np.abs(np.einsum("ij,ij->j", phi[:, :6], M @ g["phi_" + tag][:, :6]))
+    np.testing.assert_allclose(cos, 1.0, atol=1e-8)
+    eye = np.eye(r)
+    assert np.linalg.norm(eye - phi.T @ Mphi) / np.linalg.norm(eye) < 1e-8        # test_PODProjector.py:154-168
+    assert np.linalg.norm(M @ phi - Mphi) / np.linalg.norm(Mphi) < 1e-8           # :170-174
+    assert (not np.allclose(shift, 0)) == shifted                                 # :176-186
+    with pytest.raises(NotImplementedError):
+        hf.PODProjectorFromData(None, M).construct_subspace(g["u_data"].copy(), r, method="ghep")
+
+
+def test_pod_projector_class(ctx, tmp_path):
+    X = _snapshots(100, 2500, 0.3, 8)
+    params = hf.PODParameterList()
+    assert params["rank"] == 20 and params["oversampling"] == 10 and params["sample_per_process"] == 100
+    params["verbose"] = False
+    params["output_directory"] = str(tmp_path) + "/"
+
+    class Obs:
+        def sample_observables(self, n, prior, noise):
+            return X[:n]
+
+    hf.parRandom.reseed(7)
+    pod = hf.PODProjector(Obs(), prior=None, parameters=params)
+    pod.construct_subspace()
+    exact = np.linalg.eigvalsh(X @ X.T / 100)[::-1][:20]
+    assert hp_o.eig_rel_err(pod.d[:10], exact[:10]) < 1e-6
+    saved = np.load(os.path.join(str(tmp_path), "POD_projector.npy"))
+    assert saved.shape == (2500, 20)
+    np.testing.assert_array_equal(saved, hf.mv_to_dense(pod.U_MV))
+    np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "POD_d.npy")), pod.d)
+
+
+def test_kle_projector_class(ctx):
+    """The reference's KLE test, mass and identity modes (test_KLEProjector.py:80-217)."""
+    N = 1200
+    M, K = _fem(N)
+    A = (M + 0.02 * K).toarray()
+    Rm = A @ np.diag(1.0 / np.asarray(M.sum(axis=1)).ravel()) @ A
+    Rm = 0.5 * (Rm + Rm.T)
+
+    class Prior:
+        pass
+
+    prior = Prior()
+    prior.M = M
+    prior.R = sp.csr_matrix(Rm)
+    prior.Rsolver = hp_o.SparseLUSolver(sp.csr_matrix(Rm))       # host black box, like PETSc in the reference
+    prior.Rsolver.N = N
+    params = hf.KLEParameterList()
+    assert params["rank"] == 128 and params["input_decoder_name"] == "KLE_decoder"
+    params["rank"], params["verbose"], params["save_and_plot"] = 30, False, False
+    kle = hf.KLEProjector(prior, parameters=params)
+    d, dec, enc = kle.construct_input_subspace("mass")
+    V, E = dec.to_dense(), enc.to_dense()
+    r = 30
+    assert kle.M_orthogonal is True
+    assert np.linalg.norm(V.T @ (M @ V) - np.eye(r)) / np.sqrt(r) < 1e-10         # :96-99
+    assert rel(E, M @ V) < 1e-10                                                  # :101-108
+    Cm = np.linalg.inv(Rm)
+    MCMV = M @ (Cm @ (M @ V))
+    assert np.linalg.norm(MCMV - (M @ V) * d) / np.linalg.norm(MCMV) < 1e-4       # :110-129
+    d2, dec2, _ = kle.construct_input_subspace("identity")
+    V2 = dec2.to_dense()
+    assert np.linalg.norm(V2.T @ V2 - np.eye(r)) / np.sqrt(r) < 1e-10             # :183-196
+    CV = Cm @ V2
+    assert np.linalg.norm(CV - V2 * d2) / np.linalg.norm(CV) < 1e-4               # :198-217
+    with pytest.raises(NotImplementedError):
+        kle.construct_input_subspace("prior")
+
+
+def test_active_subspace_batched_equals_serialized(ctx, tmp_path):
+    """The reference's own AS test: with identical Omega and samples the batched (device operator over
+    stored Jacobians) and the serialized (host black box re-applied every pass) constructions give the
+    same eigenvalues, ||d_batch - d_serial||_2 < 1e-12 (test_derivativeSubspace.py:92-102) -- here 1e-10
+    relative because the two routes sum in different orders on different hardware."""
+    rng = np.random.default_rng(9)
+    ns, q, N = 16, 30, 1800
+    P, _ = np.linalg.qr(rng.standard_normal((N, q)))
+    J = np.einsum("ioc,tc->iot", rng.standard_normal((ns, q, q)) * np.exp(-0.15 * np.arange(q))[None, None, :], P)
+    M, K = _fem(N)
+    A = (M + 0.05 * K)
+    Rm = (A @ sp.diags(1.0 / np.asarray(M.sum(axis=1)).ravel()) @ A).tocsr()
+
+    class Prior:
+        pass
+
+    prior = Prior()
+    prior.R = Rm
+    prior.Rsolver = hp_o.SparseLUSolver(Rm)
+
+    class Obs:
+        def jacobian_data(self, n):
+            return J[:n]
+
+        def input_dimension(self):
+            return N
+
+        def output_dimension(self):
+            return q
+
+        def jtj_host_operator(self):
+            return hf_o.MeanJTJOperator(J)      # host black box with the reference's protocol
+
+        def jjt_host_operator(self):
+            class JJT:
+                def matMvMult_np(self, W):
+                    return hf_o.mean_jjt_block(J, W)
+            return JJT()
+
+    results = {}
+    for serialized in (False, True):
+        params = hf.ActiveSubspaceParameterList()
+        assert params["rank"] == 128 and params["samples_per_process"] == 64 and params["serialized_sampling"] is True
+        params["rank"], params["oversampling"], params["samples_per_process"] = 20, 8, ns
+        params["serialized_sampling"], params["verbose"], params["store_Omega"] = serialized, False, True
+        params["output_directory"] = str(tmp_path) + "/"
+        hf.parRandom.reseed(123)
+        asp = hf.ActiveSubspaceProjector(Obs(), prior, parameters=params)
+        d, dec, enc = asp.construct_input_subspace(prior_preconditioned=True)
+        dn, decn, _ = asp.construct_output_subspace()
+        results[serialized] = (d, dec.to_dense(), enc.to_dense(), dn, asp.Omega_GN.to_dense())
+    d_b, V_b, E_b, dn_b, Om_b = results[False]
+    d_s, V_s, E_s, dn_s, Om_s = results[True]
+    np.testing.assert_array_equal(Om_b, Om_s)
+    assert np.linalg.norm(d_b - d_s) / np.linalg.norm(d_b) < 1e-10
+    assert np.linalg.norm(dn_b - dn_s) / np.linalg.norm(dn_b) < 1e-10
+    # oracle parity on the same Omega, R-orthonormality, encoder = R decoder
+    d_ref, V_ref = hp_o.double_pass_g(hf_o.MeanJTJOperator(J), hp_o.SparseOperator(Rm), hp_o.SparseLUSolver(Rm),
+                                      np.asfortranarray(Om_b), 20, s=1)
+    assert hp_o.eig_rel_err(d_b, d_ref) < 1e-7
+    assert np.linalg.norm(V_b.T @ (Rm @ V_b) - np.eye(20)) / np.sqrt(20) < 1e-10
+    assert rel(E_b, Rm @ V_b) < 1e-10
+    saved = np.load(os.path.join(str(tmp_path), "AS_%d_input_decoder.npy" % ns))
+    assert saved.shape == (N, 20)
+    assert os.path.exists(os.path.join(str(tmp_path), "AS_%d_d_GN.npy" % ns))
+    assert os.path.exists(os.path.join(str(tmp_path), "AS_%d_output_decoder.npy" % ns))
+
+
+# ------------------------------------------------------------------ size-independent properties at larger sizes
+def test_large_pod_properties(ctx):
+    """Down-scaled config 3 (N=50,000, 512 snapshots, r=128, p=10) generated on the device: invariants only."""
+    from hippyflow_amd import workloads
+    wl = workloads.pod_workload(N=50000, n=512, latent=192, rate=0.05, seed=3)
+    hf.parRandom.reseed(5)
+    Omega = hf.MultiVector(50000, 138)
+    hf.parRandom.normal(1.0, Omega)
+    d, U = hf.doublePass(wl.operator, Omega, 128, s=1)
+    G = U.dot_mv(U)
+    assert np.linalg.norm(G - np.eye(128)) / np.sqrt(128) < 1e-10
+    AU = hf.MultiVector(50000, 128)
+    wl.operator.matMvMult(U, AU)
+    Rn = hf.MultiVector(AU)
+    hf.MvDSmatMult(U, np.diag(d), Rn)
+    Rn.axpy(-1.0, AU)
+    assert np.linalg.norm(Rn.norm()) / np.linalg.norm(AU.norm()) < 1e-4
+    assert hp_o.eig_rel_err(d[:64], wl.exact_eigenvalues[:64]) < 1e-6            # known spectrum of the synthetic set
