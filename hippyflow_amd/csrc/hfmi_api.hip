@@ -777,7 +777,7 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
       right = BZ;
     }
     HFMI_TRY(launch_tsgemm_tn(ctx, Q->p, Q->ld, k, right->p, right->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_GRAM), SM_LD, 1, 0));
-    const int rtot_mode = want_r ? (passes == 0 ? 1 : 2) : 0;
+    const int rtot_mode = (passes == 0) ? 1 : 2;   // always track R = R_p ... R_1: its diagonal exposes dependent columns
     HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, shift_rel, pivot_tol));
     hfmi_status_words st;
     HFMI_TRY(read_status(ctx, &st));
@@ -789,6 +789,19 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     if (passes >= 2 && !st.shifted && st.gram_dev < 1e-2) break;
     if (passes >= max_passes) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: no convergence in %d Cholesky-QR passes (defect %.2e)", passes, st.gram_dev);
   }
+  // The reference's MGS zeroes a column whose norm drops below 10 eps of its pre-sweep norm
+  // (numerically dependent); Cholesky-QR would instead normalise round-off noise.  R_jj / ||z_j|| is that
+  // drop: hand such blocks to the Gram-Schmidt route, which reproduces the reference's behaviour.
+  {
+    std::vector<double> rt((size_t)k * SM_LD), cn(k);
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_RTOT), (size_t)k * SM_LD, rt.data()));
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_AUX), (size_t)k, cn.data()));
+    for (int j = 0; j < k; ++j)
+      if (!(rt[(size_t)j * SM_LD + j] > 100.0 * 2.220446049250313e-16 * cn[j]))
+        HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: vector %d is numerically dependent on its predecessors (R_jj/||z_j|| = %.2e)", j,
+                  cn[j] > 0 ? rt[(size_t)j * SM_LD + j] / cn[j] : 0.0);
+  }
+  (void)want_r;
   if (B && BQ) HFMI_TRY(hfmi_op_apply(B, Q, BQ, 0));
   if (passes_out) *passes_out = passes;
   return HFMI_OK;

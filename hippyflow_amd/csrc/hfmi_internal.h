@@ -46,7 +46,7 @@ struct hfmi_block {
 // Small dense matrices live in one fixed device arena (row-major, ld = SM_LD).
 #define SM_MAXK 256
 #define SM_LD 256
-enum { SM_GRAM = 0, SM_R, SM_RINV, SM_RTOT, SM_T, SM_V, SM_TMP, SM_TMP2, SM_NSLOTS };
+enum { SM_GRAM = 0, SM_R, SM_RINV, SM_RTOT, SM_T, SM_V, SM_TMP, SM_TMP2, SM_AUX, SM_NSLOTS };
 
 struct hfmi_status_words {  // device-resident, read back by the host after small kernels
   double min_pivot_ratio;   // min_j pivot_j / G_jj

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
                                                             double* __restrict__ Rtot, double* __restrict__ Rtmp,
                                                             int ldo, int rtot_mode, double shift_rel,
                                                             double pivot_tol, double* __restrict__ gscratch,
-                                                            int use_lds, hfmi_status_words* __restrict__ status) {
+                                                            int use_lds, double* __restrict__ colnorm0,
+                                                            hfmi_status_words* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
   double* diag0 = red + 32;                            // k original diagonal entries
@@ -53,7 +54,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   __shared__ int s_break;
 
   // diag and orthonormality defect || D^-1/2 G D^-1/2 - I ||_F of the input
-  for (int i = tid; i < k; i += nthr) diag0[i] = G[i * ldg + i];
+  for (int i = tid; i < k; i += nthr) {
+    diag0[i] = G[i * ldg + i];
+    if (rtot_mode == 1) colnorm0[i] = sqrt(fmax(diag0[i], 0.0));  // norms of the ORIGINAL columns (first pass)
+  }
   __syncthreads();
   double dev = 0.0, tr = 0.0;
   for (int e = tid; e < k * k; e += nthr) {
@@ -187,7 +191,7 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
   hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(SMALL_THREADS), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
                      sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
-                     rtot_mode, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, ctx->status_dev);
+                     rtot_mode, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX), ctx->status_dev);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }

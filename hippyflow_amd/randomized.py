@@ -159,7 +159,9 @@ def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_m
         B_dev = as_device_operator(B, N, Omega.ctx)
         Binv_dev = as_device_operator(Binv, N, Omega.ctx)
         return _fused(A_dev, coll, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs)
-    Binv_op = Binv if (hasattr(Binv, "mult") and not hasattr(Binv, "solve")) else Solver2Operator(Binv)
+    # B^{-1}: a device operator / solver as is; a host solver object (solve(y, x) on numpy arrays, like the
+    # PETSc solvers of the reference) is reached through a host-callback operator
+    Binv_op = as_device_operator(Binv, N, Omega.ctx)
     Ybar = MultiVector(N, nvec, ctx=Omega.ctx)
     Q = MultiVector(Omega)
     for _ in range(s):

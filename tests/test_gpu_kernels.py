@@ -230,7 +230,7 @@ def test_orthogonalize_mgs_method_and_rank_deficiency(ctx):
         Q = hf.MultiVector.from_dense(Z)
         R = Q.orthogonalize(method)
         Qd = Q.to_dense()
-        assert R[3, 3] == 0.0 and not Qd[:, 3].any()    # the reference zeroes the dependent column
+        assert R[3, 3] == 0.0 and not Qd[:, 3].any(), "method %d" % method    # the reference zeroes the dependent column
         np.testing.assert_allclose(np.abs(Qd), np.abs(Qo), atol=1e-10)
         np.testing.assert_allclose(R, Ro, atol=1e-10)
 
