@@ -102,11 +102,11 @@ def cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o):
     cores = os.cpu_count() or 1
     k = Omega_host.shape[1]
     if args.workload == "as":
-        ns_s = 4
-        Jh = wl.J.view(0, ns_s * wl.q).to_vectors().reshape(ns_s, wl.q, N)     # dense Jacobians of 4 samples
+        ns_s = 16
+        Jh = wl.J.view(0, ns_s * wl.q).to_vectors().reshape(ns_s, wl.q, N)     # dense Jacobians of the sample
         W = Omega_host
         t0 = time.perf_counter()
-        Y = hf_o.mean_jtj_block(Jh, W)
+        Y = hf_o.mean_jtj_block_blas3(Jh, W)
         t_apply = time.perf_counter() - t0
         t0 = time.perf_counter()
         Q, _ = hp_o._qr_posdiag(Y)
@@ -212,14 +212,15 @@ def main():
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded latent-factor model, generated in HBM)",
            "config": desc}
 
-    # roofline of the dominant kernel, from per-launch HIP events recorded inside the timed region
-    dom = max(prof, key=lambda kname: prof[kname]["ms"])
-    pk = prof[dom]
-    if pk["launches"] > 0 and pk["ms"] > 0:
+    # roofline of the dominant kernel (= the (kernel, shape) group with the largest total time), from per-launch
+    # HIP events recorded inside the timed region on the stream the kernels run on
+    prof = [g for g in prof if g["launches"] > 0 and g["ms"] > 0]
+    if prof:
+        pk = max(prof, key=lambda g: g["ms"])
         avg_ms = pk["ms"] / pk["launches"]
-        tflops = pk["flops"] / pk["launches"] / (avg_ms * 1e-3) / 1e12
-        gbs = pk["bytes"] / pk["launches"] / (avg_ms * 1e-3) / 1e9
-        ai = pk["flops"] / pk["bytes"]
+        tflops = pk["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
+        gbs = pk["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        ai = pk["flops_per_launch"] / pk["bytes_per_launch"]
         ridge = FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         if ai >= ridge:
             out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -227,14 +228,19 @@ def main():
         else:
             out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "traffic": None}
-        out["roofline"].update({"kernel": dom, "avg_launch_ms": avg_ms, "launches_per_step": pk["launches"] / args.steps,
-                                "algorithmic_flops_per_launch": pk["flops"] / pk["launches"],
-                                "algorithmic_bytes_per_launch": pk["bytes"] / pk["launches"],
-                                "arithmetic_intensity_flop_per_byte": ai, "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+        out["roofline"].update({"kernel": "%s m=%d k=%d N=%d" % (pk["kernel"], pk["m"], pk["k"], pk["N"]), "avg_launch_ms": avg_ms,
+                                "launches_per_step": pk["launches"] / args.steps,
+                                "algorithmic_flops_per_launch": pk["flops_per_launch"],
+                                "algorithmic_bytes_per_launch": pk["bytes_per_launch"],
+                                "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+                                "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                                 "fp64_mfma_frac": tflops / FP64_MFMA_PEAK_TFLOPS})
-        out["kernels"] = {kname: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
-                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None}
-                          for kname, v in prof.items()}
+        mfma_ms = sum(g["ms"] for g in prof) / args.steps
+        out["kernels"] = [{"kernel": g["kernel"], "m": g["m"], "k": g["k"], "N": g["N"], "ms_per_step": g["ms"] / args.steps,
+                           "launches_per_step": g["launches"] / args.steps, "avg_launch_ms": g["ms"] / g["launches"],
+                           "tflops": g["flops_per_launch"] * g["launches"] / (g["ms"] * 1e-3) / 1e12}
+                          for g in sorted(prof, key=lambda g: -g["ms"])]
+        out["ms_per_step_in_mfma_kernels"] = mfma_ms
     try:
         out["device_peaks_measured"] = ctx.bench_peaks()
     except Exception as exc:   # the micro-benchmark is informative only

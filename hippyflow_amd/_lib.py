@@ -75,7 +75,8 @@ SIGNATURES = {
     "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
     "hfmi_bench_peaks": [_P, _D, _D, _D],
     "hfmi_profile_begin": [_P],
-    "hfmi_profile_end": [_P, _D, C.POINTER(C.c_int64), _D, _D],
+    "hfmi_profile_end": [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), _D,
+                         C.POINTER(C.c_int64), _D, _D],
 }
 NON_STATUS = {"hfmi_last_error": (C.c_char_p, []), "hfmi_version": (C.c_int, [])}
 
@@ -187,11 +188,16 @@ class Context:
         call("hfmi_profile_begin", self.handle)
 
     def profile_end(self):
-        """{kernel class: {ms, launches, flops, bytes}} for the MFMA kernels launched since profile_begin."""
-        ms, n, fl, by = (C.c_double * 2)(), (C.c_int64 * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
-        call("hfmi_profile_end", self.handle, ms, n, fl, by)
+        """One record per distinct (MFMA kernel, shape) launched since profile_begin: total ms, launches and the
+        algorithmic flops / bytes of one launch."""
+        G = 64
+        ng = C.c_int(0)
+        kind, shape = (C.c_int * G)(), (C.c_int64 * (3 * G))()
+        ms, n, fl, by = (C.c_double * G)(), (C.c_int64 * G)(), (C.c_double * G)(), (C.c_double * G)()
+        call("hfmi_profile_end", self.handle, G, C.byref(ng), kind, shape, ms, n, fl, by)
         names = ("k_tsgemm_tn", "k_tsgemm_nn")
-        return {names[i]: {"ms": ms[i], "launches": int(n[i]), "flops": fl[i], "bytes": by[i]} for i in range(2)}
+        return [{"kernel": names[kind[g]], "m": shape[3 * g], "k": shape[3 * g + 1], "N": shape[3 * g + 2], "ms": ms[g],
+                 "launches": int(n[g]), "flops_per_launch": fl[g], "bytes_per_launch": by[g]} for g in range(ng.value)]
 
     def close(self):
         if self.handle:

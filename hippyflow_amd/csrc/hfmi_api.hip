@@ -996,12 +996,16 @@ extern "C" int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const h
 }
 
 // ------------------------------------------------------------------ instrumentation
-int prof_start(hfmi_ctx* ctx, int kind, double flops, double bytes) {
+int prof_start(hfmi_ctx* ctx, int kind, int64_t m, int64_t k, int64_t N) {
   if (!ctx->profiling) return -1;
   hfmi_ctx::prof_rec r;
   r.kind = kind;
-  r.flops = flops;
-  r.bytes = bytes;
+  r.m = m;
+  r.k = k;
+  r.N = N;
+  // algorithmic work (each operand touched once): flops 2 N m k, bytes 8 (N m + N k + m k)
+  r.flops = 2.0 * (double)N * (double)m * (double)k;
+  r.bytes = 8.0 * ((double)N * m + (double)N * k + (double)m * k);
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
   (void)hipEventRecord(r.e0, ctx->stream);
   ctx->prof.push_back(r);
@@ -1021,28 +1025,39 @@ extern "C" int hfmi_profile_begin(hfmi_ctx* ctx) {
   ctx->profiling = true;
   return HFMI_OK;
 }
-extern "C" int hfmi_profile_end(hfmi_ctx* ctx, double* ms2, int64_t* launches2, double* flops2, double* bytes2) {
-  if (!ctx || !ms2 || !launches2 || !flops2 || !bytes2) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+extern "C" int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int* kind, int64_t* shape, double* ms,
+                                int64_t* launches, double* flops_per_launch, double* bytes_per_launch) {
+  if (!ctx || !ngroups || !kind || !shape || !ms || !launches || !flops_per_launch || !bytes_per_launch)
+    HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   ctx->profiling = false;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 2; ++i) {
-    ms2[i] = 0.0;
-    launches2[i] = 0;
-    flops2[i] = 0.0;
-    bytes2[i] = 0.0;
-  }
+  int ng = 0;
   for (auto& r : ctx->prof) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.kind >= 0 && r.kind < 2) {
-      ms2[r.kind] += ms;
-      launches2[r.kind] += 1;
-      flops2[r.kind] += r.flops;
-      bytes2[r.kind] += r.bytes;
-    }
+    float t = 0.f;
+    const bool ok = hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess;
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
+    if (!ok) continue;
+    int g = 0;
+    for (; g < ng; ++g)
+      if (kind[g] == r.kind && shape[3 * g] == r.m && shape[3 * g + 1] == r.k && shape[3 * g + 2] == r.N) break;
+    if (g == ng) {
+      if (ng >= max_groups) continue;
+      kind[g] = r.kind;
+      shape[3 * g] = r.m;
+      shape[3 * g + 1] = r.k;
+      shape[3 * g + 2] = r.N;
+      ms[g] = 0.0;
+      launches[g] = 0;
+      flops_per_launch[g] = r.flops;
+      bytes_per_launch[g] = r.bytes;
+      ++ng;
+    }
+    ms[g] += t;
+    launches[g] += 1;
   }
   ctx->prof.clear();
+  *ngroups = ng;
   return HFMI_OK;
 }
 extern "C" int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, int reps, double* host_C, double* avg_ms) {

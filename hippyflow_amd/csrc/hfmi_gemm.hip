@@ -279,7 +279,7 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nsplit * mpad * kpad * sizeof(double), &partv));
   double* part = (double*)partv;
   // algorithmic work of this launch: flops 2 N m k, bytes 8 (N m + N k + m k)
-  const int pidx = prof_start(ctx, 0, 2.0 * (double)N * m * k, 8.0 * ((double)N * m + (double)N * k + (double)m * k));
+  const int pidx = prof_start(ctx, 0, m, k, N);
 #define TN_NT(NTV)                                                                                             \
   case NTV:                                                                                                    \
     HFMI_TRY(tn_dispatch_mt<NTV>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad)); \
@@ -319,28 +319,42 @@ int launch_tsgemm_tn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
 constexpr int NN_KC = 32;  // reduction indices per LDS stage (8 MFMA k-steps)
 
 // Preconditions: lda multiple of 32 and >= round_up(N,32) (rows beyond N readable); S finite, ld even.
+// The reduction axis m may be split over gridDim-many workgroups (msplit > 1): each split writes a raw partial
+// block and k_reduce_nn adds them in a fixed order -- this is what balances the grid over the 256 CUs when
+// there are only a few row tiles (quantisation), at the price of msplit * N * r * 16 bytes of extra traffic.
 template <int TT, int NT>
 __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
                                                       const double* __restrict__ S, int lds_, int r,
-                                                      double* __restrict__ Y, int64_t ldy, int64_t N) {
+                                                      double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles,
+                                                      int msplit, int mchunk, int64_t pstride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2][NN_KC][SLD]
   constexpr int COLS = NT * 16;
   constexpr int SLD = COLS + ((NT % 2 == 0) ? 16 : 0);  // SLD % 32 == 16: conflict-free ds_read_b64
-  constexpr int TP = TT / 2;
+  constexpr int TP = TT / 2;                            // tile pairs fed by one 16-byte load per lane
+  constexpr bool ODD = (TT & 1) != 0;                   // plus one single tile fed by an 8-byte load
+  constexpr int TPA = TP > 0 ? TP : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, kk = lane >> 4;
-  const int64_t t0 = (int64_t)blockIdx.x * (64 * TT) + wave * (16 * TT);
-  const int nstages = (m + NN_KC - 1) / NN_KC;
+  const int logical = xcd_remap(blockIdx.x, ntiles * msplit);
+  const int split = logical / ntiles, tile = logical % ntiles;
+  const int64_t t0 = (int64_t)tile * (64 * TT) + wave * (16 * TT);
+  const int i_begin = split * mchunk;
+  int i_end = i_begin + mchunk;
+  if (i_end > m) i_end = m;
+  const int nstages = (i_end - i_begin + NN_KC - 1) / NN_KC;
   const int64_t tmax = round_up_dev(N, 32) - 2;
+  double* Yo = Y + (int64_t)split * pstride;
 
   // streamed operand: lane (c16, kk) fetches rows t0 + tp*32 + 2*c16 + {0,1} of vector i0 + kk
-  int64_t toff[TP];
+  int64_t toff[TPA];
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
     int64_t t = t0 + tp * 32 + 2 * c16;
     toff[tp] = t > tmax ? tmax : t;  // rows >= N are never stored; keep the address legal
   }
+  int64_t toff1 = t0 + TP * 32 + c16;
+  if (toff1 > tmax + 1) toff1 = tmax + 1;
   // S stage: NN_KC rows x COLS cols as 16-byte pairs, NT per thread
   int s_row[NT], s_cp[NT];
 #pragma unroll
@@ -356,6 +370,10 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[tt][nt] = d4{0.0, 0.0, 0.0, 0.0};
 
+  struct AFrag {
+    d2 p[TPA];
+    double s;
+  };
   d2 sreg[NT];
   auto stage_load = [&](int is) {
 #pragma unroll
@@ -369,43 +387,48 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
 #pragma unroll
     for (int qd = 0; qd < NT; ++qd) {
       d2 v = sreg[qd];
-      if (is + s_row[qd] >= m) v = d2{0.0, 0.0};  // rows past the reduction length contribute nothing
+      if (is + s_row[qd] >= i_end) v = d2{0.0, 0.0};  // rows past this split's range contribute nothing
       *reinterpret_cast<d2*>(L + s_row[qd] * SLD + s_cp[qd] * 2) = v;
     }
   };
-  auto load_a = [&](d2(&dst)[TP], int i0) {
+  auto load_a = [&](AFrag& dst, int i0) {
     int col = i0 + kk;
     if (col > m - 1) col = m - 1;
     const double* p = A + (int64_t)col * lda;
 #pragma unroll
-    for (int tp = 0; tp < TP; ++tp) dst[tp] = *reinterpret_cast<const d2*>(p + toff[tp]);
+    for (int tp = 0; tp < TP; ++tp) dst.p[tp] = *reinterpret_cast<const d2*>(p + toff[tp]);
+    if (ODD) dst.s = p[toff1];
   };
   auto ldss = [&](double(&sf)[NT], const double* L, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) sf[nt] = L[(ks * 4 + kk) * SLD + nt * 16 + c16];
   };
-  auto mma = [&](const d2(&a)[TP], const double(&sf)[NT]) {
+  auto mma = [&](const AFrag& a, const double(&sf)[NT]) {
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        acc[2 * tp][nt] = MFMA_F64(sf[nt], a[tp].x, acc[2 * tp][nt]);
-        acc[2 * tp + 1][nt] = MFMA_F64(sf[nt], a[tp].y, acc[2 * tp + 1][nt]);
+        acc[2 * tp][nt] = MFMA_F64(sf[nt], a.p[tp].x, acc[2 * tp][nt]);
+        acc[2 * tp + 1][nt] = MFMA_F64(sf[nt], a.p[tp].y, acc[2 * tp + 1][nt]);
       }
+    if (ODD) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[TT - 1][nt] = MFMA_F64(sf[nt], a.s, acc[TT - 1][nt]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  stage_load(0);
-  stage_store(lds, 0);
+  stage_load(i_begin);
+  stage_store(lds, i_begin);
   __syncthreads();
   // register ring of 4 k-steps for the streamed operand (prefetch distance 3), ping-pong LDS fragments
-  d2 a0[TP], a1[TP], a2[TP], a3[TP];
+  AFrag a0, a1, a2, a3;
   double sf0[NT], sf1[NT];
-  load_a(a0, 0);
-  load_a(a1, 4);
-  load_a(a2, 8);
+  load_a(a0, i_begin);
+  load_a(a1, i_begin + 4);
+  load_a(a2, i_begin + 8);
   for (int s = 0; s < nstages; ++s) {
-    const int is = s * NN_KC;
+    const int is = i_begin + s * NN_KC;
     const bool has_next = s + 1 < nstages;
     if (has_next) stage_load(is + NN_KC);
     const double* L = lds + (s & 1) * NN_KC * SLD;
@@ -445,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
     for (int rg = 0; rg < 4; ++rg) {
       const int j = nt * 16 + kk + 4 * rg;
       if (j < r) {
-        double* yc = Y + (int64_t)j * ldy;
+        double* yc = Yo + (int64_t)j * ldy;
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
           const int64_t t = t0 + tp * 32 + 2 * c16;
@@ -455,8 +478,41 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
             yc[t] = acc[2 * tp][nt][rg];
           }
         }
+        if (ODD) {
+          const int64_t t = t0 + TP * 32 + c16;
+          if (t < N) yc[t] = acc[TT - 1][nt][rg];
+        }
       }
     }
+}
+
+// Y[j][t] = sum_s part[s][j][t]  (fixed order), rows t < N
+__global__ void k_reduce_nn(const double* __restrict__ part, int msplit, int64_t pstride, int64_t ldp, double* __restrict__ Y,
+                            int64_t ldy, int64_t N, int r) {
+  for (int j = blockIdx.y; j < r; j += gridDim.y) {
+    const double* p = part + (int64_t)j * ldp;
+    double* y = Y + (int64_t)j * ldy;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 acc = *reinterpret_cast<const d2*>(p + t);
+        for (int sp = 1; sp < msplit; ++sp) {
+          const d2 v = *reinterpret_cast<const d2*>(p + (int64_t)sp * pstride + t);
+          acc.x += v.x;
+          acc.y += v.y;
+        }
+        *reinterpret_cast<d2*>(y + t) = acc;
+      } else {
+        double acc = p[t];
+        for (int sp = 1; sp < msplit; ++sp) acc += p[(int64_t)sp * pstride + t];
+        y[t] = acc;
+      }
+    }
+  }
+}
+
+static inline int nn_tt(int nt) {
+  static const int t[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
+  return t[nt];
 }
 
 template <int TT, int NT>
@@ -466,9 +522,46 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
   const size_t shmem = (size_t)2 * NN_KC * SLD * sizeof(double);
   auto kern = k_tsgemm_nn<TT, NT>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  dim3 grid((unsigned)((N + 64 * TT - 1) / (64 * TT))), block(256);
-  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N);
+  const int ntiles = (int)((N + 64 * TT - 1) / (64 * TT));
+  // split the reduction axis so that the grid fills the chip in (nearly) whole rounds of CUs
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int stages = (m + NN_KC - 1) / NN_KC;
+  int best = 1;
+  double best_cost = 1e300;
+  for (int ns = 1; ns <= 64; ++ns) {
+    if (ns > 1 && stages / ns < 8) break;
+    const int64_t blocks = (int64_t)ntiles * ns;
+    const int64_t rounds = (blocks + cus - 1) / cus;
+    const double eff = (double)blocks / (double)(rounds * cus);
+    const double part_ratio = (ns > 1) ? 2.0 * ns * (double)r / (double)m : 0.0;  // partial write+read vs streaming A
+    const double cost = 1.0 / eff + part_ratio;
+    if (cost < best_cost - 1e-12) {
+      best_cost = cost;
+      best = ns;
+    }
+  }
+  int msplit = best;
+  int mchunk = (int)round_up((m + msplit - 1) / msplit, NN_KC);
+  msplit = (m + mchunk - 1) / mchunk;
+  double* out = Y;
+  int64_t ldo = ldy, pstride = 0;
+  if (msplit > 1) {
+    ldo = round_up(N, 32);
+    pstride = ldo * r;
+    void* pv = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)msplit * pstride * sizeof(double), &pv));
+    out = (double*)pv;
+  }
+  dim3 grid((unsigned)(ntiles * msplit)), block(256);
+  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, ntiles, msplit, mchunk, pstride);
   HIP_TRY(hipGetLastError());
+  if (msplit > 1) {
+    int64_t gx = ((N + 1) / 2 + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_reduce_nn, dim3((unsigned)gx, (unsigned)r), dim3(256), 0, ctx->stream, (const double*)out, msplit,
+                       pstride, ldo, Y, ldy, N, r);
+    HIP_TRY(hipGetLastError());
+  }
   return HFMI_OK;
 }
 
@@ -479,8 +572,8 @@ static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   case NTV:               \
     return nn_launch_inst<TTV, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
   switch (nt) {
-    NN_CASE(1, 4) NN_CASE(2, 4) NN_CASE(3, 4) NN_CASE(4, 4) NN_CASE(5, 4) NN_CASE(6, 4) NN_CASE(7, 4) NN_CASE(8, 4)
-    NN_CASE(9, 2) NN_CASE(10, 2) NN_CASE(11, 2) NN_CASE(12, 2) NN_CASE(13, 2) NN_CASE(14, 2) NN_CASE(15, 2)
+    NN_CASE(1, 8) NN_CASE(2, 8) NN_CASE(3, 8) NN_CASE(4, 8) NN_CASE(5, 6) NN_CASE(6, 5) NN_CASE(7, 4) NN_CASE(8, 4)
+    NN_CASE(9, 3) NN_CASE(10, 3) NN_CASE(11, 2) NN_CASE(12, 2) NN_CASE(13, 2) NN_CASE(14, 2) NN_CASE(15, 2)
     NN_CASE(16, 2)
   }
 #undef NN_CASE
@@ -522,7 +615,7 @@ int launch_tsgemm_nn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   }
   for (int r0 = 0; r0 < r; r0 += 256) {
     const int rp = (r - r0 < 256) ? (r - r0) : 256;
-    const int pidx = prof_start(ctx, 1, 2.0 * (double)N * m * rp, 8.0 * ((double)N * m + (double)N * rp + (double)m * rp));
+    const int pidx = prof_start(ctx, 1, m, rp, N);
     HFMI_TRY(nn_panel(ctx, A, lda, m, S + r0, lds_, rp, out + (int64_t)r0 * ldo, ldo, N));
     prof_stop(ctx, pidx);
   }

@@ -74,10 +74,10 @@ struct hfmi_ctx {
   std::vector<hfmi_block*> tmp_blocks;  // cached temporaries for the fused solves
   // optional per-launch event timing of the two MFMA kernel classes
   bool profiling;
-  struct prof_rec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+  struct prof_rec { int kind; int64_t m, k, N; hipEvent_t e0, e1; double flops, bytes; };
   std::vector<prof_rec> prof;
 };
-int prof_start(hfmi_ctx* ctx, int kind, double flops, double bytes);  // returns record index or -1
+int prof_start(hfmi_ctx* ctx, int kind, int64_t m, int64_t k, int64_t N);  // returns record index or -1
 int prof_stop(hfmi_ctx* ctx, int idx);
 
 static inline double* sm_ptr(hfmi_ctx* c, int slot) { return c->small + (size_t)slot * SM_MAXK * SM_LD; }

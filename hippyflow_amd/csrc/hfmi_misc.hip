@@ -394,7 +394,7 @@ int launch_gamma_apply(hfmi_ctx* ctx, double* G, int ldg, int ndata, int q, int 
 }
 
 // ------------------------------------------------------------------ micro-benchmarks (roofline denominators)
-__global__ __launch_bounds__(256, 1) void k_bench_mfma(double* out, int iters) {
+__global__ __launch_bounds__(256, 2) void k_bench_mfma(double* out, int iters) {
   d4 acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
@@ -433,23 +433,23 @@ int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, d
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   float ms = 0.f;
   // fp64 MFMA: 4 waves/CU (one per SIMD) x 8 independent accumulators
-  const int it1 = 20000;
-  hipLaunchKernelGGL(k_bench_mfma, dim3(cus), dim3(256), 0, ctx->stream, out, 100);
+  const int it1 = 2000, g1 = cus * 16;
+  hipLaunchKernelGGL(k_bench_mfma, dim3(g1), dim3(256), 0, ctx->stream, out, 100);
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_bench_mfma, dim3(cus), dim3(256), 0, ctx->stream, out, it1);
+  hipLaunchKernelGGL(k_bench_mfma, dim3(g1), dim3(256), 0, ctx->stream, out, it1);
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));
   HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  *mfma_tflops = (double)cus * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+  *mfma_tflops = (double)g1 * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
   // fp64 vector FMA: 8 waves/CU x 16 independent chains
-  const int it2 = 20000;
-  hipLaunchKernelGGL(k_bench_fma, dim3(cus * 2), dim3(256), 0, ctx->stream, out, 100);
+  const int it2 = 2000, g2 = cus * 32;
+  hipLaunchKernelGGL(k_bench_fma, dim3(g2), dim3(256), 0, ctx->stream, out, 100);
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_bench_fma, dim3(cus * 2), dim3(256), 0, ctx->stream, out, it2);
+  hipLaunchKernelGGL(k_bench_fma, dim3(g2), dim3(256), 0, ctx->stream, out, it2);
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));
   HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  *fma_tflops = (double)cus * 2 * 256 * it2 * 16 * 2.0 / (ms * 1e-3) / 1e12;
+  *fma_tflops = (double)g2 * 256 * it2 * 16 * 2.0 / (ms * 1e-3) / 1e12;
   // HBM copy
   const int64_t n = (int64_t)(bytes / 2 / sizeof(d2));
   d2* src = (d2*)buf;

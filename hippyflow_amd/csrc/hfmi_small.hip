@@ -7,8 +7,19 @@
 //                  per eigenvector-matrix row) so the eigenvector update never sits on the critical path.
 #include "hfmi_internal.h"
 
+#include <stdlib.h>
 #define SMALL_THREADS 1024
 #define EPS_D 2.220446049250313e-16
+// workgroup size of the one-workgroup kernels (tuning knob for experiments: HFMI_SMALL_THREADS)
+static int small_threads() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("HFMI_SMALL_THREADS");
+    v = e ? atoi(e) : SMALL_THREADS;
+    if (v < 64 || v > 1024 || (v & 63)) v = SMALL_THREADS;
+  }
+  return v;
+}
 
 __device__ __forceinline__ double block_sum(double v, double* scratch /* >= 16 doubles, LDS */) {
 #pragma unroll
@@ -53,6 +64,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   const int tid = threadIdx.x, nthr = blockDim.x;
   __shared__ int s_break;
 
+  // 2-D thread map (no integer divisions in any hot loop): lanes run along a row, waves over rows
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+
   // diag and orthonormality defect || D^-1/2 G D^-1/2 - I ||_F of the input
   for (int i = tid; i < k; i += nthr) {
     diag0[i] = G[i * ldg + i];
@@ -60,14 +74,14 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   }
   __syncthreads();
   double dev = 0.0, tr = 0.0;
-  for (int e = tid; e < k * k; e += nthr) {
-    const int i = e / k, j = e % k;
-    const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
-    const double dd = diag0[i] * diag0[j];
-    const double x = (dd > 0.0 ? g / sqrt(dd) : 0.0) - (i == j ? 1.0 : 0.0);
-    dev += x * x;
-    if (i == j) tr += g;
-  }
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) {
+      const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+      const double dd = diag0[i] * diag0[j];
+      const double x = (dd > 0.0 ? g * rsqrt(dd) : 0.0) - (i == j ? 1.0 : 0.0);
+      dev += x * x;
+      if (i == j) tr += g;
+    }
   dev = block_sum(dev, red);
   tr = block_sum(tr, red);
 
@@ -75,12 +89,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   double min_ratio = 1e300;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const double shift = attempt ? shift_rel * tr : 0.0;
-    for (int e = tid; e < k * k; e += nthr) {
-      const int i = e / k, j = e % k;
-      double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
-      if (i == j) g += shift;
-      M[i * ldm + j] = (j >= i) ? g : 0.0;
-    }
+    for (int i = wave; i < k; i += nw)
+      for (int j = lane; j < k; j += 64) {
+        double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+        if (i == j) g += shift;
+        M[i * ldm + j] = (j >= i) ? g : 0.0;
+      }
     if (tid == 0) s_break = 0;
     __syncthreads();
     double ratio_local = 1e300;
@@ -98,10 +112,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
       for (int c = j + tid; c < k; c += nthr) M[j * ldm + c] = (c == j) ? rjj : M[j * ldm + c] * inv;
       __syncthreads();
       // trailing update of the upper triangle: M[i][c] -= R[j][i] R[j][c], j < i <= c
-      const int rem = k - j - 1;
-      for (int e = tid; e < rem * rem; e += nthr) {
-        const int i = j + 1 + e / rem, c = j + 1 + e % rem;
-        if (c >= i) M[i * ldm + c] -= M[j * ldm + i] * M[j * ldm + c];
+      for (int i = j + 1 + wave; i < k; i += nw) {
+        const double rji = M[j * ldm + i];
+        for (int c = i + lane; c < k; c += 64) M[i * ldm + c] -= rji * M[j * ldm + c];
       }
       __syncthreads();
     }
@@ -124,16 +137,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
     return;
   }
   // R out (upper triangle, zeros below)
-  for (int e = tid; e < k * k; e += nthr) {
-    const int i = e / k, j = e % k;
-    Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
-  }
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
   __syncthreads();
   // in-place inverse of the upper triangle (dtrti2 ordering): after step j the leading (j+1) block of M holds
   // the inverse.  x_i = -(sum_{l=i}^{j-1} X[i][l] R[l][j]) / R[j][j] for i < j: one wave per row, lanes split
   // the dot product; results are parked in diag0 until every wave has finished reading column j.
   {
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     for (int j = 0; j < k; ++j) {
       const double xjj = 1.0 / M[j * ldm + j];
       for (int i = wave; i < j; i += nw) {
@@ -149,30 +159,24 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
       __syncthreads();
     }
   }
-  for (int e = tid; e < k * k; e += nthr) {
-    const int i = e / k, j = e % k;
-    Rinv[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
-  }
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) Rinv[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
   // running product of the R factors across Cholesky-QR passes: Rtot <- R * Rtot
   if (rtot_mode == 1) {
-    for (int e = tid; e < k * k; e += nthr) {
-      const int i = e / k, j = e % k;
-      Rtot[i * ldo + j] = Rout[i * ldo + j];
-    }
+    for (int i = wave; i < k; i += nw)
+      for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rout[i * ldo + j];
   } else if (rtot_mode == 2) {
     __syncthreads();
-    for (int e = tid; e < k * k; e += nthr) {
-      const int i = e / k, j = e % k;
-      double s = 0.0;
-      if (j >= i)
-        for (int l = i; l <= j; ++l) s += Rout[i * ldo + l] * Rtot[l * ldo + j];
-      Rtmp[i * ldo + j] = s;
-    }
+    for (int i = wave; i < k; i += nw)
+      for (int j = lane; j < k; j += 64) {
+        double acc = 0.0;
+        if (j >= i)
+          for (int l = i; l <= j; ++l) acc += Rout[i * ldo + l] * Rtot[l * ldo + j];
+        Rtmp[i * ldo + j] = acc;
+      }
     __syncthreads();
-    for (int e = tid; e < k * k; e += nthr) {
-      const int i = e / k, j = e % k;
-      Rtot[i * ldo + j] = Rtmp[i * ldo + j];
-    }
+    for (int i = wave; i < k; i += nw)
+      for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rtmp[i * ldo + j];
   }
   if (tid == 0) {
     status->min_pivot_ratio = min_ratio;
@@ -189,7 +193,7 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
   const size_t shmem = (32 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
-  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(SMALL_THREADS), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
+  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
                      sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
                      rtot_mode, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX), ctx->status_dev);
   HIP_TRY(hipGetLastError());
@@ -236,20 +240,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   double* red = reinterpret_cast<double*>(smem);                // 32
   double2* rot = reinterpret_cast<double2*>(red + 32);          // 128 (c, s) per pair
   double* Ad = reinterpret_cast<double*>(rot + 128);            // 256 diagonal copy / keys
-  double* lds_a = Ad + 256;
+  short* pa = reinterpret_cast<short*>(Ad + 256);               // 128 + 128 pair members of the current round
+  short* pb = pa + 128;
+  double* lds_a = reinterpret_cast<double*>(pb + 128);
   const int lda = use_lds ? (k | 1) : SM_LD;
   double* A = use_lds ? lds_a : gwork;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int n = (k + 1) & ~1;  // players (one dummy if k is odd)
   const int np = n / 2;
 
   double fro = 0.0;
-  for (int e = tid; e < k * k; e += nthr) {
-    const int i = e / k, j = e % k;
-    const double v = 0.5 * (T[i * ldt + j] + T[j * ldt + i]);
-    A[i * lda + j] = v;
-    fro += v * v;
-  }
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) {
+      const double v = 0.5 * (T[i * ldt + j] + T[j * ldt + i]);
+      A[i * lda + j] = v;
+      fro += v * v;
+    }
   fro = block_sum(fro, red);
   __syncthreads();
   const double tol2 = EPS_D * EPS_D * fro;
@@ -258,18 +265,19 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   double off2 = 0.0;
   for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
     off2 = 0.0;
-    for (int e = tid; e < k * k; e += nthr) {
-      const int i = e / k, j = e % k;
-      if (j > i) off2 += 2.0 * A[i * lda + j] * A[i * lda + j];
-    }
+    for (int i = wave; i < k; i += nw)
+      for (int j = i + 1 + lane; j < k; j += 64) off2 += 2.0 * A[i * lda + j] * A[i * lda + j];
     off2 = block_sum(off2, red);
     __syncthreads();
     if (off2 <= tol2) break;
     for (int r = 0; r < n - 1; ++r) {
-      // phase 1: one rotation per pair
+      // phase 1: the round's pairs (kept in LDS: no modulo arithmetic in the update phase) and one
+      // rotation per pair
       if (tid < np) {
         int a, b;
         rr_pair(n, r, tid, a, b);
+        pa[tid] = (short)a;
+        pb[tid] = (short)b;
         double c = 1.0, s = 0.0;
         if (b < k) {
           const double apq = A[a * lda + b];
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
           if (apq != 0.0 && !(fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq))) {
             const double theta = 0.5 * (aqq - app) / apq;
             const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
+            c = rsqrt(t * t + 1.0);
             s = t * c;
           }
         }
@@ -286,34 +294,43 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
         rotlog[((size_t)sweeps * (n - 1) + r) * np + tid] = make_double2(c, s);
       }
       __syncthreads();
-      // phase 2: every 2x2 block (P, Q) <- J_P^T * block * J_Q
-      for (int e = tid; e < np * np; e += nthr) {
-        const int P = e / np, Q = e % np;
-        int p1, q1, p2, q2;
-        rr_pair(n, r, P, p1, q1);
-        rr_pair(n, r, Q, p2, q2);
-        // a dummy player (k odd) has index >= k: its entries read as 0 and are never written; the rotation of
-        // its pair is the identity, so the real member still receives the other pairs' rotations
-        const bool r2 = q1 < k, c2 = q2 < k;
-        const double2 rp = rot[P], rq = rot[Q];
-        const double x11 = A[p1 * lda + p2];
-        const double x12 = c2 ? A[p1 * lda + q2] : 0.0;
-        const double x21 = r2 ? A[q1 * lda + p2] : 0.0;
-        const double x22 = (r2 && c2) ? A[q1 * lda + q2] : 0.0;
-        // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
-        const double y11 = rq.x * x11 - rq.y * x12, y12 = rq.y * x11 + rq.x * x12;
-        const double y21 = rq.x * x21 - rq.y * x22, y22 = rq.y * x21 + rq.x * x22;
-        // rows with J_P
-        double z11 = rp.x * y11 - rp.y * y21, z21 = rp.y * y11 + rp.x * y21;
-        double z12 = rp.x * y12 - rp.y * y22, z22 = rp.y * y12 + rp.x * y22;
-        if (P == Q) {
-          z12 = 0.0;
-          z21 = 0.0;
+      // phase 2: every 2x2 block {P, Q}, P <= Q, <- J_P^T * block * J_Q.  Only the upper triangle of the
+      // symmetric matrix is stored/updated (element (i, j) lives at A[min][max]): half the LDS traffic.
+      // Waves over P, lanes over Q >= P.
+      for (int P = wave; P < np; P += nw) {
+        const int p1 = pa[P], q1 = pb[P];          // p1 < q1
+        const double2 rp = rot[P];
+        const bool r2 = q1 < k;
+        for (int Q = P + lane; Q < np; Q += 64) {
+          const int p2 = pa[Q], q2 = pb[Q];        // p2 < q2
+          // a dummy player (k odd) has index >= k: its entries read as 0 and are never written; the rotation
+          // of its pair is the identity, so the real member still receives the other pairs' rotations
+          const bool c2 = q2 < k;
+          const double2 rq = rot[Q];
+#define UT(i, j) A[((i) < (j) ? (i) : (j)) * lda + ((i) < (j) ? (j) : (i))]
+          const double x11 = UT(p1, p2);
+          const double x12 = c2 ? UT(p1, q2) : 0.0;
+          const double x21 = r2 ? ((P == Q) ? x12 : UT(q1, p2)) : 0.0;
+          const double x22 = (r2 && c2) ? UT(q1, q2) : 0.0;
+          // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
+          const double y11 = rq.x * x11 - rq.y * x12, y12 = rq.y * x11 + rq.x * x12;
+          const double y21 = rq.x * x21 - rq.y * x22, y22 = rq.y * x21 + rq.x * x22;
+          // rows with J_P
+          const double z11 = rp.x * y11 - rp.y * y21, z21 = rp.y * y11 + rp.x * y21;
+          const double z12 = rp.x * y12 - rp.y * y22, z22 = rp.y * y12 + rp.x * y22;
+          UT(p1, p2) = z11;
+          if (P == Q) {
+            if (r2) {
+              UT(p1, q1) = 0.0;                    // the annihilated pivot
+              UT(q1, q1) = z22;
+            }
+          } else {
+            if (c2) UT(p1, q2) = z12;
+            if (r2) UT(q1, p2) = z21;
+            if (r2 && c2) UT(q1, q2) = z22;
+          }
+#undef UT
         }
-        A[p1 * lda + p2] = z11;
-        if (c2) A[p1 * lda + q2] = z12;
-        if (r2) A[q1 * lda + p2] = z21;
-        if (r2 && c2) A[q1 * lda + q2] = z22;
       }
       __syncthreads();
     }
@@ -339,6 +356,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
 }
 
 // Row i of V = e_i^T * (product of all logged rotations); one workgroup per row, the row lives in LDS.
+// The pair (a, b) of lane p in round r is ((r + p) mod (n-1), (r - p) mod (n-1)) -- advanced by +1 per round
+// with a wrap test instead of a modulo; lane 0 pairs the fixed player n-1 with r.
 __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restrict__ rotlog, int k,
                                                         const hfmi_status_words* __restrict__ status,
                                                         const int* __restrict__ perm, double* __restrict__ V, int ldv) {
@@ -348,15 +367,28 @@ __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restric
   for (int j = tid; j < n; j += blockDim.x) row[j] = (j == i) ? 1.0 : 0.0;
   __syncthreads();
   const int rounds = status->sweeps * (n - 1);
+  int a = 0, b = 0;
+  if (tid < np) rr_pair(n, 0, tid, a, b);
+  int ua = (tid == 0) ? 0 : tid % (n - 1);                      // un-ordered members for the increment
+  int ub = (tid == 0) ? 0 : (n - 1 - tid) % (n - 1);
+  int r = 0;
   for (int rr = 0; rr < rounds; ++rr) {
-    const int r = rr % (n - 1);
     if (tid < np) {
-      int a, b;
-      rr_pair(n, r, tid, a, b);
       const double2 cs = rotlog[(size_t)rr * np + tid];
       const double va = row[a], vb = row[b];
       row[a] = cs.x * va - cs.y * vb;
       row[b] = cs.y * va + cs.x * vb;
+      // next round's pair
+      r = (r + 1 == n - 1) ? 0 : r + 1;
+      if (tid == 0) {
+        a = r;
+        b = n - 1;
+      } else {
+        ua = (ua + 1 == n - 1) ? 0 : ua + 1;
+        ub = (ub + 1 == n - 1) ? 0 : ub + 1;
+        a = ua < ub ? ua : ub;
+        b = ua < ub ? ub : ua;
+      }
     }
     __syncthreads();
   }
@@ -366,16 +398,16 @@ __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restric
 
 int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_eig: k=%d out of range", k);
-  const int use_lds = (k <= 138) ? 1 : 0;
+  const int use_lds = (k <= 138) ? 1 : 0;   // 138*139*8 + 4.9 KB of tables = 158.3 KB <= 160 KB
   const int n = (k + 1) & ~1;
   const size_t log_bytes = (size_t)JAC_MAX_SWEEPS * (n - 1) * (n / 2) * sizeof(double2) + 1024 * sizeof(int);
   void* logv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_MISC, log_bytes, &logv));
   double2* rotlog = (double2*)logv;
   int* perm = (int*)((char*)logv + (size_t)JAC_MAX_SWEEPS * (n - 1) * (n / 2) * sizeof(double2));
-  const size_t shmem = (32 + 256 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
+  const size_t shmem = (32 + 256 + 256 + 64) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(SMALL_THREADS), shmem, ctx->stream, sm_ptr(ctx, slot_t), SM_LD, k,
+  hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_t), SM_LD, k,
                      sm_ptr(ctx, SM_TMP), use_lds, rotlog, dvals, perm, sort_by_abs, ctx->status_dev);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,

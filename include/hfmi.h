@@ -17,7 +17,7 @@
  *     processes.  All work is enqueued on the context's HIP stream.
  *   - a BLOCK is hippylib's MultiVector: nvec vectors of length N, each vector
  *     contiguous in HBM (column-major N x nvec with leading dimension ld,
- *     ld % 16 == 0, 128-byte aligned columns, rows N..ld-1 kept at zero).
+ *     ld % 32 == 0, 256-byte aligned columns, rows N..ld-1 kept at zero).
  *     Snapshot matrices (n snapshots of length N; PODProjector.py:340-357) and
  *     stacked Jacobians ((ndata*q) rows of length N; operatorWrappers.py:62-64)
  *     are blocks too: one vector per snapshot / per Jacobian row.
@@ -71,8 +71,8 @@ int hfmi_timer_stop(hfmi_ctx* ctx, double* milliseconds); /* synchronises */
 /* ---------------------------------------------------------------- blocks
  * hippylib MultiVector(vector, nvec) and its copy constructor. */
 int hfmi_block_create(hfmi_ctx* ctx, int64_t N, int nvec, hfmi_block** out); /* zero-filled */
-/* wrap device memory owned by the caller (e.g. a torch tensor): ld % 16 == 0, ld >= N,
- * dptr 128-byte aligned, rows N..ld-1 zero. */
+/* wrap device memory owned by the caller (e.g. a torch tensor): ld % 32 == 0, ld >= N,
+ * dptr 128-byte aligned; rows N..ld-1 are zeroed by the call. */
 int hfmi_block_wrap(hfmi_ctx* ctx, double* dptr, int64_t N, int nvec, int64_t ld, hfmi_block** out);
 /* view of vectors [first, first+count) of a block (MultiVector.__getitem__) */
 int hfmi_block_view(hfmi_block* parent, int first, int count, hfmi_block** out);
@@ -185,12 +185,14 @@ int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, i
 int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms);
 /* fp64 MFMA / fp64 FMA / HBM-copy micro-benchmarks (peak denominators measured in the same job) */
 int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbs);
-/* per-kernel-class HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from
- * the timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by
- * events on the context's stream.  end() synchronises and returns, for class 0 (tsgemm_tn) and
- * class 1 (tsgemm_nn): total milliseconds, launches, algorithmic flops and algorithmic bytes. */
+/* per-launch HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from the
+ * timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by events on
+ * the context's stream.  end() synchronises and returns one record per distinct (kernel, shape):
+ * kind[g] 0 = k_tsgemm_tn, 1 = k_tsgemm_nn; shape[3*g..] = (short-side rows m, columns k, long axis N);
+ * total milliseconds, launches, and the ALGORITHMIC flops / bytes of one launch. */
 int hfmi_profile_begin(hfmi_ctx* ctx);
-int hfmi_profile_end(hfmi_ctx* ctx, double* ms2, int64_t* launches2, double* flops2, double* bytes2);
+int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int* kind, int64_t* shape, double* ms,
+                     int64_t* launches, double* flops_per_launch, double* bytes_per_launch);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,17 @@ def mean_jtj_block(J, W, noise_cov_inv=None):
     return np.asfortranarray(Y / ndata)
 
 
+def mean_jtj_block_blas3(J, W, noise_cov_inv=None):
+    """Same as mean_jtj_block with the two contractions as threaded BLAS-3 matmuls over the stacked
+    (ndata*r, dM) Jacobian -- the "best-effort CPU" form timed as bench.py's cpu_baseline."""
+    ndata, r, dM = J.shape
+    Js = J.reshape(ndata * r, dM)
+    G = Js @ W                                        # (ndata*r, k)
+    if noise_cov_inv is not None:
+        G = (noise_cov_inv @ G.reshape(ndata, r, -1)).reshape(ndata * r, -1)
+    return np.asfortranarray(Js.T @ G / ndata)
+
+
 def mean_jjt_block(J, W):
     """Output-space counterpart (JJT, jacobian.py:169-193 averaged by
     SummedListOperator, activeSubspaceProjector.py:82-95):
