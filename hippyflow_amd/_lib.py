@@ -75,6 +75,7 @@ SIGNATURES = {
     "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
     "hfmi_bench_peaks": [_P, _D, _D, _D],
     "hfmi_profile_begin": [_P],
+    "hfmi_tuning_set": [C.c_char_p, C.c_int],
     "hfmi_profile_end": [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), _D,
                          C.POINTER(C.c_int64), _D, _D],
 }

@@ -44,14 +44,21 @@ constexpr int TN_LDB = 34;  // LDS leading dimension (doubles): 16-byte aligned 
 // Preconditions (guaranteed by the block layout, hfmi.h): lda, ldb multiples of 32 doubles, rows N..ld-1 of
 // every vector are zero, so the reduction runs over whole 32-row stages with NO masks or branches in the loop:
 // every load below is unconditional (clamped addresses), which is what lets the prefetches stay in flight.
-template <int MT, int NT, bool TR>
-__global__ __launch_bounds__(256, 1) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
-                                                      const double* __restrict__ B, int64_t ldb, int k,
-                                                      int64_t Npad, int64_t chunk, int nrb, int nsplit,
-                                                      double* __restrict__ part, int mpad, int kpad) {
+//
+// WAVES = 4: one wave per SIMD with up to 32 accumulator tiles (256 AGPRs).  WAVES = 8: two waves per SIMD with
+// up to 16 tiles each -- same workgroup tile, but while one wave of a SIMD sits in a barrier / LDS / HBM wait the
+// other keeps the matrix pipe busy.
+template <int MT, int NT, bool TR, int WAVES, int RING>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
+                                                                    const double* __restrict__ B, int64_t ldb, int k,
+                                                                    int64_t Npad, int64_t chunk, int nrb, int nsplit,
+                                                                    double* __restrict__ part, int mpad, int kpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][TN_LDB]
   constexpr int COLS = NT * 16;
+  constexpr int NTHR = WAVES * 64;
+  constexpr int CH = COLS * 16;                   // 16-byte chunks per stage
+  constexpr int NQ = (CH + NTHR - 1) / NTHR;      // chunks per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kk = lane >> 4;
 
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_tn(const double* __restrict__
   if (t_end > Npad) t_end = Npad;
   const int nstages = (int)((t_end - t_begin) / TN_BK);
   const int64_t t_last = t_end - 8;  // last iteration base that is safe to fetch
-  const int rowbase = rb * (64 * MT) + wave * (16 * MT);
+  const int rowbase = rb * (16 * MT * WAVES) + wave * (16 * MT);
 
   const double* a_ptr[MT];
 #pragma unroll
@@ -71,11 +78,11 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_tn(const double* __restrict__
     if (row > m - 1) row = m - 1;
     a_ptr[mt] = A + (int64_t)row * lda + kk * 2;
   }
-  // B stage: COLS * 16 chunks of 16 bytes, NT per thread
-  const double* b_ptr[NT];
+  const double* b_ptr[NQ];
 #pragma unroll
-  for (int qd = 0; qd < NT; ++qd) {
-    const int c = tid + 256 * qd;
+  for (int qd = 0; qd < NQ; ++qd) {
+    int c = tid + NTHR * qd;
+    if (c > CH - 1) c = CH - 1;
     int col = c >> 4;
     if (col > k - 1) col = k - 1;
     b_ptr[qd] = B + (int64_t)col * ldb + (c & 15) * 2;
@@ -87,20 +94,20 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_tn(const double* __restrict__
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
 
-  d2 breg[NT];
+  d2 breg[NQ];
   auto stage_load = [&](int64_t ts) {
 #pragma unroll
-    for (int qd = 0; qd < NT; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + ts);
+    for (int qd = 0; qd < NQ; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + ts);
   };
   auto stage_store = [&](double* L) {
 #pragma unroll
-    for (int qd = 0; qd < NT; ++qd) {
-      const int c = tid + 256 * qd;
-      *reinterpret_cast<d2*>(L + (c >> 4) * TN_LDB + (c & 15) * 2) = breg[qd];
+    for (int qd = 0; qd < NQ; ++qd) {
+      const int c = tid + NTHR * qd;
+      if (CH % NTHR == 0 || c < CH) *reinterpret_cast<d2*>(L + (c >> 4) * TN_LDB + (c & 15) * 2) = breg[qd];
     }
   };
   auto load_a = [&](d2(&dst)[MT], int64_t t) {
-    if (t > t_last) t = t_last;  // wave-uniform clamp: the prefetch past the end re-reads valid data
+    if (t > t_last) t = t_last;  // wave-uniform clamp: prefetches past the end re-read valid data
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const d2*>(a_ptr[mt] + t);
   };
@@ -132,27 +139,57 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_tn(const double* __restrict__
     stage_store(lds);
     __syncthreads();
   }
-  d2 a0[MT], a1[MT], bf0[NT], bf1[NT];
-  load_a(a0, t_begin);
-  for (int s = 0; s < nstages; ++s) {
-    const int64_t ts = t_begin + (int64_t)s * TN_BK;
-    const bool has_next = s + 1 < nstages;
-    if (has_next) stage_load(ts + TN_BK);
-    const double* L = lds + (s & 1) * COLS * TN_LDB;
-    ldsb(bf0, L, 0);
-    load_a(a1, ts + 8);
-    ldsb(bf1, L, 1);
-    mma(a0, bf0);
-    load_a(a0, ts + 16);
-    ldsb(bf0, L, 2);
-    mma(a1, bf1);
-    load_a(a1, ts + 24);
-    ldsb(bf1, L, 3);
-    mma(a0, bf0);
-    load_a(a0, ts + 32);
-    mma(a1, bf1);
-    if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * TN_LDB);
-    __syncthreads();
+  // streamed operand: register ring over iterations of 8 reduction indices; RING = 2: prefetch distance 1,
+  // RING = 4: prefetch distance 3
+  d2 bf0[NT], bf1[NT];
+  if constexpr (RING == 2) {
+    d2 a0[MT], a1[MT];
+    load_a(a0, t_begin);
+    for (int s = 0; s < nstages; ++s) {
+      const int64_t ts = t_begin + (int64_t)s * TN_BK;
+      const bool has_next = s + 1 < nstages;
+      if (has_next) stage_load(ts + TN_BK);
+      const double* L = lds + (s & 1) * COLS * TN_LDB;
+      ldsb(bf0, L, 0);
+      load_a(a1, ts + 8);
+      ldsb(bf1, L, 1);
+      mma(a0, bf0);
+      load_a(a0, ts + 16);
+      ldsb(bf0, L, 2);
+      mma(a1, bf1);
+      load_a(a1, ts + 24);
+      ldsb(bf1, L, 3);
+      mma(a0, bf0);
+      load_a(a0, ts + 32);
+      mma(a1, bf1);
+      if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * TN_LDB);
+      __syncthreads();
+    }
+  } else {
+    d2 a0[MT], a1[MT], a2[MT], a3[MT];
+    load_a(a0, t_begin);
+    load_a(a1, t_begin + 8);
+    load_a(a2, t_begin + 16);
+    for (int s = 0; s < nstages; ++s) {
+      const int64_t ts = t_begin + (int64_t)s * TN_BK;
+      const bool has_next = s + 1 < nstages;
+      if (has_next) stage_load(ts + TN_BK);
+      const double* L = lds + (s & 1) * COLS * TN_LDB;
+      ldsb(bf0, L, 0);
+      load_a(a3, ts + 24);
+      ldsb(bf1, L, 1);
+      mma(a0, bf0);
+      load_a(a0, ts + 32);
+      ldsb(bf0, L, 2);
+      mma(a1, bf1);
+      load_a(a1, ts + 40);
+      ldsb(bf1, L, 3);
+      mma(a2, bf0);
+      load_a(a2, ts + 48);
+      mma(a3, bf1);
+      if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * TN_LDB);
+      __syncthreads();
+    }
   }
 
   double* P = part + (int64_t)sp * mpad * kpad;
@@ -191,45 +228,82 @@ __global__ void k_reduce_partials(const double* __restrict__ part, int nsplit, i
   }
 }
 
-static inline int tn_mt_max(int nt) {
-  static const int t[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
-  return t[nt];
+#include <stdlib.h>
+#include <string.h>
+// Tuning knobs of the MFMA kernels (A/B measurements: environment HFMI_GEMM_WAVES / HFMI_GEMM_RING, or
+// hfmi_tuning_set at run time).
+//   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
+//   ring : register prefetch ring of the streamed operand in tsgemm_tn (2 = distance 1, 4 = distance 3)
+static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 8 column tiles, else 8)
+static void tuning_init() {
+  if (g_waves) return;
+  const char* e = getenv("HFMI_GEMM_WAVES");
+  g_waves = (e && atoi(e) == 4) ? 4 : 8;   // measured: 8 waves + ring 2 is best or equal on every shape (scripts/gemm_ab.py)
+  e = getenv("HFMI_GEMM_RING");
+  g_ring = (e && atoi(e) == 4) ? 4 : 2;
+}
+static int gemm_waves() {
+  tuning_init();
+  return g_waves;
+}
+static int gemm_ring() {
+  tuning_init();
+  return g_ring;
+}
+extern "C" int hfmi_tuning_set(const char* key, int value) {
+  tuning_init();
+  if (key && !strcmp(key, "waves") && (value == 4 || value == 8)) g_waves = value;
+  else if (key && !strcmp(key, "ring") && (value == 2 || value == 4)) g_ring = value;
+  else if (key && !strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
+  else HFMI_FAIL(HFMI_ERR_INVALID, "tuning_set: unknown key/value");
+  return HFMI_OK;
+}
+// tallest wave tile (in 16-row MFMA tiles) for a panel of nt column tiles
+static inline int tn_mt_max(int nt, int waves) {
+  static const int t4[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
+  static const int t8[17] = {0, 5, 5, 5, 4, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+  return waves == 4 ? t4[nt] : t8[nt];
 }
 
-template <int MT, int NT>
-static int tn_launch_inst(hfmi_ctx* ctx, bool tr, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
-                          int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
+template <int MT, int NT, int WAVES, bool TR, int RING>
+static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t N,
+                         int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
   const size_t shmem = (size_t)2 * NT * 16 * TN_LDB * sizeof(double);
-  dim3 grid(nrb * nsplit), block(256);
-  if (tr) {
-    auto kern = k_tsgemm_tn<MT, NT, true>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad,
-                       kpad);
-  } else {
-    auto kern = k_tsgemm_tn<MT, NT, false>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad,
-                       kpad);
-  }
+  auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, RING>;
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,
+                     nsplit, part, mpad, kpad);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
 
-template <int NT>
+template <int MT, int NT, int WAVES>
+static int tn_launch_inst(hfmi_ctx* ctx, bool tr, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
+                          int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
+  const bool ring4 = gemm_ring() == 4;
+  if (tr) {
+    if (ring4) return tn_launch_one<MT, NT, WAVES, true, 4>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+    return tn_launch_one<MT, NT, WAVES, true, 2>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+  }
+  if (ring4) return tn_launch_one<MT, NT, WAVES, false, 4>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+  return tn_launch_one<MT, NT, WAVES, false, 2>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+}
+
+template <int NT, int WAVES>
 static int tn_dispatch_mt(hfmi_ctx* ctx, int mt, bool tr, const double* A, int64_t lda, int m, const double* B,
                           int64_t ldb, int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad,
                           int kpad) {
-#define TN_CASE(M)                                                                                              \
-  case M:                                                                                                       \
-    if constexpr (M * NT <= 32)                                                                                 \
-      return tn_launch_inst<M, NT>(ctx, tr, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);     \
+  constexpr int LIM = (WAVES == 8) ? 16 : 32;
+#define TN_CASE(M)                                                                                                 \
+  case M:                                                                                                          \
+    if constexpr (M * NT <= LIM)                                                                                   \
+      return tn_launch_inst<M, NT, WAVES>(ctx, tr, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad); \
     break;
   switch (mt) {
-    TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7) TN_CASE(8)
+    TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(8)
   }
 #undef TN_CASE
-  HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: no instance for MT=%d NT=%d", mt, NT);
+  HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: no instance for MT=%d NT=%d WAVES=%d", mt, NT, WAVES);
 }
 
 // one panel of at most 256 columns of B
@@ -242,12 +316,14 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
     HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: leading dimensions must be multiples of 32 and >= round_up(N,32)");
   const bool tr = (rs == 1 && cs != 1);  // column-major output: coalesce along i
   // wave tile height: as tall as the accumulator budget allows, but no taller than the problem needs
+  const int waves = (nt > 11) ? 4 : gemm_waves();   // very wide panels: the 2-waves/SIMD register budget is too tight
   const int row_tiles = (m + 15) / 16;
-  int mt = tn_mt_max(nt);
-  const int need = (row_tiles + 3) / 4;
+  int mt = tn_mt_max(nt, waves);
+  const int need = (row_tiles + waves - 1) / waves;
   if (need < mt) mt = need;
+  if (mt == 7) mt = 6;
   if (mt < 1) mt = 1;
-  const int rows_per_block = 64 * mt;
+  const int rows_per_block = 16 * waves * mt;
   const int nrb = (m + rows_per_block - 1) / rows_per_block;
   const int mpad = nrb * rows_per_block;
   // split the long axis so that the grid fills the chip in (nearly) whole rounds of CUs
@@ -280,9 +356,12 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   double* part = (double*)partv;
   // algorithmic work of this launch: flops 2 N m k, bytes 8 (N m + N k + m k)
   const int pidx = prof_start(ctx, 0, m, k, N);
-#define TN_NT(NTV)                                                                                             \
-  case NTV:                                                                                                    \
-    HFMI_TRY(tn_dispatch_mt<NTV>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad)); \
+#define TN_NT(NTV)                                                                                                       \
+  case NTV:                                                                                                              \
+    if (waves == 8)                                                                                                      \
+      HFMI_TRY((tn_dispatch_mt<NTV, 8>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
+    else                                                                                                                 \
+      HFMI_TRY((tn_dispatch_mt<NTV, 4>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
     break;
   switch (nt) {
     TN_NT(1) TN_NT(2) TN_NT(3) TN_NT(4) TN_NT(5) TN_NT(6) TN_NT(7) TN_NT(8) TN_NT(9) TN_NT(10) TN_NT(11) TN_NT(12)
@@ -322,11 +401,11 @@ constexpr int NN_KC = 32;  // reduction indices per LDS stage (8 MFMA k-steps)
 // The reduction axis m may be split over gridDim-many workgroups (msplit > 1): each split writes a raw partial
 // block and k_reduce_nn adds them in a fixed order -- this is what balances the grid over the 256 CUs when
 // there are only a few row tiles (quantisation), at the price of msplit * N * r * 16 bytes of extra traffic.
-template <int TT, int NT>
-__global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
-                                                      const double* __restrict__ S, int lds_, int r,
-                                                      double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles,
-                                                      int msplit, int mchunk, int64_t pstride) {
+template <int TT, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
+                                                                    const double* __restrict__ S, int lds_, int r,
+                                                                    double* __restrict__ Y, int64_t ldy, int64_t N,
+                                                                    int ntiles, int msplit, int mchunk, int64_t pstride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2][NN_KC][SLD]
   constexpr int COLS = NT * 16;
@@ -334,11 +413,14 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
   constexpr int TP = TT / 2;                            // tile pairs fed by one 16-byte load per lane
   constexpr bool ODD = (TT & 1) != 0;                   // plus one single tile fed by an 8-byte load
   constexpr int TPA = TP > 0 ? TP : 1;
+  constexpr int NTHR = WAVES * 64;
+  constexpr int CH = NN_KC * COLS / 2;            // 16-byte pairs per stage
+  constexpr int NQ = (CH + NTHR - 1) / NTHR;      // pairs per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, kk = lane >> 4;
   const int logical = xcd_remap(blockIdx.x, ntiles * msplit);
   const int split = logical / ntiles, tile = logical % ntiles;
-  const int64_t t0 = (int64_t)tile * (64 * TT) + wave * (16 * TT);
+  const int64_t t0 = (int64_t)tile * (16 * TT * WAVES) + wave * (16 * TT);
   const int i_begin = split * mchunk;
   int i_end = i_begin + mchunk;
   if (i_end > m) i_end = m;
@@ -355,11 +437,12 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
   }
   int64_t toff1 = t0 + TP * 32 + c16;
   if (toff1 > tmax + 1) toff1 = tmax + 1;
-  // S stage: NN_KC rows x COLS cols as 16-byte pairs, NT per thread
-  int s_row[NT], s_cp[NT];
+  // S stage: NN_KC rows x COLS cols as 16-byte pairs, NQ per thread
+  int s_row[NQ], s_cp[NQ];
 #pragma unroll
-  for (int qd = 0; qd < NT; ++qd) {
-    const int c = tid + 256 * qd;
+  for (int qd = 0; qd < NQ; ++qd) {
+    int c = tid + NTHR * qd;
+    if (c > CH - 1) c = CH - 1;
     s_row[qd] = c / (COLS / 2);
     s_cp[qd] = c % (COLS / 2);
   }
@@ -374,10 +457,10 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
     d2 p[TPA];
     double s;
   };
-  d2 sreg[NT];
+  d2 sreg[NQ];
   auto stage_load = [&](int is) {
 #pragma unroll
-    for (int qd = 0; qd < NT; ++qd) {
+    for (int qd = 0; qd < NQ; ++qd) {
       int row = is + s_row[qd];
       if (row > m - 1) row = m - 1;
       sreg[qd] = *reinterpret_cast<const d2*>(S + (int64_t)row * lds_ + s_cp[qd] * 2);
@@ -385,10 +468,10 @@ __global__ __launch_bounds__(256, 1) void k_tsgemm_nn(const double* __restrict__
   };
   auto stage_store = [&](double* L, int is) {
 #pragma unroll
-    for (int qd = 0; qd < NT; ++qd) {
+    for (int qd = 0; qd < NQ; ++qd) {
       d2 v = sreg[qd];
       if (is + s_row[qd] >= i_end) v = d2{0.0, 0.0};  // rows past this split's range contribute nothing
-      *reinterpret_cast<d2*>(L + s_row[qd] * SLD + s_cp[qd] * 2) = v;
+      if (CH % NTHR == 0 || tid + NTHR * qd < CH) *reinterpret_cast<d2*>(L + s_row[qd] * SLD + s_cp[qd] * 2) = v;
     }
   };
   auto load_a = [&](AFrag& dst, int i0) {
@@ -510,19 +593,22 @@ __global__ void k_reduce_nn(const double* __restrict__ part, int msplit, int64_t
   }
 }
 
-static inline int nn_tt(int nt) {
-  static const int t[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
-  return t[nt];
+// tallest wave tile (in 16-row tiles along the long axis) for nt column tiles
+static inline int nn_tt(int nt, int waves) {
+  static const int t4[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
+  static const int t8[17] = {0, 8, 8, 5, 4, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+  return waves == 4 ? t4[nt] : t8[nt];
 }
 
-template <int TT, int NT>
+template <int TT, int NT, int WAVES>
 static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r,
                           double* Y, int64_t ldy, int64_t N) {
   constexpr int SLD = NT * 16 + ((NT % 2 == 0) ? 16 : 0);
   const size_t shmem = (size_t)2 * NN_KC * SLD * sizeof(double);
-  auto kern = k_tsgemm_nn<TT, NT>;
+  auto kern = k_tsgemm_nn<TT, NT, WAVES>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  const int ntiles = (int)((N + 64 * TT - 1) / (64 * TT));
+  const int tile_rows = 16 * TT * WAVES;
+  const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
   // split the reduction axis so that the grid fills the chip in (nearly) whole rounds of CUs
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   const int stages = (m + NN_KC - 1) / NN_KC;
@@ -552,7 +638,7 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
     HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)msplit * pstride * sizeof(double), &pv));
     out = (double*)pv;
   }
-  dim3 grid((unsigned)(ntiles * msplit)), block(256);
+  dim3 grid((unsigned)(ntiles * msplit)), block(WAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, ntiles, msplit, mchunk, pstride);
   HIP_TRY(hipGetLastError());
   if (msplit > 1) {
@@ -568,13 +654,16 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
 static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
                     int64_t ldy, int64_t N) {
   const int nt = (r + 15) / 16;
-#define NN_CASE(NTV, TTV) \
-  case NTV:               \
-    return nn_launch_inst<TTV, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
+  tuning_init();
+  const int waves = g_nn_waves ? g_nn_waves : (nt >= 9 ? 8 : 4);
+#define NN_CASE(NTV, TT4, TT8)                                                                   \
+  case NTV:                                                                                      \
+    if (waves == 8) return nn_launch_inst<TT8, NTV, 8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);   \
+    return nn_launch_inst<TT4, NTV, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
   switch (nt) {
-    NN_CASE(1, 8) NN_CASE(2, 8) NN_CASE(3, 8) NN_CASE(4, 8) NN_CASE(5, 6) NN_CASE(6, 5) NN_CASE(7, 4) NN_CASE(8, 4)
-    NN_CASE(9, 3) NN_CASE(10, 3) NN_CASE(11, 2) NN_CASE(12, 2) NN_CASE(13, 2) NN_CASE(14, 2) NN_CASE(15, 2)
-    NN_CASE(16, 2)
+    NN_CASE(1, 8, 8) NN_CASE(2, 8, 8) NN_CASE(3, 8, 5) NN_CASE(4, 8, 4) NN_CASE(5, 6, 3) NN_CASE(6, 5, 2)
+    NN_CASE(7, 4, 2) NN_CASE(8, 4, 2) NN_CASE(9, 3, 1) NN_CASE(10, 3, 1) NN_CASE(11, 2, 1) NN_CASE(12, 2, 1)
+    NN_CASE(13, 2, 1) NN_CASE(14, 2, 1) NN_CASE(15, 2, 1) NN_CASE(16, 2, 1)
   }
 #undef NN_CASE
   HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_nn: panel too wide (%d)", r);

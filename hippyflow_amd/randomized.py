@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from .collectives import CollectiveOperator, MatrixMultCollectiveOperator
+from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
 from .multivector import MatMvMult, MultiVector, MvDSmatMult, Vector
 from .operators import DeviceOperator, Solver2Operator, as_device_operator
 
@@ -110,7 +110,7 @@ def _fused(A_dev, collective, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs,
         else:
             L.call("hfmi_double_pass_g", A_dev._op, B_dev._op, Binv_dev._op, Omega.handle, int(k), int(s), flags, L.ptr(d), U.handle)
 
-    if collective is not None and collective.size() > 1:
+    if collective is not None and not isinstance(collective, NullCollective):
         hook = _PostApplyHook(A_dev, collective, mpi_op)
         with hook:
             try:

@@ -190,6 +190,8 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * the context's stream.  end() synchronises and returns one record per distinct (kernel, shape):
  * kind[g] 0 = k_tsgemm_tn, 1 = k_tsgemm_nn; shape[3*g..] = (short-side rows m, columns k, long axis N);
  * total milliseconds, launches, and the ALGORITHMIC flops / bytes of one launch. */
+/* kernel tuning knobs for A/B measurements: ("waves", 4|8), ("ring", 2|4); see csrc/hfmi_gemm.hip */
+int hfmi_tuning_set(const char* key, int value);
 int hfmi_profile_begin(hfmi_ctx* ctx);
 int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int* kind, int64_t* shape, double* ms,
                      int64_t* launches, double* flops_per_launch, double* bytes_per_launch);
