@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -363,6 +364,10 @@ static int read_status(hfmi_ctx* ctx, hfmi_status_words* out) {
   HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   *out = *ctx->status_host;
+  static const bool dbg = getenv("HFMI_DEBUG_TIMING") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[hfmi timing] %s cycles: %lld %lld %lld %lld\n", out->tick[4] ? "jacobi(total,phase1,phase2,sweeps)" : "chol(load,chol,inv,out)",
+            out->tick[0], out->tick[1], out->tick[2], out->tick[3]);
   return HFMI_OK;
 }
 
@@ -778,7 +783,7 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     }
     HFMI_TRY(launch_tsgemm_tn(ctx, Q->p, Q->ld, k, right->p, right->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_GRAM), SM_LD, 1, 0));
     const int rtot_mode = (passes == 0) ? 1 : 2;   // always track R = R_p ... R_1: its diagonal exposes dependent columns
-    HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, shift_rel, pivot_tol));
+    HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol));
     hfmi_status_words st;
     HFMI_TRY(read_status(ctx, &st));
     if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
@@ -793,13 +798,12 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
   // (numerically dependent); Cholesky-QR would instead normalise round-off noise.  R_jj / ||z_j|| is that
   // drop: hand such blocks to the Gram-Schmidt route, which reproduces the reference's behaviour.
   {
-    std::vector<double> rt((size_t)k * SM_LD), cn(k);
-    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_RTOT), (size_t)k * SM_LD, rt.data()));
-    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_AUX), (size_t)k, cn.data()));
+    std::vector<double> aux((size_t)SM_LD + k);       // [0, k): original column norms; [SM_LD, SM_LD + k): diag(R)
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_AUX), (size_t)SM_LD + k, aux.data()));
     for (int j = 0; j < k; ++j)
-      if (!(rt[(size_t)j * SM_LD + j] > 100.0 * 2.220446049250313e-16 * cn[j]))
+      if (!(aux[SM_LD + j] > 100.0 * 2.220446049250313e-16 * aux[j]))
         HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: vector %d is numerically dependent on its predecessors (R_jj/||z_j|| = %.2e)", j,
-                  cn[j] > 0 ? rt[(size_t)j * SM_LD + j] / cn[j] : 0.0);
+                  aux[j] > 0 ? aux[SM_LD + j] / aux[j] : 0.0);
   }
   (void)want_r;
   if (B && BQ) HFMI_TRY(hfmi_op_apply(B, Q, BQ, 0));

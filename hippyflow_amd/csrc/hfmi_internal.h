@@ -56,6 +56,7 @@ struct hfmi_status_words {  // device-resident, read back by the host after smal
   int failed;               // breakdown even after shifting / not converged
   int sweeps;               // Jacobi sweeps used
   int pad;
+  long long tick[8];        // shader-clock section timings of the last small kernel (HFMI_DEBUG_TIMING=1 prints them)
 };
 
 struct hfmi_ctx {
@@ -160,7 +161,7 @@ int launch_gamma_apply(hfmi_ctx* ctx, double* G, int ldg, int ndata, int q, int 
 // G (k x k, SM slot) = R^T R; writes R (upper), Rinv (upper); if rtot_accumulate, Rtot <- R * Rtot.
 // Status words (min pivot ratio, defect, shifted/failed) land in ctx->status_dev.
 int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
-                    double shift_rel, double pivot_tol);
+                    int full_r, double shift_rel, double pivot_tol);
 // T (k x k) -> eigenvalues (sorted descending) into dvals (device, k), eigenvectors into slot_v (columns).
 int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs);
 int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);

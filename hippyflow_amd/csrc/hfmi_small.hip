@@ -47,43 +47,81 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
 // ------------------------------------------------------------------------------------------------
 // Cholesky + triangular inverse.  M points at the working k x k matrix (LDS when it fits, else a global
 // scratch slot), row-major with leading dimension ldm.
+//
+// One workgroup; everything here is issue/latency bound on a single CU (fp64 VALU is quarter rate: a dependent
+// v_fma_f64 costs 32 cycles with 4 waves per SIMD; a software fp64 divide ~300), so the structure avoids
+// redundant scalar fp64 math (v_rsq_f64 + Newton instead of sqrt and divide on every thread), maps triangular
+// index sets onto ALL lanes (folded triangle, reciprocal-multiply index split) and computes the inverse with
+// no workgroup barriers at all.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);      // ~2^-26 relative
+  y = y * (1.5 - 0.5 * x * y * y);         // two Newton steps -> ~1 ulp
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+// cell e of the folded triangle {(row, col): 0 <= row <= col < n}: ceil(n/2) strips of n+1 cells, strip r holds
+// row r (n-r cells) followed by row n-1-r (r+1 cells).  Returns false for the duplicate half of the middle strip.
+__device__ __forceinline__ bool tri_cell(int e, int n, float inv_np1, int& row, int& col) {
+  int r = (int)((float)e * inv_np1);
+  int cc = e - r * (n + 1);
+  if (cc < 0) {
+    --r;
+    cc += n + 1;
+  } else if (cc > n) {
+    ++r;
+    cc -= n + 1;
+  }
+  if (cc < n - r) {
+    row = r;
+    col = r + cc;
+    return true;
+  }
+  const int r2 = n - 1 - r;
+  row = r2;
+  col = r2 + (cc - (n - r));
+  return r2 != r;
+}
+
 __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __restrict__ G, int ldg, int k,
                                                             double* __restrict__ Rout, double* __restrict__ Rinv,
                                                             double* __restrict__ Rtot, double* __restrict__ Rtmp,
-                                                            int ldo, int rtot_mode, double shift_rel,
+                                                            int ldo, int rtot_mode, int full_r, double shift_rel,
                                                             double pivot_tol, double* __restrict__ gscratch,
                                                             int use_lds, double* __restrict__ colnorm0,
+                                                            double* __restrict__ rdiag,
                                                             hfmi_status_words* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
   double* diag0 = red + 32;                            // k original diagonal entries
-  double* lds_m = diag0 + 256;
+  double* invd = diag0 + 256;                          // 1 / R_jj
+  double* lds_m = invd + 256;
   const int ldm = use_lds ? (k | 1) : ldo;
   double* M = use_lds ? lds_m : gscratch;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   __shared__ int s_break;
 
-  // 2-D thread map (no integer divisions in any hot loop): lanes run along a row, waves over rows
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-
+  long long tk0 = clock64(), tk1, tk2, tk3, tk4;
   // diag and orthonormality defect || D^-1/2 G D^-1/2 - I ||_F of the input
   for (int i = tid; i < k; i += nthr) {
     diag0[i] = G[i * ldg + i];
     if (rtot_mode == 1) colnorm0[i] = sqrt(fmax(diag0[i], 0.0));  // norms of the ORIGINAL columns (first pass)
   }
   __syncthreads();
+  for (int i = tid; i < k; i += nthr) invd[i] = diag0[i] > 0.0 ? fast_rsqrt(diag0[i]) : 0.0;
+  __syncthreads();
   double dev = 0.0, tr = 0.0;
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) {
       const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
-      const double dd = diag0[i] * diag0[j];
-      const double x = (dd > 0.0 ? g * rsqrt(dd) : 0.0) - (i == j ? 1.0 : 0.0);
+      const double x = g * invd[i] * invd[j] - (i == j ? 1.0 : 0.0);
       dev += x * x;
       if (i == j) tr += g;
     }
   dev = block_sum(dev, red);
   tr = block_sum(tr, red);
+  tk1 = clock64();
 
   int shifted = 0, failed = 0;
   double min_ratio = 1e300;
@@ -105,16 +143,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
         if (tid == 0) s_break = 1;
         break;
       }
-      ratio_local = fmin(ratio_local, piv / ref);
-      const double rjj = sqrt(piv);
-      const double inv = 1.0 / rjj;
+      if (tid == 0) ratio_local = fmin(ratio_local, piv / ref);
+      const double inv = fast_rsqrt(piv);
+      const double rjj = piv * inv;
       __syncthreads();
       for (int c = j + tid; c < k; c += nthr) M[j * ldm + c] = (c == j) ? rjj : M[j * ldm + c] * inv;
+      if (tid == 0) invd[j] = inv;
       __syncthreads();
-      // trailing update of the upper triangle: M[i][c] -= R[j][i] R[j][c], j < i <= c
-      for (int i = j + 1 + wave; i < k; i += nw) {
-        const double rji = M[j * ldm + i];
-        for (int c = i + lane; c < k; c += 64) M[i * ldm + c] -= rji * M[j * ldm + c];
+      // trailing update of the upper triangle: M[i][c] -= R[j][i] R[j][c], j < i <= c  (folded onto all lanes)
+      const int n = k - j - 1;
+      if (n > 0) {
+        const float inv_np1 = __frcp_rn((float)(n + 1));
+        const int cells = ((n + 1) >> 1) * (n + 1);
+        const double* rj = M + j * ldm + j + 1;
+        for (int e = tid; e < cells; e += nthr) {
+          int a, b;
+          if (tri_cell(e, n, inv_np1, a, b)) M[(j + 1 + a) * ldm + j + 1 + b] -= rj[a] * rj[b];
+        }
       }
       __syncthreads();
     }
@@ -136,66 +181,84 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
     }
     return;
   }
+  tk2 = clock64();
   // R out (upper triangle, zeros below)
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
-  __syncthreads();
-  // in-place inverse of the upper triangle (dtrti2 ordering): after step j the leading (j+1) block of M holds
-  // the inverse.  x_i = -(sum_{l=i}^{j-1} X[i][l] R[l][j]) / R[j][j] for i < j: one wave per row, lanes split
-  // the dot product; results are parked in diag0 until every wave has finished reading column j.
+  // Inverse X = R^-1 by back substitution, one column per 16-lane group, NO workgroup barriers: column c is
+  // x_c = 1/R_cc, x_i = -(sum_{l=i+1..c} R[i][l] x_l) / R_ii for i < c.  x is written into the (unused)
+  // strictly lower triangle, X[i][c] -> M[c][i], so columns never collide with R or with each other.
   {
-    for (int j = 0; j < k; ++j) {
-      const double xjj = 1.0 / M[j * ldm + j];
-      for (int i = wave; i < j; i += nw) {
-        double s = 0.0;
-        for (int l = i + lane; l < j; l += 64) s += M[i * ldm + l] * M[l * ldm + j];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) diag0[i] = -s * xjj;
+    const int grp = lane >> 4, gl = lane & 15;
+    for (int c0 = 4 * wave; c0 < k; c0 += 4 * nw) {
+      const int c = c0 + grp;
+      const bool live = c < k;
+      const double xc = live ? invd[c] : 0.0;
+      const int cmax = (c0 + 3 < k) ? c0 + 3 : k - 1;
+      for (int i = cmax - 1; i >= 0; --i) {
+        double sacc = 0.0;
+        if (live && i < c) {
+          const double* ri = M + i * ldm;
+          const double* xr = M + c * ldm;
+          for (int l = i + 1 + gl; l <= c; l += 16) sacc += ri[l] * (l == c ? xc : xr[l]);
+        }
+        sacc += __shfl_xor(sacc, 8, 64);
+        sacc += __shfl_xor(sacc, 4, 64);
+        sacc += __shfl_xor(sacc, 2, 64);
+        sacc += __shfl_xor(sacc, 1, 64);
+        if (live && i < c && gl == 0) M[c * ldm + i] = -sacc * invd[i];
       }
-      __syncthreads();
-      for (int i = tid; i < j; i += nthr) M[i * ldm + j] = diag0[i];
-      if (tid == 0) M[j * ldm + j] = xjj;
-      __syncthreads();
     }
   }
+  __syncthreads();
+  tk3 = clock64();
   for (int i = wave; i < k; i += nw)
-    for (int j = lane; j < k; j += 64) Rinv[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
-  // running product of the R factors across Cholesky-QR passes: Rtot <- R * Rtot
-  if (rtot_mode == 1) {
-    for (int i = wave; i < k; i += nw)
-      for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rout[i * ldo + j];
-  } else if (rtot_mode == 2) {
-    __syncthreads();
-    for (int i = wave; i < k; i += nw)
-      for (int j = lane; j < k; j += 64) {
-        double acc = 0.0;
-        if (j >= i)
-          for (int l = i; l <= j; ++l) acc += Rout[i * ldo + l] * Rtot[l * ldo + j];
-        Rtmp[i * ldo + j] = acc;
-      }
-    __syncthreads();
-    for (int i = wave; i < k; i += nw)
-      for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rtmp[i * ldo + j];
+    for (int j = lane; j < k; j += 64) Rinv[i * ldo + j] = (j > i) ? M[j * ldm + i] : (j == i ? invd[i] : 0.0);
+  // diagonal of the running product R = R_p ... R_1 (its ratio to the original column norms exposes
+  // numerically dependent columns); the full product only when the caller wants R
+  for (int i = tid; i < k; i += nthr) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * M[i * ldm + i];
+  if (full_r) {
+    if (rtot_mode == 1) {
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+    } else {
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) {
+          double acc = 0.0;
+          if (j >= i)
+            for (int l = i; l <= j; ++l) acc += M[i * ldm + l] * Rtot[l * ldo + j];
+          Rtmp[i * ldo + j] = acc;
+        }
+      __syncthreads();
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rtmp[i * ldo + j];
+    }
   }
+  tk4 = clock64();
   if (tid == 0) {
     status->min_pivot_ratio = min_ratio;
     status->gram_dev = sqrt(dev);
     status->shifted = shifted;
     status->failed = 0;
+    status->tick[0] = tk1 - tk0;  // load + defect
+    status->tick[1] = tk2 - tk1;  // Cholesky
+    status->tick[2] = tk3 - tk2;  // inverse
+    status->tick[3] = tk4 - tk3;  // outputs + R product
+    status->tick[4] = 0;
   }
 }
 
 int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
-                    double shift_rel, double pivot_tol) {
+                    int full_r, double shift_rel, double pivot_tol) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "chol_inv: k=%d out of range", k);
-  const int use_lds = (k <= 140) ? 1 : 0;
-  const size_t shmem = (32 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
+  const int use_lds = (k <= 139) ? 1 : 0;   // (32 + 256 + 256) * 8 + 139 * 139 * 8 = 158,920 bytes <= 160 KB
+  const size_t shmem = (32 + 256 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
   hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
                      sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
-                     rtot_mode, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX), ctx->status_dev);
+                     rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX),
+                     sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
@@ -249,6 +312,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int n = (k + 1) & ~1;  // players (one dummy if k is odd)
   const int np = n / 2;
+  const float inv_np1 = __frcp_rn((float)(np + 1));
+  const int cells = ((np + 1) >> 1) * (np + 1);
 
   double fro = 0.0;
   for (int i = wave; i < k; i += nw)
@@ -261,6 +326,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   __syncthreads();
   const double tol2 = EPS_D * EPS_D * fro;
 
+  long long tj0 = clock64(), tp1 = 0, tp2 = 0;
   int sweeps = 0;
   double off2 = 0.0;
   for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
@@ -273,6 +339,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
     for (int r = 0; r < n - 1; ++r) {
       // phase 1: the round's pairs (kept in LDS: no modulo arithmetic in the update phase) and one
       // rotation per pair
+      const long long ta = clock64();
       if (tid < np) {
         int a, b;
         rr_pair(n, r, tid, a, b);
@@ -294,45 +361,56 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
         rotlog[((size_t)sweeps * (n - 1) + r) * np + tid] = make_double2(c, s);
       }
       __syncthreads();
-      // phase 2: every 2x2 block {P, Q}, P <= Q, <- J_P^T * block * J_Q.  Only the upper triangle of the
-      // symmetric matrix is stored/updated (element (i, j) lives at A[min][max]): half the LDS traffic.
-      // Waves over P, lanes over Q >= P.
-      for (int P = wave; P < np; P += nw) {
-        const int p1 = pa[P], q1 = pb[P];          // p1 < q1
-        const double2 rp = rot[P];
-        const bool r2 = q1 < k;
-        for (int Q = P + lane; Q < np; Q += 64) {
-          const int p2 = pa[Q], q2 = pb[Q];        // p2 < q2
-          // a dummy player (k odd) has index >= k: its entries read as 0 and are never written; the rotation
-          // of its pair is the identity, so the real member still receives the other pairs' rotations
-          const bool c2 = q2 < k;
-          const double2 rq = rot[Q];
-#define UT(i, j) A[((i) < (j) ? (i) : (j)) * lda + ((i) < (j) ? (j) : (i))]
-          const double x11 = UT(p1, p2);
-          const double x12 = c2 ? UT(p1, q2) : 0.0;
-          const double x21 = r2 ? ((P == Q) ? x12 : UT(q1, p2)) : 0.0;
-          const double x22 = (r2 && c2) ? UT(q1, q2) : 0.0;
-          // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
-          const double y11 = rq.x * x11 - rq.y * x12, y12 = rq.y * x11 + rq.x * x12;
-          const double y21 = rq.x * x21 - rq.y * x22, y22 = rq.y * x21 + rq.x * x22;
-          // rows with J_P
-          const double z11 = rp.x * y11 - rp.y * y21, z21 = rp.y * y11 + rp.x * y21;
-          const double z12 = rp.x * y12 - rp.y * y22, z22 = rp.y * y12 + rp.x * y22;
-          UT(p1, p2) = z11;
-          if (P == Q) {
-            if (r2) {
-              UT(p1, q1) = 0.0;                    // the annihilated pivot
-              UT(q1, q1) = z22;
-            }
-          } else {
-            if (c2) UT(p1, q2) = z12;
-            if (r2) UT(q1, p2) = z21;
-            if (r2 && c2) UT(q1, q2) = z22;
+      const long long tb = clock64();
+      tp1 += tb - ta;
+      // phase 2: every 2x2 block {P, Q}, P <= Q, <- J_P^T * block * J_Q, mirrored into the lower triangle (full
+      // symmetric storage: no min/max index logic).  The np (np + 1) / 2 blocks are laid onto ALL lanes through the
+      // folded-triangle map -- this phase is fp64-VALU-issue bound, so idle lanes are the main cost.
+      for (int e = tid; e < cells; e += nthr) {
+        int P, Q;
+        if (!tri_cell(e, np, inv_np1, P, Q)) continue;
+        const int p1 = pa[P], q1 = pb[P], p2 = pa[Q], q2 = pb[Q];
+        const int p1r = __mul24(p1, lda), q1r = __mul24(q1, lda), p2r = __mul24(p2, lda), q2r = __mul24(q2, lda);
+        // a dummy player (k odd) has index >= k: its entries read as 0 and are never written; the rotation of
+        // its pair is the identity, so the real member still receives the other pairs' rotations
+        const bool r2 = q1 < k, c2 = q2 < k;
+        const double2 rp = rot[P], rq = rot[Q];
+        const double x11 = A[p1r + p2];
+        const double x12 = c2 ? A[p1r + q2] : 0.0;
+        const double x21 = r2 ? A[q1r + p2] : 0.0;
+        const double x22 = (r2 && c2) ? A[q1r + q2] : 0.0;
+        // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
+        const double y11 = rq.x * x11 - rq.y * x12, y12 = rq.y * x11 + rq.x * x12;
+        const double y21 = rq.x * x21 - rq.y * x22, y22 = rq.y * x21 + rq.x * x22;
+        // rows with J_P
+        const double z11 = rp.x * y11 - rp.y * y21, z21 = rp.y * y11 + rp.x * y21;
+        const double z12 = rp.x * y12 - rp.y * y22, z22 = rp.y * y12 + rp.x * y22;
+        if (P == Q) {
+          A[p1r + p1] = z11;
+          if (r2) {
+            A[q1r + q1] = z22;
+            A[p1r + q1] = 0.0;        // the annihilated pivot
+            A[q1r + p1] = 0.0;
           }
-#undef UT
+        } else {
+          A[p1r + p2] = z11;
+          A[p2r + p1] = z11;
+          if (c2) {
+            A[p1r + q2] = z12;
+            A[q2r + p1] = z12;
+          }
+          if (r2) {
+            A[q1r + p2] = z21;
+            A[p2r + q1] = z21;
+          }
+          if (r2 && c2) {
+            A[q1r + q2] = z22;
+            A[q2r + q1] = z22;
+          }
         }
       }
       __syncthreads();
+      tp2 += clock64() - tb;
     }
   }
   // eigenvalues, sort descending (rank by counting; ties broken by index -> a permutation)
@@ -352,6 +430,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
     status->offdiag = fro > 0.0 ? sqrt(off2 / fro) : 0.0;
     status->sweeps = sweeps;
     status->failed = (sweeps >= JAC_MAX_SWEEPS && off2 > tol2) ? 1 : 0;
+    status->tick[0] = clock64() - tj0;
+    status->tick[1] = tp1;
+    status->tick[2] = tp2;
+    status->tick[3] = sweeps;
+    status->tick[4] = 1;
   }
 }
 

@@ -423,6 +423,7 @@ def test_large_pod_properties(ctx):
 
 
 # ------------------------------------------------------------------ RCCL plumbing on one GPU (world size 1)
+@pytest.mark.timeout(1200)      # the first `import torch` on a fresh box can take minutes while the image pages in
 def test_torch_collective_on_device_blocks(ctx):
     """The multi-GPU route end to end with a 1-rank nccl group: zero-copy tensor view of a block, in-place
     all-reduce / bcast in HBM, and the fused solve's post-apply hook (the driver runs the real 2/4/8-GPU case)."""
