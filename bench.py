@@ -235,6 +235,19 @@ def main():
                                 "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
                                 "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                                 "fp64_mfma_frac": tflops / FP64_MFMA_PEAK_TFLOPS})
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
+        # correction + WRITE_SIZE; profiles/pmc_traffic.json) -- bench.py cannot run the profiler on itself
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            rec = tr["kernels"].get(out["roofline"]["kernel"])
+            if rec:
+                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / pk["bytes_per_launch"]
+                out["roofline"]["pmc_mfma_pipe_util"] = rec.get("mfma_pipe_util")
+                out["roofline"]["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
+        except (OSError, ValueError, KeyError):
+            pass
         mfma_ms = sum(g["ms"] for g in prof) / args.steps
         out["kernels"] = [{"kernel": g["kernel"], "m": g["m"], "k": g["k"], "N": g["N"], "ms_per_step": g["ms"] / args.steps,
                            "launches_per_step": g["launches"] / args.steps, "avg_launch_ms": g["ms"] / g["launches"],
