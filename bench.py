@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--quick", action="store_true", help="1/8-size problem (smoke / profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="exercise the multi-GPU code path (process group, TorchCollective, all-reduce hook) with one rank")
     return ap.parse_args()
 
 
@@ -143,6 +145,10 @@ def cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE JSON line: anything libraries print (e.g. the RCCL version banner) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -153,11 +159,17 @@ def main():
 
     import hippyflow_amd as hf
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.dist_single
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         collective = hf.TorchCollective()
     else:
         collective = hf.NullCollective()
@@ -167,7 +179,7 @@ def main():
 
     wl, op, B, Binv, N, r, p, desc = build_workload(args, hf, rank, world)
     k = r + p
-    A = hf.CollectiveOperator(op, collective, mpi_op="avg") if world > 1 else op
+    A = hf.CollectiveOperator(op, collective, mpi_op="avg") if use_dist else op
     hf.parRandom.reseed(1)
     Omega = hf.MultiVector(N, k)
     hf.parRandom.normal(1.0, Omega)          # identical on every rank (counter-based RNG): no broadcast
@@ -276,7 +288,9 @@ def main():
                          "note": "oracle = CPU restatement of the reference path on the same Omega and the same operator (factored form)"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
