@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--quick", action="store_true", help="1/8-size problem (smoke / profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--samples-total", type=int, default=512,
+                    help="config 4 only: total Monte-Carlo samples (512 = BASELINE; 64 on one GPU reproduces the per-GPU "
+                         "share of the 8-GPU run, for estimating the non-scaling part)")
     ap.add_argument("--dist-single", action="store_true",
                     help="exercise the multi-GPU code path (process group, TorchCollective, all-reduce hook) with one rank")
     return ap.parse_args()
@@ -48,7 +51,7 @@ def build_workload(args, hf, rank, world):
     from hippyflow_amd import workloads
     scale = 8 if args.quick else 1
     if args.workload == "as":
-        N, ns_total, q, r, p = 200000 // scale, 512, 100, 64, 10
+        N, ns_total, q, r, p = 200000 // scale, args.samples_total, 100, 64, 10
         assert ns_total % world == 0
         ns_local = ns_total // world
         wl = workloads.as_workload(N, ns_local, q=q, latent=q, rate=0.06, seed=4, first_sample=rank * ns_local, ns_total=ns_total)
@@ -86,7 +89,7 @@ def host_reference(args, wl, Omega_host, r, hf_o, hp_o):
     from hippyflow_amd import workloads
     if args.workload == "as":
         P = wl.P.to_dense()
-        H = workloads.as_reduced_matrix(4, wl.ns_total, wl.q, wl.latent, 0.06)
+        H = workloads.as_reduced_matrix(4, wl.ns_total, wl.q, wl.latent, 0.06)   # all samples of all ranks
         apply_A = lambda W: np.asfortranarray(P @ (H @ (P.T @ W)))
         return hp_o.double_pass_blas3(apply_A, Omega_host, r)
     if args.workload == "pod":
@@ -291,6 +294,7 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                      # whatever the libraries print while shutting down stays off stdout
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -942,6 +942,46 @@ extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, in
 }
 
 // ------------------------------------------------------------------ fused double pass
+// Rayleigh quotient T = Q^T A Q for operators of Gram form A = scale * X^T Gamma X (snapshot Gram, mean J^T J):
+//   T = scale * (X Q)^T Gamma (X Q)
+// -- the same matrix as the reference's (A Q)^T Q by associativity, symmetric by construction, and it needs only the
+// reduction GEMM G = X Q (no N x k block A Q, i.e. one of the four big contractions of the solve disappears).  A rank
+// average attached to the operator (CollectiveOperator 'avg'/'sum') is linear, so the hook is applied to T itself: the
+// second all-reduce of the solve shrinks from N x k to k x k.
+static bool op_has_gram_form(const hfmi_op* A) { return A->kind == OP_SNAPSHOT_GRAM || A->kind == OP_JTJ; }
+
+static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T) {
+  hfmi_ctx* ctx = A->ctx;
+  const hfmi_block& X = A->X;
+  if (X.N != Q->N) HFMI_FAIL(HFMI_ERR_INVALID, "operator acts on vectors of length %lld, got %lld", (long long)X.N, (long long)Q->N);
+  const int m = X.nvec, k = Q->nvec;
+  const int64_t ldm = round_up(m, 32);
+  const bool gam = (A->kind == OP_JTJ && A->gamma_inv != nullptr);
+  void* gv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)ldm * k * sizeof(double) * (gam ? 2 : 1), &gv));
+  double* Gc = (double*)gv;                          // (m x k), column-major: a block of k vectors of length m
+  double* Gc2 = gam ? Gc + ldm * k : Gc;
+  HFMI_TRY(launch_tsgemm_tn(ctx, X.p, X.ld, m, Q->p, Q->ld, k, X.N, 1.0, 0.0, Gc, 1, ldm, 0));
+  HFMI_TRY(launch_zero_pad(ctx, Gc, m, k, ldm));
+  if (gam) {
+    HFMI_TRY(launch_gamma_apply_cm(ctx, Gc, Gc2, ldm, A->ndata, A->q, k, A->gamma_inv, (int)round_up(A->q, 16)));
+    HFMI_TRY(launch_zero_pad(ctx, Gc2, m, k, ldm));
+  }
+  HFMI_TRY(launch_tsgemm_tn(ctx, Gc, ldm, k, Gc2, ldm, k, m, A->scale, 0.0, sm_ptr(ctx, slot_T), SM_LD, 1, 0));
+  if (A->post_fn) {
+    hfmi_block t;
+    t.ctx = ctx;
+    t.p = sm_ptr(ctx, slot_T);
+    t.N = SM_LD;
+    t.nvec = k;
+    t.ld = SM_LD;
+    t.owner = false;
+    const int rc = A->post_fn(A->post_user, &t);
+    if (rc != 0) HFMI_FAIL(HFMI_ERR_CALLBACK, "post-apply hook returned %d", rc);
+  }
+  return HFMI_OK;
+}
+
 static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* Omega, int r, int s, int flags,
                             double* host_d, hfmi_block* U) {
   if (!A || !Omega || !host_d || !U) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
@@ -977,9 +1017,14 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
   const int method = (flags & 2) ? HFMI_QR_MGS : HFMI_QR_AUTO;
   HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, method, nullptr));
-  HFMI_TRY(hfmi_op_apply(A, Qp, AQ, 0));
-  // T = (AQ)^T Q, small eigensolve, U = Q V[:, :r]
-  HFMI_TRY(launch_tsgemm_tn(ctx, AQ->p, AQ->ld, k, Qp->p, Qp->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_T), SM_LD, 1, 0));
+  if (op_has_gram_form(A) && !(flags & 4)) {
+    HFMI_TRY(op_rayleigh_quotient_gram(A, Qp, SM_T));
+  } else {
+    // T = (AQ)^T Q as the reference forms it
+    HFMI_TRY(hfmi_op_apply(A, Qp, AQ, 0));
+    HFMI_TRY(launch_tsgemm_tn(ctx, AQ->p, AQ->ld, k, Qp->p, Qp->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_T), SM_LD, 1, 0));
+  }
+  // small eigensolve, U = Q V[:, :r]
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
   HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1));

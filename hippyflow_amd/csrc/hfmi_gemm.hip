@@ -600,33 +600,41 @@ static inline int nn_tt(int nt, int waves) {
   return waves == 4 ? t4[nt] : t8[nt];
 }
 
+// Launch plan of tsgemm_nn for a tile of `tile_rows` rows: how many ways to split the reduction axis m so that the
+// grid fills the 256 CUs in (nearly) whole rounds.  Time model (the kernel is MFMA bound, the split partials only
+// cost their own HBM round trip in k_reduce_nn): t = flops / (eff * rate) + (msplit + 1) * N * r * 8 / hbm.
+static double nn_plan(hfmi_ctx* ctx, int tile_rows, int m, int r, int64_t N, double rate_factor, int* msplit_out) {
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int64_t ntiles = (N + tile_rows - 1) / tile_rows;
+  const int stages = (m + NN_KC - 1) / NN_KC;
+  const double flops = 2.0 * (double)ntiles * tile_rows * (double)m * (double)(((r + 15) / 16) * 16);
+  const double rate = 60e12 * rate_factor, hbm = 4.0e12;
+  int best = 1;
+  double best_t = 1e300;
+  for (int ns = 1; ns <= 64; ++ns) {
+    if (ns > 1 && stages / ns < 8) break;
+    const int64_t blocks = ntiles * ns;
+    const int64_t rounds = (blocks + cus - 1) / cus;
+    const double eff = (double)blocks / (double)(rounds * cus);
+    const double t = flops / (eff * rate) + (ns > 1 ? (ns + 1.0) * (double)N * r * 8.0 / hbm + 3e-6 : 0.0);
+    if (t < best_t - 1e-12) {
+      best_t = t;
+      best = ns;
+    }
+  }
+  *msplit_out = best;
+  return best_t;
+}
+
 template <int TT, int NT, int WAVES>
 static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r,
-                          double* Y, int64_t ldy, int64_t N) {
+                          double* Y, int64_t ldy, int64_t N, int msplit) {
   constexpr int SLD = NT * 16 + ((NT % 2 == 0) ? 16 : 0);
   const size_t shmem = (size_t)2 * NN_KC * SLD * sizeof(double);
   auto kern = k_tsgemm_nn<TT, NT, WAVES>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const int tile_rows = 16 * TT * WAVES;
   const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
-  // split the reduction axis so that the grid fills the chip in (nearly) whole rounds of CUs
-  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  const int stages = (m + NN_KC - 1) / NN_KC;
-  int best = 1;
-  double best_cost = 1e300;
-  for (int ns = 1; ns <= 64; ++ns) {
-    if (ns > 1 && stages / ns < 8) break;
-    const int64_t blocks = (int64_t)ntiles * ns;
-    const int64_t rounds = (blocks + cus - 1) / cus;
-    const double eff = (double)blocks / (double)(rounds * cus);
-    const double part_ratio = (ns > 1) ? 2.0 * ns * (double)r / (double)m : 0.0;  // partial write+read vs streaming A
-    const double cost = 1.0 / eff + part_ratio;
-    if (cost < best_cost - 1e-12) {
-      best_cost = cost;
-      best = ns;
-    }
-  }
-  int msplit = best;
   int mchunk = (int)round_up((m + msplit - 1) / msplit, NN_KC);
   msplit = (m + mchunk - 1) / mchunk;
   double* out = Y;
@@ -651,15 +659,38 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
   return HFMI_OK;
 }
 
+// one-wave-per-SIMD variants: the tile height is chosen among TMAX, TMAX-1, TMAX-2 (16-row tiles per wave) together
+// with the reduction split, by the time model above -- a slightly shorter tile often fills the last round of CUs
+template <int NT, int TMAX>
+static int nn_launch_w4(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
+                        int64_t ldy, int64_t N) {
+  constexpr int T1 = TMAX > 1 ? TMAX - 1 : 1, T2 = TMAX > 2 ? TMAX - 2 : 1;
+  int ms0 = 1, ms1 = 1, ms2 = 1;
+  const double c0 = nn_plan(ctx, 64 * TMAX, m, r, N, 1.0, &ms0);
+  const double c1 = (T1 != TMAX) ? nn_plan(ctx, 64 * T1, m, r, N, 0.98, &ms1) : 1e300;
+  const double c2 = (T2 != T1) ? nn_plan(ctx, 64 * T2, m, r, N, 0.96, &ms2) : 1e300;
+  if (c0 <= c1 && c0 <= c2) return nn_launch_inst<TMAX, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms0);
+  if (c1 <= c2) return nn_launch_inst<T1, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms1);
+  return nn_launch_inst<T2, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms2);
+}
+
+template <int NT, int TT>
+static int nn_launch_w8(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
+                        int64_t ldy, int64_t N) {
+  int ms = 1;
+  nn_plan(ctx, 128 * TT, m, r, N, 1.0, &ms);
+  return nn_launch_inst<TT, NT, 8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms);
+}
+
 static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
                     int64_t ldy, int64_t N) {
   const int nt = (r + 15) / 16;
   tuning_init();
   const int waves = g_nn_waves ? g_nn_waves : (nt >= 9 ? 8 : 4);
-#define NN_CASE(NTV, TT4, TT8)                                                                   \
-  case NTV:                                                                                      \
-    if (waves == 8) return nn_launch_inst<TT8, NTV, 8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);   \
-    return nn_launch_inst<TT4, NTV, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
+#define NN_CASE(NTV, TT4, TT8)                                                             \
+  case NTV:                                                                                \
+    if (waves == 8) return nn_launch_w8<NTV, TT8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);  \
+    return nn_launch_w4<NTV, TT4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
   switch (nt) {
     NN_CASE(1, 8, 8) NN_CASE(2, 8, 8) NN_CASE(3, 8, 5) NN_CASE(4, 8, 4) NN_CASE(5, 6, 3) NN_CASE(6, 5, 2)
     NN_CASE(7, 4, 2) NN_CASE(8, 4, 2) NN_CASE(9, 3, 1) NN_CASE(10, 3, 1) NN_CASE(11, 2, 1) NN_CASE(12, 2, 1)

@@ -156,6 +156,8 @@ int launch_diag_scale(hfmi_ctx* ctx, double* z, int64_t ldz, const double* r, in
                       int64_t N, int nvec);
 // small q x q (row-major) applied to each sample's q x k slab of G in place: G_i <- Gamma G_i
 int launch_gamma_apply(hfmi_ctx* ctx, double* G, int ldg, int ndata, int q, int k, const double* gamma, int ldgam);
+int launch_gamma_apply_cm(hfmi_ctx* ctx, const double* Gc, double* out, int64_t ld, int ndata, int q, int k, const double* gamma,
+                          int ldgam);
 
 // ------------------------------------------------------------------ small dense kernels (hfmi_small.hip)
 // G (k x k, SM slot) = R^T R; writes R (upper), Rinv (upper); if rtot_accumulate, Rtot <- R * Rtot.

@@ -393,6 +393,35 @@ int launch_gamma_apply(hfmi_ctx* ctx, double* G, int ldg, int ndata, int q, int 
   return HFMI_OK;
 }
 
+// column-major variant for the Rayleigh-quotient shortcut: Gc is (ndata*q) x k with leading dimension ld (one
+// column per probe vector); out[:, j] slab i = Gamma * Gc[:, j] slab i
+__global__ void k_gamma_apply_cm(const double* __restrict__ Gc, double* __restrict__ out, int64_t ld, int q, int k,
+                                 const double* __restrict__ gamma, int ldgam) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* slab = reinterpret_cast<double*>(smem);     // [k][q]
+  const int64_t base = (int64_t)blockIdx.x * q;
+  for (int e = threadIdx.x; e < q * k; e += blockDim.x) {
+    const int j = e / q, o = e % q;
+    slab[e] = Gc[(int64_t)j * ld + base + o];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < q * k; e += blockDim.x) {
+    const int j = e / q, o = e % q;
+    double s = 0.0;
+    for (int p = 0; p < q; ++p) s += gamma[o * ldgam + p] * slab[j * q + p];
+    out[(int64_t)j * ld + base + o] = s;
+  }
+}
+int launch_gamma_apply_cm(hfmi_ctx* ctx, const double* Gc, double* out, int64_t ld, int ndata, int q, int k, const double* gamma,
+                          int ldgam) {
+  const size_t shmem = (size_t)q * k * sizeof(double);
+  if (shmem > 150 * 1024) HFMI_FAIL(HFMI_ERR_INVALID, "gamma_apply: q*k slab (%zu bytes) exceeds LDS", shmem);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_gamma_apply_cm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(k_gamma_apply_cm, dim3(ndata), dim3(256), shmem, ctx->stream, Gc, out, ld, q, k, gamma, ldgam);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
 // ------------------------------------------------------------------ micro-benchmarks (roofline denominators)
 __global__ __launch_bounds__(256, 2) void k_bench_mfma(double* out, int iters) {
   d4 acc[8];

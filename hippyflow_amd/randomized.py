@@ -99,10 +99,10 @@ class _PostApplyHook:
         return False
 
 
-def _fused(A_dev, collective, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs):
+def _fused(A_dev, collective, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs, literal_T=False):
     d = np.empty(k)
     U = MultiVector(Omega.size(), k, ctx=Omega.ctx)
-    flags = (1 if sort_by_abs else 0) | (2 if use_mgs else 0)
+    flags = (1 if sort_by_abs else 0) | (2 if use_mgs else 0) | (4 if literal_T else 0)
 
     def run():
         if B_dev is None:
@@ -124,14 +124,16 @@ def _fused(A_dev, collective, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs,
     return d, U
 
 
-def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True):
+def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True, literal_T=False):
     """Randomized double pass for the dominant k eigenpairs of a Hermitian operator A.
-    Omega: MultiVector with nvec >= k Gaussian probe vectors (not modified)."""
+    Omega: MultiVector with nvec >= k Gaussian probe vectors (not modified).
+    ``literal_T=True`` forms T = (A Q)^T Q exactly as the reference does; by default the fused route forms the same
+    matrix as scale (X Q)^T Gamma (X Q) for Gram-form operators (one fewer N x k product, k x k rank average)."""
     nvec = Omega.nvec()
     assert nvec >= k
     A_dev, coll, mpi_op = _unwrap_collective(A)
     if fused and A_dev is not None:
-        return _fused(A_dev, coll, mpi_op, None, None, Omega, k, s, sort_by_abs, use_mgs)
+        return _fused(A_dev, coll, mpi_op, None, None, Omega, k, s, sort_by_abs, use_mgs, literal_T)
     Q = MultiVector(Omega)
     Y = MultiVector(Omega.size(), nvec, ctx=Omega.ctx)
     for _ in range(s):
@@ -148,7 +150,7 @@ def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, 
     return d, U
 
 
-def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True):
+def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True, literal_T=False):
     """Randomized double pass for A u = lambda B u (B SPD), U^T B U = I.
     ``Binv`` is a solver object (``solve(y, x)``) as in the reference, or an operator."""
     nvec = Omega.nvec()
@@ -158,7 +160,7 @@ def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_m
     if fused and A_dev is not None:
         B_dev = as_device_operator(B, N, Omega.ctx)
         Binv_dev = as_device_operator(Binv, N, Omega.ctx)
-        return _fused(A_dev, coll, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs)
+        return _fused(A_dev, coll, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs, literal_T)
     # B^{-1}: a device operator / solver as is; a host solver object (solve(y, x) on numpy arrays, like the
     # PETSc solvers of the reference) is reached through a host-callback operator
     Binv_op = as_device_operator(Binv, N, Omega.ctx)

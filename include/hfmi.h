@@ -170,7 +170,9 @@ int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_a
  * Omega has k >= r vectors and is not modified; on return host_d[r] holds the
  * eigenvalues (descending) and U (r vectors) the (B-)orthonormal eigenvectors.
  * Everything stays on the device between the first apply and the final U.
- * flags: bit 0 = sort by |d|;  bit 1 = use HFMI_QR_MGS. */
+ * flags: bit 0 = sort by |d|;  bit 1 = use HFMI_QR_MGS;  bit 2 = form T = (A Q)^T Q literally (by default, for
+ * operators of Gram form A = scale X^T Gamma X the same matrix is formed as scale (X Q)^T Gamma (X Q), which skips
+ * the second N x k block product and shrinks the rank average of that pass to k x k). */
 int hfmi_double_pass(hfmi_op* A, const hfmi_block* Omega, int r, int s, int flags, double* host_d,
                      hfmi_block* U);
 int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* Omega, int r, int s,

@@ -470,3 +470,99 @@ def test_torch_collective_on_device_blocks(ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ BASELINE sizes: size-independent properties
+def test_full_size_config3_pod_properties(ctx):
+    """Config 3 at full size (2048 snapshots x N = 5e5, r = 128, p = 10; 8.2 GB of snapshots generated in HBM):
+    orthonormality, eigen-residual and the known spectrum of the synthetic snapshot set."""
+    from hippyflow_amd import workloads
+    wl = workloads.pod_workload(N=500000, n=2048, latent=256, rate=0.05, seed=3)
+    hf.parRandom.reseed(1)
+    Omega = hf.MultiVector(500000, 138)
+    hf.parRandom.normal(1.0, Omega)
+    d, U = hf.doublePass(wl.operator, Omega, 128, s=1)
+    assert np.linalg.norm(U.dot_mv(U) - np.eye(128)) / np.sqrt(128) < 1e-10
+    AU = hf.MultiVector(500000, 128)
+    wl.operator.matMvMult(U, AU)
+    Rn = hf.MultiVector(AU)
+    hf.MvDSmatMult(U, np.diag(d), Rn)
+    Rn.axpy(-1.0, AU)
+    assert np.linalg.norm(Rn.norm()) / np.linalg.norm(AU.norm()) < 1e-4
+    assert hp_o.eig_rel_err(d[:40], wl.exact_eigenvalues[:40]) < 1e-6        # randomization error grows towards r
+    assert hp_o.eig_rel_err(d[:100], wl.exact_eigenvalues[:100]) < 1e-2
+    # linearity of the operator application at full size: A(2 W1 - 3 W2) = 2 A W1 - 3 A W2
+    W1, W2 = hf.MultiVector(500000, 16), hf.MultiVector(500000, 16)
+    hf.parRandom.normal(1.0, W1)
+    hf.parRandom.normal(1.0, W2)
+    Y1, Y2, Y3 = hf.MultiVector(500000, 16), hf.MultiVector(500000, 16), hf.MultiVector(500000, 16)
+    wl.operator.matMvMult(W1, Y1)
+    wl.operator.matMvMult(W2, Y2)
+    W3 = hf.MultiVector(W1)
+    W3.scale(2.0)
+    W3.axpy(-3.0, W2)
+    wl.operator.matMvMult(W3, Y3)
+    Y3.axpy(-2.0, Y1)
+    Y3.axpy(3.0, Y2)
+    assert np.linalg.norm(Y3.norm()) < 1e-12 * np.linalg.norm(Y1.norm())
+
+
+def test_config4_shard_of_eight_gpu_run(ctx):
+    """The per-GPU share of config 4 at 8 GPUs (64 of 512 samples, N = 2e5, 10 GB of Jacobians): the local
+    operator against the factored host form of the same samples, plus prior-free double-pass invariants."""
+    from hippyflow_amd import workloads
+    N, q = 200000, 100
+    wl = workloads.as_workload(N, 64, q=q, latent=q, rate=0.06, seed=4, first_sample=3 * 64, ns_total=512)
+    hf.parRandom.reseed(2)
+    W = hf.MultiVector(N, 74)
+    hf.parRandom.normal(1.0, W)
+    Y = hf.MultiVector(N, 74)
+    wl.operator.matMvMult(W, Y)
+    P = wl.P.to_dense()
+    H = np.einsum("ioc,iod->cd", wl.A, wl.A) / 64          # mean A_i^T A_i of THIS shard (samples 192..255)
+    ref = P @ (H @ (P.T @ W.to_dense()))
+    assert rel(Y.to_dense(), ref) < 1e-12
+    A0 = workloads.sample_factor(4, 3 * 64, q, q) * wl.s    # the shard starts at global sample 192
+    np.testing.assert_array_equal(wl.A[0], A0)
+    d, U = hf.doublePass(wl.operator, W, 64, s=1)
+    assert np.linalg.norm(U.dot_mv(U) - np.eye(64)) / 8 < 1e-10
+    d_ref, _ = hp_o.double_pass_blas3(lambda Z: np.asfortranarray(P @ (H @ (P.T @ Z))), np.asfortranarray(W.to_dense()), 64)
+    assert hp_o.eig_rel_err(d, d_ref) < 1e-9
+
+
+@pytest.mark.parametrize("N,k,r", [(1, 1, 1), (5, 3, 2), (31, 4, 4), (33, 256, 200), (100, 20, 20)])
+def test_ragged_and_extreme_shapes(ctx, N, k, r):
+    """Edge cases: vectors shorter than one 32-row stage, a single probe vector, the maximum block width (256)."""
+    rng = np.random.default_rng(N + k)
+    n = max(1, min(N, 7))
+    X = rng.standard_normal((n, N))
+    kk = min(k, N)                      # more probe vectors than the space has dimensions is rank deficient by construction
+    rr = min(r, kk)
+    Omega = np.asfortranarray(rng.standard_normal((N, kk)))
+    d, U = hf.doublePass(hf.SnapshotGramOperator(X), hf.MultiVector.from_dense(Omega), rr, s=1)
+    d_ref, U_ref = hp_o.double_pass(hf_o.SnapshotGramOperator(X), Omega, rr, s=1)
+    nz = d_ref > 1e-12 * max(d_ref[0], 1e-300)
+    np.testing.assert_allclose(d[nz], d_ref[nz], rtol=1e-8)
+    assert np.all(np.abs(d[~nz]) <= 1e-10 * max(d_ref[0], 1e-300))
+    with pytest.raises(AssertionError):
+        hf.doublePass(hf.SnapshotGramOperator(X), hf.MultiVector.from_dense(Omega), kk + 1)
+
+
+@pytest.mark.parametrize("gamma", [False, True])
+def test_gram_form_rayleigh_quotient_equals_literal(ctx, gamma):
+    """T = scale (X Q)^T Gamma (X Q) (default, fused route) against the reference's literal T = (A Q)^T Q."""
+    rng = np.random.default_rng(21)
+    J = rng.standard_normal((9, 12, 1500)) * np.exp(-0.2 * np.arange(12))[None, :, None]
+    Gam = None
+    if gamma:
+        Gm = rng.standard_normal((12, 12))
+        Gam = Gm @ Gm.T + 12 * np.eye(12)
+    Omega = np.asfortranarray(rng.standard_normal((1500, 10)))
+    op = hf.MeanJTJfromDataOperator(J, noise_cov_inv=Gam)
+    d_ref, U_ref = hp_o.double_pass(hf_o.MeanJTJOperator(J, Gam), Omega, 7)
+    d1, U1 = hf.doublePass(op, hf.MultiVector.from_dense(Omega), 7)
+    d2, U2 = hf.doublePass(op, hf.MultiVector.from_dense(Omega), 7, literal_T=True)
+    d3, U3 = hf.doublePass(op, hf.MultiVector.from_dense(Omega), 7, fused=False)
+    for d, U in ((d1, U1), (d2, U2), (d3, U3)):
+        np.testing.assert_allclose(d, d_ref, rtol=1e-10)
+        assert hp_o.principal_angle(np.asfortranarray(U.to_dense()[:, :5]), U_ref[:, :5]) < 1e-7
