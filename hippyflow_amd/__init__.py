@@ -9,13 +9,13 @@ from ._lib import Context, HfmiError, device_count, load
 from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, MultipleSamePartitioningPDEsCollective,
                           MultipleSerialPDEsCollective, NullCollective, TorchCollective)
 from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector
-from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator,
+from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobianOperator, DeviceOperator, HostCallbackOperator,
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, PriorPreconditionedProjector,
                         SnapshotGramOperator, Solver2Operator, SummedListOperator, as_device_operator, npToDeviceOperator)
 from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, KLEParameterList, KLEProjector,
                          ParameterList, PODParameterList, PODProjector, PODProjectorFromData, weighted_l2_norm_vector)
-from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
+from .randomized import accuracyEnhancedSVD, doublePass, doublePassG, parRandom, svd_small, sym_eig_small
 from .utilities import dense_to_mv_local, mv_to_dense, mv_to_dense_local
 
 __version__ = "0.1.0"

@@ -69,6 +69,7 @@ SIGNATURES = {
     "hfmi_op_destroy": [_P],
     "hfmi_borth_qr": [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int)],
     "hfmi_sym_eig_small": [_P, _P, C.c_int, C.c_int, _P, _P],
+    "hfmi_svd_small": [_P, _P, C.c_int, _P, _P, _P],
     "hfmi_double_pass": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "hfmi_double_pass_g": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "hfmi_bench_tsgemm_tn": [_P, _P, C.c_int, C.c_int, _P, _D],

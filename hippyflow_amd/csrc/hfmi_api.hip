@@ -941,6 +941,31 @@ extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, in
   return HFMI_OK;
 }
 
+// np.linalg.svd of the small triangular factor inside hp.accuracyEnhancedSVD
+extern "C" int hfmi_svd_small(hfmi_ctx* ctx, const double* host_R, int k, double* host_sigma, double* host_U, double* host_V) {
+  if (!ctx || !host_R || !host_sigma) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "svd_small: k=%d out of range [1,%d]", k, SM_MAXK);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HFMI_TRY(upload_small(ctx, host_R, k, k, sm_ptr(ctx, SM_T), SM_LD));
+  void* dv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
+  HFMI_TRY(launch_jacobi_svd(ctx, k, SM_T, SM_R, SM_V, (double*)dv));
+  hfmi_status_words st;
+  HFMI_TRY(read_status(ctx, &st));
+  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "svd_small: one-sided Jacobi did not converge (max cosine %.2e)", st.offdiag);
+  HFMI_TRY(read_back(ctx, (const double*)dv, k, host_sigma));
+  std::vector<double> tmp((size_t)k * SM_LD);
+  if (host_U) {
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_R), (size_t)k * SM_LD, tmp.data()));
+    for (int i = 0; i < k; ++i) memcpy(host_U + (size_t)i * k, tmp.data() + (size_t)i * SM_LD, (size_t)k * sizeof(double));
+  }
+  if (host_V) {
+    HFMI_TRY(read_back(ctx, sm_ptr(ctx, SM_V), (size_t)k * SM_LD, tmp.data()));
+    for (int i = 0; i < k; ++i) memcpy(host_V + (size_t)i * k, tmp.data() + (size_t)i * SM_LD, (size_t)k * sizeof(double));
+  }
+  return HFMI_OK;
+}
+
 // ------------------------------------------------------------------ fused double pass
 // Rayleigh quotient T = Q^T A Q for operators of Gram form A = scale * X^T Gamma X (snapshot Gram, mean J^T J):
 //   T = scale * (X Q)^T Gamma (X Q)

@@ -479,6 +479,136 @@ __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restric
   for (int c = k + tid; c < ((k + 15) & ~15); c += blockDim.x) V[i * ldv + c] = 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi SVD of a small square matrix R = U diag(sigma) V^T: column pairs of W (= R, then
+// R V) are rotated until mutually orthogonal; sigma_j = ||w_j||, U = W diag(1/sigma), V = product of the
+// rotations (logged, replayed by k_jacobi_vectors).  Full relative accuracy for small singular values (unlike
+// eig(R^T R)).  Used by accuracyEnhancedSVD (hippylib randomizedSVD; activeSubspaceProjector.py:813-834,1026).
+// One 16-lane group per column pair, one workgroup barrier per round.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_svd(const double* __restrict__ R, int ldr, int k,
+                                                              double* __restrict__ gwork, int use_lds,
+                                                              double2* __restrict__ rotlog, double* __restrict__ svals,
+                                                              int* __restrict__ perm, double* __restrict__ Uleft, int ldu,
+                                                              hfmi_status_words* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);   // 32
+  double* sig = red + 32;                          // 256
+  double* lds_w = sig + 256;
+  const int ldw = use_lds ? (k | 1) : SM_LD;
+  double* W = use_lds ? lds_w : gwork;             // column-major: W[col * ldw + row]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int grp = tid >> 4, gl = tid & 15, ngrp = nthr >> 4;
+  const int n = (k + 1) & ~1, np = n / 2;
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) W[j * ldw + i] = R[i * ldr + j];
+  __syncthreads();
+  int sweeps = 0;
+  double worst = 0.0;
+  for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
+    double mx = 0.0;
+    for (int r = 0; r < n - 1; ++r) {
+      for (int P = grp; P < np; P += ngrp) {
+        int a, b;
+        rr_pair(n, r, P, a, b);
+        double c = 1.0, sn = 0.0;
+        if (b < k) {
+          double* wa = W + a * ldw;
+          double* wb = W + b * ldw;
+          double al = 0.0, be = 0.0, ga = 0.0;
+          for (int i = gl; i < k; i += 16) {
+            const double x = wa[i], y = wb[i];
+            al += x * x;
+            be += y * y;
+            ga += x * y;
+          }
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) {
+            al += __shfl_xor(al, off, 64);
+            be += __shfl_xor(be, off, 64);
+            ga += __shfl_xor(ga, off, 64);
+          }
+          const double lim = sqrt(al * be);
+          const double ratio = lim > 0.0 ? fabs(ga) / lim : 0.0;
+          mx = fmax(mx, ratio);
+          if (ratio > EPS_D) {
+            const double zeta = 0.5 * (be - al) / ga;
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = rsqrt(1.0 + t * t);
+            sn = c * t;
+            for (int i = gl; i < k; i += 16) {
+              const double x = wa[i], y = wb[i];
+              wa[i] = c * x - sn * y;
+              wb[i] = sn * x + c * y;
+            }
+          }
+        }
+        if (gl == 0) rotlog[((size_t)sweeps * (n - 1) + r) * np + P] = make_double2(c, sn);
+      }
+      __syncthreads();
+    }
+    // convergence: every pair of the sweep was already orthogonal to round-off
+    mx = -block_min(-mx, red);
+    worst = mx;
+    __syncthreads();
+    if (mx <= 4.0 * EPS_D) {
+      ++sweeps;
+      break;
+    }
+  }
+  // singular values, sort descending
+  for (int j = wave; j < k; j += nw) {
+    double a2 = 0.0;
+    for (int i = lane; i < k; i += 64) a2 += W[j * ldw + i] * W[j * ldw + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a2 += __shfl_down(a2, off, 64);
+    if (lane == 0) sig[j] = sqrt(a2);
+  }
+  __syncthreads();
+  for (int i = tid; i < k; i += nthr) {
+    const double ki = sig[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j)
+      if (sig[j] > ki || (sig[j] == ki && j < i)) ++rank;
+    perm[rank] = i;
+    svals[rank] = ki;
+  }
+  __syncthreads();
+  // left singular vectors U[:, c] = w_perm[c] / sigma  (row-major k x k output)
+  for (int cidx = wave; cidx < k; cidx += nw) {
+    const int j = perm[cidx];
+    const double inv = sig[j] > 0.0 ? 1.0 / sig[j] : 0.0;
+    for (int i = lane; i < k; i += 64) Uleft[i * ldu + cidx] = W[j * ldw + i] * inv;
+  }
+  if (tid == 0) {
+    status->offdiag = worst;
+    status->sweeps = sweeps > JAC_MAX_SWEEPS ? JAC_MAX_SWEEPS : sweeps;
+    status->failed = (worst > 1e-12) ? 1 : 0;
+    status->tick[4] = 2;
+  }
+}
+
+int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, double* svals) {
+  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_svd: k=%d out of range", k);
+  const int use_lds = (k <= 140) ? 1 : 0;
+  const int n = (k + 1) & ~1;
+  const size_t log_bytes = (size_t)(JAC_MAX_SWEEPS + 1) * (n - 1) * (n / 2) * sizeof(double2) + 1024 * sizeof(int);
+  void* logv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_MISC, log_bytes, &logv));
+  double2* rotlog = (double2*)logv;
+  int* perm = (int*)((char*)logv + (size_t)(JAC_MAX_SWEEPS + 1) * (n - 1) * (n / 2) * sizeof(double2));
+  const size_t shmem = (32 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_r), SM_LD, k,
+                     sm_ptr(ctx, SM_TMP), use_lds, rotlog, svals, perm, sm_ptr(ctx, slot_u), SM_LD, ctx->status_dev);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
+                     sm_ptr(ctx, slot_v), SM_LD);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
 int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_eig: k=%d out of range", k);
   const int use_lds = (k <= 138) ? 1 : 0;   // 138*139*8 + 4.9 KB of tables = 158.3 KB <= 160 KB

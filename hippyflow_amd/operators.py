@@ -274,6 +274,40 @@ class HostCallbackOperator(DeviceOperator):
         self.mult(x, y)
 
 
+class DenseJacobianOperator:
+    """A stored Jacobian J (q x N) behind the reference's rectangular-operator protocol
+    (ObservableJacobian: ``mult`` N -> q, ``transpmult`` q -> N, ``init_vector(x, dim)``; jacobian.py:62-139).
+    The rows of J are the vectors of a block, so J W is a ``dot_mv`` (reduction over N) and J^T Y an ``MvDSmatMult``."""
+
+    def __init__(self, J, ctx=None):
+        self.rows = J if isinstance(J, MultiVector) else MultiVector.from_vectors(np.asarray(J, dtype=np.float64), ctx=ctx)
+        self.ctx = self.rows.ctx
+        self.shape = (self.rows.nvec(), self.rows.size())
+
+    def mpi_comm(self):
+        from .multivector import _NullComm
+        return _NullComm()
+
+    def init_vector(self, x, dim):
+        if dim not in (0, 1):
+            raise ValueError("dim must be 0 or 1")
+        x.init(self.shape[dim])
+
+    def matMvMult(self, X, Y):          # Y (q x k) = J X
+        Y_dense = self.rows.dot_mv(X)                    # (q, k)
+        L.call("hfmi_block_upload", Y.handle, L.ptr(np.ascontiguousarray(Y_dense)), L.LAYOUT_DENSE)
+
+    def matMvTranspmult(self, X, Y):    # Y (N x k) = J^T X
+        from .multivector import MvDSmatMult
+        MvDSmatMult(self.rows, np.ascontiguousarray(X.to_dense()), Y)
+
+    def mult(self, x, y):
+        self.matMvMult(x._mv, y._mv)
+
+    def transpmult(self, x, y):
+        self.matMvTranspmult(x._mv, y._mv)
+
+
 class ComposedOperator(DeviceOperator):
     """y = c(b(a x))."""
 

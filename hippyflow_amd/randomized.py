@@ -178,3 +178,40 @@ def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_m
     U = MultiVector(N, k, ctx=Omega.ctx)
     MvDSmatMult(Q, np.ascontiguousarray(V[:, :k]), U)
     return d, U
+
+
+def svd_small(R, ctx=None):
+    """np.linalg.svd(R) of a small square matrix on the device (one-sided Jacobi): R = U diag(s) V^T."""
+    R = L.as_f64(R)
+    k = R.shape[0]
+    sv, U, V = np.empty(k), np.empty((k, k)), np.empty((k, k))
+    L.call("hfmi_svd_small", (ctx or L.Context.default()).handle, L.ptr(R), k, L.ptr(sv), L.ptr(U), L.ptr(V))
+    return U, sv, V
+
+
+def accuracyEnhancedSVD(A, Omega, k, s=1, check=False):
+    """hp.accuracyEnhancedSVD: randomized SVD A ~ U diag(d) V^T of a rectangular operator with ``mult`` /
+    ``transpmult`` (or the block forms ``matMvMult`` / ``matMvTranspmult``) and ``init_vector(x, dim)``
+    (call sites: activeSubspaceProjector.py:813-834,1026).  Omega lives in the domain.  Returns (U, d, V)."""
+    from .multivector import MatMvTranspmult
+    nvec = Omega.nvec()
+    assert nvec >= k
+    y_vec = Vector(ctx=Omega.ctx)
+    A.init_vector(y_vec, 0)
+    Z = MultiVector(Omega)
+    Y = MultiVector(y_vec, nvec)
+    MatMvMult(A, Omega, Y)
+    for _ in range(s):
+        MatMvTranspmult(A, Y, Z)
+        MatMvMult(A, Z, Y)
+    Q = MultiVector(Y)
+    Q.orthogonalize()
+    BT = MultiVector(Omega.size(), nvec, ctx=Omega.ctx)
+    MatMvTranspmult(A, Q, BT)
+    R = BT.orthogonalize()
+    V_hat, d, U_hatT = svd_small(R, Omega.ctx)        # R = V_hat diag(d) U_hatT^T
+    U = MultiVector(y_vec, k)
+    MvDSmatMult(Q, np.ascontiguousarray(U_hatT[:, :k]), U)
+    V = MultiVector(Omega.size(), k, ctx=Omega.ctx)
+    MvDSmatMult(BT, np.ascontiguousarray(V_hat[:, :k]), V)
+    return U, d[:k].copy(), V

@@ -165,6 +165,11 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
 int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,
                        double* host_V);
 
+/* np.linalg.svd(R) of the small factor inside hp.accuracyEnhancedSVD (activeSubspaceProjector.py:813-834,1026):
+ * R (host, k x k row-major) = U diag(sigma) V^T, sigma descending; U, V row-major k x k (columns = vectors).
+ * One-workgroup one-sided Jacobi in LDS (full relative accuracy of small singular values). */
+int hfmi_svd_small(hfmi_ctx* ctx, const double* host_R, int k, double* host_sigma, double* host_U, double* host_V);
+
 /* ---------------------------------------------------------------- full solves (a5, a6)
  * hp.doublePass(A, Omega, r, s) / hp.doublePassG(A, B, Binv, Omega, r, s):
  * Omega has k >= r vectors and is not modified; on return host_d[r] holds the

@@ -307,3 +307,25 @@ def principal_angle(U, U_ref, apply_B=None):
     G = P.T @ BP
     lam = np.linalg.eigvalsh(0.5 * (G + G.T)).max()
     return float(np.arcsin(min(1.0, np.sqrt(max(lam, 0.0)))))
+
+
+# ----------------------------------------------------------------------------
+# hp.accuracyEnhancedSVD (hippylib randomizedSVD.py; call sites activeSubspaceProjector.py:813-834,1026,
+# dataGenerator.py:182-193).  PARITY UNPINNED like the rest of this module.  A is a rectangular operator
+# with mult (domain -> range) and transpmult; Omega has nvec >= k columns in the DOMAIN.
+# ----------------------------------------------------------------------------
+def accuracy_enhanced_svd(A_mult, A_transpmult, Omega, k, s=1):
+    """Y = A Omega; s times {Z = A^T Y; Y = A Z}; Q = orth(Y); B^T = A^T Q = Q_B R; svd(R) = Vh diag(d) Uh;
+    U = Q Uh^T[:, :k], V = Q_B Vh[:, :k].  ``A_mult`` / ``A_transpmult`` map 2-D arrays (block form)."""
+    nvec = Omega.shape[1]
+    assert nvec >= k
+    Y = np.asfortranarray(A_mult(Omega))
+    for _ in range(s):
+        Z = A_transpmult(Y)
+        Y = np.asfortranarray(A_mult(Z))
+    Q = as_block(Y)
+    mgs_reortho(Q)
+    BT = as_block(A_transpmult(Q))
+    R = mgs_reortho(BT)
+    V_hat, d, U_hat = np.linalg.svd(R, full_matrices=False)
+    return np.asfortranarray(Q @ U_hat.T[:, :k]), d[:k], np.asfortranarray(BT @ V_hat[:, :k])

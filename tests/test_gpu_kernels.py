@@ -282,3 +282,16 @@ def test_sym_eig_small_graded_relative_accuracy(ctx):
     d, _ = hf.sym_eig_small(T)
     w = np.linalg.svd(G, compute_uv=False) ** 2
     assert np.max(np.abs(d - w) / w) < 1e-9
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 30, 75, 138, 200])
+def test_svd_small_matches_numpy(ctx, k):
+    rng = np.random.default_rng(k)
+    R = np.triu(rng.standard_normal((k, k))) @ np.diag(np.logspace(0, -10, k))      # graded, like the QR factor of a decaying block
+    U, sv, V = hf.svd_small(R)
+    ref = np.linalg.svd(R, compute_uv=False)
+    assert np.all(np.diff(sv) <= 0)
+    np.testing.assert_allclose(sv, ref, rtol=1e-9, atol=1e-15 * ref[0])               # relative accuracy of small singular values
+    assert np.linalg.norm(U.T @ U - np.eye(k)) < 1e-12 * k
+    assert np.linalg.norm(V.T @ V - np.eye(k)) < 1e-12 * k
+    assert np.linalg.norm((U * sv) @ V.T - R) < 1e-13 * k * np.linalg.norm(R)

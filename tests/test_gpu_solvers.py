@@ -566,3 +566,23 @@ def test_gram_form_rayleigh_quotient_equals_literal(ctx, gamma):
     for d, U in ((d1, U1), (d2, U2), (d3, U3)):
         np.testing.assert_allclose(d, d_ref, rtol=1e-10)
         assert hp_o.principal_angle(np.asfortranarray(U.to_dense()[:, :5]), U_ref[:, :5]) < 1e-7
+
+
+def test_accuracy_enhanced_svd_of_a_jacobian(ctx):
+    """randomized SVD of a per-sample Jacobian (activeSubspaceProjector.py:813-834,1026)."""
+    rng = np.random.default_rng(31)
+    q, N, k, p = 40, 3000, 12, 8
+    Uj, _ = np.linalg.qr(rng.standard_normal((q, q)))
+    Vj, _ = np.linalg.qr(rng.standard_normal((N, q)))
+    sj = np.exp(-0.5 * np.arange(q))
+    J = (Uj * sj) @ Vj.T
+    Omega = np.asfortranarray(rng.standard_normal((N, k + p)))
+    U_ref, d_ref, V_ref = hp_o.accuracy_enhanced_svd(lambda W: J @ W, lambda Y: J.T @ Y, Omega, k, s=1)
+    U, d, V = hf.accuracyEnhancedSVD(hf.DenseJacobianOperator(J), hf.MultiVector.from_dense(Omega), k, s=1)
+    Ud, Vd = U.to_dense(), V.to_dense()
+    np.testing.assert_allclose(d, d_ref, rtol=1e-9)
+    np.testing.assert_allclose(d, sj[:k], rtol=1e-6)                                    # true singular values
+    assert np.linalg.norm(Ud.T @ Ud - np.eye(k)) < 1e-10 and np.linalg.norm(Vd.T @ Vd - np.eye(k)) < 1e-10
+    assert hp_o.principal_angle(np.asfortranarray(Ud[:, :8]), U_ref[:, :8]) < 1e-6
+    assert hp_o.principal_angle(np.asfortranarray(Vd[:, :8]), V_ref[:, :8]) < 1e-6
+    assert np.linalg.norm((Ud * d) @ Vd.T - J) / np.linalg.norm(J) < 2 * sj[k] / sj[0] + 1e-8
