@@ -16,6 +16,8 @@ from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobi
 from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, KLEParameterList, KLEProjector,
                          ParameterList, PODParameterList, PODProjector, PODProjectorFromData, weighted_l2_norm_vector)
 from .randomized import accuracyEnhancedSVD, doublePass, doublePassG, parRandom, svd_small, sym_eig_small
+from .errors import projection_error_test
+from .io_utils import get_projectors, modify_projectors
 from .utilities import dense_to_mv_local, mv_to_dense, mv_to_dense_local
 
 __version__ = "0.1.0"

@@ -1,0 +1,84 @@
+"""On-disk formats consumed downstream of the projectors.
+
+* what the projectors save: ``AS_{n}{input_decoder_name}.npy`` + ``AS_{n}_d_GN.npy``, ``AS_{n}{output_decoder_name}.npy``
+  + ``AS_{n}_d_NG.npy`` (activeSubspaceProjector.py:475-480,587-603), ``KLE_decoder.npy`` + ``KLE_d.npy``
+  (KLEProjector.py:190-192), ``POD_projector.npy`` + ``POD_d.npy`` (PODProjector.py:382-384); all (N, r) / (r,) fp64;
+* what the training side loads: ``AS_input_projector.npy``, ``AS_d_GN.npy``, ``AS_output_projector.npy``,
+  ``AS_d_NG.npy``, ``KLE_projector.npy``, ``KLE_d.npy``, ``POD_projector.npy``, ``POD_d.npy``
+  (applications/confusion/confusion_utilities.py:115-172).  The two naming schemes differ in the reference; the
+  loader here accepts either.
+* truncation by eigenvalue tolerance or fixed rank, re-orthogonalisation and rescaling of the chosen pair
+  (confusion_utilities.py:174-225); the QR runs on the device.
+"""
+import glob
+import os
+
+import numpy as np
+
+from .multivector import MultiVector
+
+
+def _first_existing(data_dir, patterns):
+    for pat in patterns:
+        hits = sorted(glob.glob(os.path.join(data_dir, pat)))
+        if hits:
+            return hits[0]
+    raise FileNotFoundError("none of %s found in %s" % (patterns, data_dir))
+
+
+def _truncate(P, d_path_patterns, data_dir, tolerance, fixed_rank):
+    if fixed_rank > 0:
+        return P[:, :fixed_rank]
+    d = np.load(_first_existing(data_dir, d_path_patterns))
+    return P[:, np.where(d > tolerance)[0]]
+
+
+def get_projectors(data_dir, as_input_tolerance=1e-4, as_output_tolerance=1e-4, kle_tolerance=1e-4, pod_tolerance=1e-4,
+                   fixed_input_rank=0, fixed_output_rank=0, mixed_output=True, verbose=False):
+    """Dictionary {'AS_input', 'AS_output', 'KLE', 'POD'} of (N, r) arrays truncated by tolerance or fixed rank.
+    Projectors that are absent from ``data_dir`` are skipped."""
+    spec = {
+        'AS_input': (['AS_input_projector.npy', 'AS_*_input_decoder.npy'], ['AS_d_GN.npy', 'AS_*_d_GN.npy'], as_input_tolerance, fixed_input_rank),
+        'AS_output': (['AS_output_projector.npy', 'AS_*_output_decoder.npy'], ['AS_d_NG.npy', 'AS_*_d_NG.npy'], as_output_tolerance, fixed_output_rank),
+        'KLE': (['KLE_projector.npy', 'KLE_decoder.npy'], ['KLE_d.npy'], kle_tolerance, fixed_input_rank),
+        'POD': (['POD_projector.npy'], ['POD_d.npy'], pod_tolerance, fixed_output_rank),
+    }
+    out = {}
+    for key, (p_pat, d_pat, tol, fixed) in spec.items():
+        try:
+            P = np.load(_first_existing(data_dir, p_pat))
+        except FileNotFoundError:
+            continue
+        if verbose:
+            print(key, 'projector shape before truncation = ', P.shape)
+        out[key] = _truncate(P, d_pat, data_dir, tol, fixed)
+        if verbose:
+            print(key, 'projector shape after truncation = ', out[key].shape)
+    return out
+
+
+def _orthonormalize(P):
+    mv = MultiVector.from_dense(np.ascontiguousarray(P))
+    mv.orthogonalize()
+    return mv.to_dense()
+
+
+def modify_projectors(projectors, input_subspace, output_subspace, seed=0):
+    """Orthogonalise and rescale the chosen input/output projector pair for the network's first/last layers.
+    Input: Q / (N/(32 r) * ||Q||_F); output: Q / ||Q||_F; 'random' draws a Gaussian basis of the same shape."""
+    assert input_subspace in ['kle', 'as', 'random']
+    assert output_subspace in ['pod', 'as', 'random']
+    rng = np.random.default_rng(seed)
+    if input_subspace == 'random':
+        input_projector = _orthonormalize(rng.standard_normal(projectors['KLE'].shape))
+    else:
+        input_projector = _orthonormalize(projectors['KLE'] if input_subspace == 'kle' else projectors['AS_input'])
+    scale_in = float(input_projector.shape[0]) / (32 * float(input_projector.shape[-1]))
+    input_projector = input_projector / (scale_in * np.linalg.norm(input_projector))
+    if output_subspace == 'random':
+        output_projector = rng.standard_normal(projectors['POD'].shape)
+        output_projector /= np.linalg.norm(output_projector)
+    else:
+        output_projector = _orthonormalize(projectors['POD'] if output_subspace == 'pod' else projectors['AS_output'])
+        output_projector = output_projector / np.linalg.norm(output_projector)
+    return input_projector, output_projector

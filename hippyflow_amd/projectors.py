@@ -340,6 +340,23 @@ class KLEProjector:
         return self.d_KLE, kle_decoder, kle_encoder
 
 
+    def test_errors(self, ranks=[None], cut_off=1e-12, samples=None):
+        """Projection-error test of the KLE basis (KLEProjector.py:202-282).  ``samples`` is a block / (n, N) array
+        of prior draws; if omitted ``prior.sample_block(n)`` supplies ``error_test_samples`` of them (the
+        reference loops prior.sample over hp.parRandom noise, a host PDE-side operation)."""
+        from .errors import projection_error_test
+        want = max((r for r in ranks if r is not None), default=0)
+        if self.d_KLE is None or len(self.d_KLE) < want:
+            if want:
+                self.parameters['rank'] = max(self.parameters['rank'], want)
+            self.construct_input_subspace()
+        if samples is None:
+            samples = self.prior.sample_block(self.parameters['error_test_samples'])
+        _, avg, std = projection_error_test(self.V_KLE, samples, ranks, B=self.M if self.M_orthogonal else None,
+                                            d=self.d_KLE, cut_off=cut_off, collective=self.collective)
+        return avg, std
+
+
 # =====================================================================================
 # POD
 # =====================================================================================
@@ -380,6 +397,17 @@ class PODProjector:
         if _is_root() and self.parameters['output_directory'] is not None:
             _save(self.parameters['output_directory'], 'POD_projector', mv_to_dense(self.U_MV))
             _save(self.parameters['output_directory'], 'POD_d', self.d)
+
+    def test_output_errors(self, ranks=[None], cut_off=1e-10, samples=None):
+        """Projection-error test on the output (PODProjector.py:392-478): relative error of projecting observable
+        samples onto the leading POD vectors.  ``samples`` defaults to fresh draws from the observable."""
+        from .errors import projection_error_test
+        if self.d is None or self.U_MV is None:
+            self.construct_subspace()
+        if samples is None:
+            samples = self.observable.sample_observables(self.parameters['sample_per_process'], self.prior, None)
+        _, avg, std = projection_error_test(self.U_MV, samples, ranks, d=self.d, cut_off=cut_off, collective=self.collective)
+        return avg, std
 
 
 def weighted_l2_norm_vector(x, W):

@@ -331,6 +331,14 @@ def test_kle_projector_class(ctx):
     assert np.linalg.norm(CV - V2 * d2) / np.linalg.norm(CV) < 1e-4               # :198-217
     with pytest.raises(NotImplementedError):
         kle.construct_input_subspace("prior")
+    # projection-error test of the basis (KLEProjector.py:202-282) on prior-like samples x = C^{1/2}-ish noise
+    kle.construct_input_subspace("mass")
+    Xs = (np.linalg.cholesky(Cm + 1e-12 * np.eye(N)) @ np.random.default_rng(3).standard_normal((N, 12))).T
+    avg, std = kle.test_errors(ranks=[5, 15, 30], samples=Xs)
+    assert avg.shape == (3,) and avg[0] > avg[1] > avg[2] > 0 and np.all(std >= 0)
+    Vm = kle.V_KLE.to_dense()
+    E = Xs.T - Vm[:, :15] @ (Vm[:, :15].T @ (M @ Xs.T))
+    np.testing.assert_allclose(avg[1], np.mean(np.linalg.norm(E, axis=0) / np.linalg.norm(Xs.T, axis=0)), rtol=1e-8)
 
 
 def test_active_subspace_batched_equals_serialized(ctx, tmp_path):
@@ -586,3 +594,38 @@ def test_accuracy_enhanced_svd_of_a_jacobian(ctx):
     assert hp_o.principal_angle(np.asfortranarray(Ud[:, :8]), U_ref[:, :8]) < 1e-6
     assert hp_o.principal_angle(np.asfortranarray(Vd[:, :8]), V_ref[:, :8]) < 1e-6
     assert np.linalg.norm((Ud * d) @ Vd.T - J) / np.linalg.norm(J) < 2 * sj[k] / sj[0] + 1e-8
+
+
+def test_projection_errors_and_downstream_formats(ctx, tmp_path):
+    """projection-error test of a basis and the loader side of the on-disk formats."""
+    N, n = 1500, 60
+    X = _snapshots(n, N, 0.25, 12)
+    params = hf.PODParameterList()
+    params["verbose"], params["rank"], params["output_directory"] = False, 20, str(tmp_path) + "/"
+
+    class Obs:
+        def sample_observables(self, k, prior, noise):
+            return X[:k]
+
+    params["sample_per_process"] = n
+    hf.parRandom.reseed(3)
+    pod = hf.PODProjector(Obs(), None, parameters=params)
+    pod.construct_subspace()
+    avg, std = pod.test_output_errors(ranks=[5, 10, 20])
+    U = pod.U_MV.to_dense()
+    for r, a in zip((5, 10, 20), avg):
+        E = X.T - U[:, :r] @ (U[:, :r].T @ X.T)
+        np.testing.assert_allclose(a, np.mean(np.linalg.norm(E, axis=0) / np.linalg.norm(X.T, axis=0)), rtol=1e-9)
+    assert avg[0] > avg[1] > avg[2] and np.all(std >= 0)
+    ranks, avg2, _ = hf.projection_error_test(pod.U_MV, X, ranks=[None, 3], d=pod.d, cut_off=pod.d[10])
+    assert ranks == [3]                                           # ranks beyond the numerical rank are dropped
+    # the training-side loader accepts what the projectors save
+    proj = hf.get_projectors(str(tmp_path) + "/", pod_tolerance=pod.d[7] * 0.999)
+    assert set(proj) == {"POD"} and proj["POD"].shape == (N, 8)
+    proj["KLE"] = np.random.default_rng(0).standard_normal((N, 6))
+    pin, pout = hf.modify_projectors(proj, "kle", "pod")
+    assert pin.shape == (N, 6) and pout.shape == (N, 8)
+    G = pin.T @ pin
+    np.testing.assert_allclose(G, np.eye(6) * G[0, 0], atol=1e-12 * G[0, 0])          # orthogonal, equal norms
+    np.testing.assert_allclose(np.linalg.norm(pin), 1.0 / (N / (32.0 * 6)), rtol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(pout), 1.0, rtol=1e-12)
