@@ -1,0 +1,149 @@
+"""Derivative-informed projected neural surrogates (BASELINE config 5) in PyTorch-ROCm.
+
+Counterparts of applications/confusion/dipnet_paper/neuralNetworks.py (keras/TF1-compat in the reference):
+``projected_low_rank_residual_network`` (:43-93), ``projected_dense`` (:98-116), ``generic_dense`` (:118-124),
+``low_rank_linear`` (:142-147), ``BiasLayer`` (:22-32).  The frozen first layer is initialised with an input
+projector (AS or KLE decoder, (dM, r_in)), the trainable last layer with an output projector transposed (POD
+basis, (dQ, r_out)); both come from ``hippyflow_amd.get_projectors`` / ``modify_projectors``.  Training uses Adam
+(the reference's hessianlearn INCG optimiser is not available) under bf16 autocast on the GPU; the accuracy
+metric is the reference scripts' relative l2 test error.  PARITY UNPINNED: TensorFlow / hessianlearn cannot run in
+this environment and the reference stores no accuracy numbers; the test compares against an fp32 CPU evaluation of
+the same PyTorch architecture.
+
+This module needs torch (the only part of the package that does: the projector path itself is ctypes + HIP).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+class BiasLayer(nn.Module):
+    """x + b with b initialised to zero (neuralNetworks.py:22-32)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return x + self.bias
+
+
+class LowRankLayer(nn.Module):
+    """Dense(rank, softplus) followed by Dense(dim) (low_rank_layer, neuralNetworks.py:34-39)."""
+
+    def __init__(self, dim, rank=8):
+        super().__init__()
+        self.down = nn.Linear(dim, rank)
+        self.up = nn.Linear(rank, dim)
+
+    def forward(self, x):
+        return self.up(nn.functional.softplus(self.down(x)))
+
+
+def _set_projection_weights(layer, projector, trainable):
+    with torch.no_grad():
+        layer.weight.copy_(torch.as_tensor(np.ascontiguousarray(projector.T), dtype=layer.weight.dtype))
+    layer.weight.requires_grad_(trainable)
+
+
+class ProjectedLowRankResidualNetwork(nn.Module):
+    """input projection (frozen) -> bias -> residual low-rank softplus blocks -> dense(r_out) -> output layer
+    initialised with the output projector (projected_low_rank_residual_network, neuralNetworks.py:43-93)."""
+
+    def __init__(self, input_projector, output_projector, ranks=(4, 4), trainable=False, set_weights=True, random_weights=False):
+        super().__init__()
+        input_dim, r_in = input_projector.shape
+        output_dim, r_out = output_projector.shape
+        self.input_proj_layer = nn.Linear(input_dim, r_in, bias=False)
+        self.input_bias = BiasLayer(r_in)
+        self.blocks = nn.ModuleList([LowRankLayer(r_in, rank) for rank in ranks])
+        self.reduced = nn.Linear(r_in, r_out)
+        self.output_layer = nn.Linear(r_out, output_dim)
+        if set_weights:
+            rng = np.random.default_rng(0)
+            _set_projection_weights(self.input_proj_layer, rng.standard_normal(input_projector.shape) if random_weights else input_projector, trainable)
+            with torch.no_grad():
+                w = rng.standard_normal(output_projector.shape) if random_weights else output_projector
+                self.output_layer.weight.copy_(torch.as_tensor(np.ascontiguousarray(w), dtype=self.output_layer.weight.dtype))
+                self.output_layer.bias.zero_()
+        else:
+            self.input_proj_layer.weight.requires_grad_(trainable)
+
+    def forward(self, x):
+        z = self.input_bias(self.input_proj_layer(x))
+        for blk in self.blocks:
+            z = blk(z) + z
+        return self.output_layer(self.reduced(z))
+
+
+class ProjectedDense(nn.Module):
+    """projected_dense (neuralNetworks.py:98-116)."""
+
+    def __init__(self, input_projector, output_projector, intermediate_layers=1, trainable=False):
+        super().__init__()
+        input_dim, r_in = input_projector.shape
+        output_dim, r_out = output_projector.shape
+        self.input_proj_layer = nn.Linear(input_dim, r_in, bias=False)
+        _set_projection_weights(self.input_proj_layer, input_projector, trainable)
+        self.input_bias_layer = BiasLayer(r_in)
+        self.dense_reduction_layer = nn.Linear(r_in, r_in)
+        dims = [r_in] + [r_out] * intermediate_layers
+        self.inner = nn.ModuleList([nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self.output_layer = nn.Linear(dims[-1], output_dim)
+
+    def forward(self, x):
+        z = nn.functional.softplus(self.dense_reduction_layer(self.input_bias_layer(self.input_proj_layer(x))))
+        for layer in self.inner:
+            z = nn.functional.softplus(layer(z))
+        return self.output_layer(z)
+
+
+class GenericDense(nn.Module):
+    """generic_dense (neuralNetworks.py:118-124): the un-projected full-space baseline."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.l1, self.l2, self.out = nn.Linear(input_dim, output_dim), nn.Linear(output_dim, output_dim), nn.Linear(output_dim, output_dim)
+
+    def forward(self, x):
+        return self.out(nn.functional.softplus(self.l2(nn.functional.softplus(self.l1(x)))))
+
+
+def l2_accuracy(model, m, q, batch=4096):
+    """1 - mean_i ||q_i - f(m_i)||_2 / ||q_i||_2 (the 'l2 accuracy' the reference's training scripts print)."""
+    model.eval()
+    errs = []
+    with torch.no_grad():
+        for i in range(0, m.shape[0], batch):
+            pred = model(m[i:i + batch]).float()
+            ref = q[i:i + batch].float()
+            errs.append(torch.linalg.norm(pred - ref, dim=1) / torch.linalg.norm(ref, dim=1))
+    return 1.0 - float(torch.cat(errs).mean())
+
+
+def train_surrogate(model, m_train, q_train, epochs=50, batch_size=128, lr=1e-3, bf16=True, seed=0, verbose=False):
+    """Mean-squared-error regression with Adam.  On a GPU the forward/backward run under bf16 autocast
+    (parameters and optimiser state stay fp32); on CPU in fp32."""
+    device = m_train.device
+    use_amp = bool(bf16 and device.type == "cuda")
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    n = m_train.shape[0]
+    history = []
+    for ep in range(epochs):
+        model.train()
+        perm = torch.randperm(n, generator=gen).to(device)
+        total = 0.0
+        for i in range(0, n, batch_size):
+            idx = perm[i:i + batch_size]
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast(device_type=device.type, dtype=torch.bfloat16, enabled=use_amp):
+                pred = model(m_train[idx])
+            loss = nn.functional.mse_loss(pred.float(), q_train[idx])
+            loss.backward()
+            opt.step()
+            total += float(loss.detach()) * idx.numel()
+        history.append(total / n)
+        if verbose:
+            print("epoch %d  mse %.4e" % (ep, history[-1]))
+    return history
