@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhfmi.so")
+LIB_PATH = os.environ.get("HFMI_LIB") or os.path.join(HERE, "libhfmi.so")   # HFMI_LIB: A/B builds (scripts/)
 
 LAYOUT_VECTORS = 0
 LAYOUT_DENSE = 1

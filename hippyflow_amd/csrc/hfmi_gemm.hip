@@ -211,21 +211,53 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_tn(const doubl
       }
 }
 
-// C[i*rs + j*cs] = scale * sum_sp part[sp][...] + beta * C   (fixed summation order: deterministic)
-__global__ void k_reduce_partials(const double* __restrict__ part, int nsplit, int64_t pstride, int inner_ld, int tr,
-                                  int m, int k, double scale, double beta, double* __restrict__ C, int64_t rs,
-                                  int64_t cs) {
-  const int fast = blockIdx.x * blockDim.x + threadIdx.x;
+// C[i*rs + j*cs] = scale * sum_sp part[sp][...] + beta * C.  A workgroup is 64 outputs x RY split lanes: lane y sums
+// the slices y, y+RY, y+2RY, ... (four independent running sums, so four loads are in flight), the RY lane totals
+// are combined through LDS in a fixed order -> deterministic, and the sum over hundreds of slices is no longer
+// one serial chain per output element (that chain used to cost more than the contraction itself for k <= 138).
+constexpr int RY = 16;
+__global__ __launch_bounds__(64 * RY) void k_reduce_partials(const double* __restrict__ part, int nsplit, int64_t pstride,
+                                                             int inner_ld, int tr, int m, int k, double scale, double beta,
+                                                             double* __restrict__ C, int64_t rs, int64_t cs) {
+  __shared__ double sh[RY][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int fast = blockIdx.x * 64 + tx;
   const int fastn = tr ? m : k, slown = tr ? k : m;
-  if (fast >= fastn) return;
   for (int slow = blockIdx.y; slow < slown; slow += gridDim.y) {
-    const int i = tr ? fast : slow, j = tr ? slow : fast;
-    const double* p = part + (int64_t)slow * inner_ld + fast;
-    double s = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) s += p[(int64_t)sp * pstride];
-    double* out = C + (int64_t)i * rs + (int64_t)j * cs;
-    *out = (beta != 0.0) ? scale * s + beta * (*out) : scale * s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (fast < fastn) {
+      const double* p = part + (int64_t)slow * inner_ld + fast;
+      int sp = ty;
+      for (; sp + 3 * RY < nsplit; sp += 4 * RY) {
+        s0 += p[(int64_t)sp * pstride];
+        s1 += p[(int64_t)(sp + RY) * pstride];
+        s2 += p[(int64_t)(sp + 2 * RY) * pstride];
+        s3 += p[(int64_t)(sp + 3 * RY) * pstride];
+      }
+      for (; sp < nsplit; sp += RY) s0 += p[(int64_t)sp * pstride];
+    }
+    sh[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && fast < fastn) {
+      double s = 0.0;
+#pragma unroll
+      for (int y = 0; y < RY; ++y) s += sh[y][tx];
+      const int i = tr ? fast : slow, j = tr ? slow : fast;
+      double* out = C + (int64_t)i * rs + (int64_t)j * cs;
+      *out = (beta != 0.0) ? scale * s + beta * (*out) : scale * s;
+    }
+    __syncthreads();
   }
+}
+
+int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_t pstride, int inner_ld, bool tr, int m,
+                           int k, double scale, double beta, double* C, int64_t rs, int64_t cs) {
+  const int fastn = tr ? m : k, slown = tr ? k : m;
+  dim3 block(64, RY), grid((fastn + 63) / 64, slown < 32768 ? slown : 32768);
+  hipLaunchKernelGGL(k_reduce_partials, grid, block, 0, ctx->stream, part, nsplit, pstride, inner_ld, tr ? 1 : 0, m, k,
+                     scale, beta, C, rs, cs);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
 }
 
 #include <stdlib.h>
@@ -235,6 +267,7 @@ __global__ void k_reduce_partials(const double* __restrict__ part, int nsplit, i
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
 //   ring : register prefetch ring of the streamed operand in tsgemm_tn (2 = distance 1, 4 = distance 3)
 static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 8 column tiles, else 8)
+static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
   if (g_waves) return;
   const char* e = getenv("HFMI_GEMM_WAVES");
@@ -255,6 +288,8 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   if (key && !strcmp(key, "waves") && (value == 4 || value == 8)) g_waves = value;
   else if (key && !strcmp(key, "ring") && (value == 2 || value == 4)) g_ring = value;
   else if (key && !strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
+  else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
+  else if (key && !strcmp(key, "ss_percu") && value >= 1 && value <= 4) tsgemm_ss_set_percu(value);
   else HFMI_FAIL(HFMI_ERR_INVALID, "tuning_set: unknown key/value");
   return HFMI_OK;
 }
@@ -371,19 +406,15 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   }
 #undef TN_NT
   prof_stop(ctx, pidx);
-  {
-    const int fastn = tr ? m : k, slown = tr ? k : m;
-    dim3 block(128), grid((fastn + 127) / 128, slown < 32768 ? slown : 32768);
-    hipLaunchKernelGGL(k_reduce_partials, grid, block, 0, ctx->stream, part, nsplit, (int64_t)mpad * kpad,
-                       tr ? mpad : kpad, tr ? 1 : 0, m, k, scale, beta, C, rs, cs);
-    HIP_TRY(hipGetLastError());
-  }
-  return HFMI_OK;
+  return launch_reduce_partials(ctx, part, nsplit, (int64_t)mpad * kpad, tr ? mpad : kpad, tr, m, k, scale, beta, C, rs,
+                                cs);
 }
 
 int launch_tsgemm_tn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
                      int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req) {
   if (m <= 0 || k <= 0 || N <= 0) return HFMI_OK;
+  if (g_ss && tsgemm_ss_applicable(m, k, A == B && lda == ldb && m == k))
+    return launch_tsgemm_ss(ctx, A, lda, m, B, ldb, k, N, scale, beta, C, rs, cs, nsplit_req);
   for (int k0 = 0; k0 < k; k0 += 256) {
     const int kp = (k - k0 < 256) ? (k - k0) : 256;
     HFMI_TRY(tn_panel(ctx, A, lda, m, B + (int64_t)k0 * ldb, ldb, kp, N, scale, beta, C + (int64_t)k0 * cs, rs, cs,

@@ -122,6 +122,14 @@ struct hfmi_op {
 // the final write coalesced when rs == 1.
 int launch_tsgemm_tn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
                      int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req);
+// skinny x skinny variant (hfmi_skinny.hip): both operands staged through LDS, m, k <= 160 and m + k <= 288 columns
+bool tsgemm_ss_applicable(int m, int k, bool same);
+void tsgemm_ss_set_percu(int v);
+int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
+                     int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req);
+// C[i*rs + j*cs] = scale * sum_sp part[sp][..] + beta * C, fixed summation order
+int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_t pstride, int inner_ld, bool tr, int m,
+                           int k, double scale, double beta, double* C, int64_t rs, int64_t cs);
 // Y (N x r) = alpha * A (N x m) * S (m x r, device row-major, ld = lds, zero padded to 16 cols) + beta * Y
 int launch_tsgemm_nn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds, int r,
                      double alpha, double beta, double* Y, int64_t ldy, int64_t N);

@@ -90,7 +90,10 @@ def test_parRandom_is_reproducible_across_contexts(ctx):
 
 # ------------------------------------------------------------------ tall-skinny contractions
 TN_SHAPES = [(1, 1, 1), (3, 2, 7), (9, 13, 100), (16, 16, 32), (17, 33, 1000), (30, 30, 4225), (138, 138, 4225),
-             (256, 30, 4225), (64, 74, 20011), (300, 260, 1000), (500, 84, 3000), (2048, 138, 20000), (700, 5, 50000)]
+             (256, 30, 4225), (64, 74, 20011), (300, 260, 1000), (500, 84, 3000), (2048, 138, 20000), (700, 5, 50000),
+             # both operands skinny (tsgemm_ss): every tiles-per-wave class, ragged tiles, more slices than stages
+             (8, 138, 70001), (138, 8, 70001), (160, 128, 5000), (144, 144, 33), (150, 130, 9999), (97, 160, 64),
+             (33, 17, 300000), (160, 1, 2049), (112, 110, 12345)]
 
 
 @pytest.mark.parametrize("m,k,N", TN_SHAPES)
@@ -103,6 +106,21 @@ def test_block_dot_matches_numpy(ctx, m, k, N):
     ref = A.T @ B
     scale = np.linalg.norm(A, axis=0)[:, None] * np.linalg.norm(B, axis=0)[None, :]
     assert np.max(np.abs(got - ref) / scale) < 1e-13
+
+
+@pytest.mark.parametrize("k,N", [(5, 1000), (74, 30011), (138, 50000), (160, 4225)])
+def test_block_gram_same_operand(ctx, k, N):
+    """Q^T Q with both arguments the SAME block (staged once through LDS) equals the two-operand product."""
+    rng = np.random.default_rng(k)
+    Q = rng.standard_normal((N, k)) * np.logspace(0, -2, k)[None, :]
+    mv = hf.MultiVector.from_dense(Q)
+    got = mv.dot_mv(mv)
+    ref = Q.T @ Q
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert np.max(np.abs(got - ref) / scale) < 1e-13
+    np.testing.assert_array_equal(got, got.T)     # same summation order for (i,j) and (j,i)
+    other = hf.MultiVector.from_dense(Q)
+    assert np.max(np.abs(mv.dot_mv(other) - got) / scale) < 1e-13
 
 
 def test_block_dot_is_deterministic(ctx):
