@@ -2,9 +2,10 @@
 // ONE workgroup with the matrix resident in LDS (k <= 140: k*(k+1)*8 bytes <= 160 KB), fp64 throughout.
 //
 //   k_chol_inv   : G = R^T R (upper), optional diagonal shift on breakdown, R^{-1}, running R product
-//   k_jacobi_eig : parallel cyclic Jacobi (round-robin ordering, one 2x2-block rotation phase per round),
-//                  rotations are logged and replayed on the identity by k_jacobi_vectors (one workgroup
-//                  per eigenvector-matrix row) so the eigenvector update never sits on the critical path.
+//   k_jacobi_eig : parallel cyclic Jacobi (round-robin ordering with the matrix kept in seat order, one 2x2-block
+//                  rotation phase per round), rotations are logged and replayed on the identity by
+//                  k_jacobi_vectors (one workgroup per eigenvector-matrix row) so the eigenvector update never
+//                  sits on the critical path.
 #include "hfmi_internal.h"
 
 #include <stdlib.h>
@@ -51,8 +52,8 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
 // One workgroup; everything here is issue/latency bound on a single CU (fp64 VALU is quarter rate: a dependent
 // v_fma_f64 costs 32 cycles with 4 waves per SIMD; a software fp64 divide ~300), so the structure avoids
 // redundant scalar fp64 math (v_rsq_f64 + Newton instead of sqrt and divide on every thread), maps triangular
-// index sets onto ALL lanes (folded triangle, reciprocal-multiply index split) and computes the inverse with
-// no workgroup barriers at all.
+// index sets onto ALL lanes (folded triangle, reciprocal-multiply index split) and spends ONE barrier per column
+// of the factorisation and one per row of the inverse.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double fast_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);      // ~2^-26 relative
@@ -83,6 +84,11 @@ __device__ __forceinline__ bool tri_cell(int e, int n, float inv_np1, int& row, 
   return r2 != r;
 }
 
+// EPT > 0: the upper triangle is distributed over the threads (EPT entries each, fixed for the whole kernel) and
+// lives in REGISTERS; a column step of the factorisation / row step of the inverse publishes one row through LDS,
+// takes one barrier and updates the owned entries with two LDS reads and two flops each -- no per-entry index
+// arithmetic.  EPT = 0: generic path for k > 139 (matrix in a global scratch slot).
+template <int EPT>
 __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __restrict__ G, int ldg, int k,
                                                             double* __restrict__ Rout, double* __restrict__ Rinv,
                                                             double* __restrict__ Rtot, double* __restrict__ Rtmp,
@@ -95,9 +101,20 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
   double* diag0 = red + 32;                            // k original diagonal entries
   double* invd = diag0 + 256;                          // 1 / R_jj
-  double* lds_m = invd + 256;
-  const int ldm = use_lds ? (k | 1) : ldo;
-  double* M = use_lds ? lds_m : gscratch;
+  double* ird0 = invd + 256;                           // 1 / (original diagonal + shift): pivot-ratio bookkeeping
+  double* lds_m = ird0 + 256;
+  // NOTE: a pointer that may be LDS or global (a runtime select) compiles to FLAT loads/stores, which are several
+  // times slower than ds_read/ds_write and tie vmcnt to lgkmcnt; the register path therefore only exists for the
+  // LDS-resident matrix and names the LDS pointer directly.
+  int ldm;
+  double* M;
+  if constexpr (EPT > 0) {
+    ldm = k | 1;
+    M = lds_m;
+  } else {
+    ldm = use_lds ? (k | 1) : ldo;
+    M = use_lds ? lds_m : gscratch;
+  }
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   __shared__ int s_break;
@@ -123,10 +140,94 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   tr = block_sum(tr, red);
   tk1 = clock64();
 
+  // owned entries (row oi <= col oc) of the register path.  The upper triangle is enumerated bottom row first
+  // (row k-1: 1 cell, row k-2: 2 cells, ...) and cell e belongs to thread e % nthr, slot q = e / nthr: slot q of
+  // ALL threads is one band of adjacent rows [bmin[q], bmax[q]], so a band that is finished (factorisation: rows
+  // <= j) or not yet started (inverse: rows >= l) is skipped by a wave-uniform branch, and the work of a step is
+  // spread evenly over the waves.
+  constexpr int NE = EPT > 0 ? EPT : 1;
+  int oi[NE], oc[NE], li[NE], bmin[NE], bmax[NE];   // li: row index clamped into the matrix (loads of idle slots)
+  double v[NE];
+  if constexpr (EPT > 0) {
+    const int total = k * (k + 1) / 2;
+    auto cell_row = [&](int e) {  // rows counted from the bottom: m (m + 1) / 2 <= e < (m + 1) (m + 2) / 2
+      int m = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (m * (m + 1) / 2 > e) --m;
+      while ((m + 1) * (m + 2) / 2 <= e) ++m;
+      return m;
+    };
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * nthr;
+      const bool ok = e < total;
+      const int m = cell_row(ok ? e : 0);
+      oi[q] = ok ? k - 1 - m : (1 << 20);   // idle slot: a row index no step ever matches
+      oc[q] = ok ? (k - 1 - m) + (e - m * (m + 1) / 2) : 0;
+      li[q] = ok ? k - 1 - m : 0;
+      v[q] = 0.0;
+      const int e_first = q * nthr, e_last = (q + 1) * nthr - 1 < total - 1 ? (q + 1) * nthr - 1 : total - 1;
+      bmax[q] = e_first < total ? k - 1 - cell_row(e_first) : -1;
+      bmin[q] = e_first < total ? k - 1 - cell_row(e_last) : 0;
+    }
+  }
+
   int shifted = 0, failed = 0;
   double min_ratio = 1e300;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const double shift = attempt ? shift_rel * tr : 0.0;
+    if constexpr (EPT > 0) {
+      if (tid == 0) s_break = 0;
+      for (int i = tid; i < k; i += nthr) ird0[i] = (diag0[i] + shift > 0.0) ? 1.0 / (diag0[i] + shift) : 0.0;
+#pragma unroll
+      for (int q = 0; q < NE; ++q)
+        if (oi[q] < k) {
+          v[q] = 0.5 * (G[oi[q] * ldg + oc[q]] + G[oc[q] * ldg + oi[q]]);
+          if (oi[q] == oc[q]) v[q] += shift;
+        }
+      double ratio_local = 1e300;
+      // Unscaled (LDL^T-style) right-looking factorisation: U[i][c] = G[i][c] - sum_{j<i} U[j][i] U[j][c] / U[j][j];
+      // R = diag(U)^{-1/2} U is formed by one scaling pass at the end.
+      for (int j = 0; j < k; ++j) {
+#pragma unroll
+        for (int q = 0; q < NE; ++q)
+          if (bmin[q] <= j && j <= bmax[q] && oi[q] == j) M[j * ldm + oc[q]] = v[q];   // row j is final: publish it
+        __syncthreads();
+        const double piv = M[j * ldm + j];
+        const double ref = diag0[j] + shift;
+        if (!(piv > pivot_tol * ref) || !(ref > 0.0)) {  // uniform decision: every thread reads the same words
+          if (tid == 0) s_break = 1;
+          break;
+        }
+        const double inv = fast_rsqrt(piv);
+        const double rp = inv * inv;
+        if (tid == 0) {
+          ratio_local = fmin(ratio_local, piv * ird0[j]);
+          invd[j] = inv;
+        }
+        const double* rj = M + j * ldm;
+        // branch-free per entry (a select on the scale factor) with all LDS reads issued before the first use:
+        // per-entry branches would serialise NE load -> fma chains; the band test is wave-uniform
+        double xa[NE], xb[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q)
+          if (bmax[q] > j) {
+            xa[q] = rj[li[q]];
+            xb[q] = rj[oc[q]];
+          }
+#pragma unroll
+        for (int q = 0; q < NE; ++q)
+          if (bmax[q] > j) v[q] -= xa[q] * ((oi[q] > j && oi[q] < k) ? rp : 0.0) * xb[q];
+      }
+      __syncthreads();
+      if (!s_break) {
+        min_ratio = ratio_local;
+        break;
+      }
+      if (attempt == 0) shifted = 1;
+      else failed = 1;
+      __syncthreads();
+      continue;
+    }
     for (int i = wave; i < k; i += nw)
       for (int j = lane; j < k; j += 64) {
         double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
@@ -134,8 +235,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
         M[i * ldm + j] = (j >= i) ? g : 0.0;
       }
     if (tid == 0) s_break = 0;
+    for (int i = tid; i < k; i += nthr) ird0[i] = (diag0[i] + shift > 0.0) ? 1.0 / (diag0[i] + shift) : 0.0;
     __syncthreads();
     double ratio_local = 1e300;
+    // Unscaled (LDL^T-style) right-looking factorisation: U[i][c] = G[i][c] - sum_{j<i} U[j][i] U[j][c] / U[j][j].
+    // Row j is never rewritten once it is the pivot row, so a column step is ONE barrier phase: every thread reads
+    // the pivot, forms 1 / U[j][j] itself (v_rsq_f64 + Newton, squared) and updates its share of the trailing
+    // triangle.  R = diag(U)^{-1/2} U is formed by one scaling pass at the end.
     for (int j = 0; j < k; ++j) {
       const double piv = M[j * ldm + j];
       const double ref = diag0[j] + shift;
@@ -143,14 +249,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
         if (tid == 0) s_break = 1;
         break;
       }
-      if (tid == 0) ratio_local = fmin(ratio_local, piv / ref);
       const double inv = fast_rsqrt(piv);
-      const double rjj = piv * inv;
-      __syncthreads();
-      for (int c = j + tid; c < k; c += nthr) M[j * ldm + c] = (c == j) ? rjj : M[j * ldm + c] * inv;
-      if (tid == 0) invd[j] = inv;
-      __syncthreads();
-      // trailing update of the upper triangle: M[i][c] -= R[j][i] R[j][c], j < i <= c  (folded onto all lanes)
+      const double rp = inv * inv;
+      if (tid == 0) {
+        ratio_local = fmin(ratio_local, piv * ird0[j]);
+        invd[j] = inv;
+      }
+      // trailing update of the upper triangle: M[i][c] -= U[j][i] U[j][c] / U[j][j], j < i <= c (folded onto all lanes)
       const int n = k - j - 1;
       if (n > 0) {
         const float inv_np1 = __frcp_rn((float)(n + 1));
@@ -158,7 +263,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
         const double* rj = M + j * ldm + j + 1;
         for (int e = tid; e < cells; e += nthr) {
           int a, b;
-          if (tri_cell(e, n, inv_np1, a, b)) M[(j + 1 + a) * ldm + j + 1 + b] -= rj[a] * rj[b];
+          if (tri_cell(e, n, inv_np1, a, b)) M[(j + 1 + a) * ldm + j + 1 + b] -= rj[a] * rp * rj[b];
         }
       }
       __syncthreads();
@@ -181,39 +286,80 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
     }
     return;
   }
+  // R = diag(U)^{-1/2} U
+  for (int i = wave; i < k; i += nw) {
+    const double sc = invd[i];
+    for (int j = i + lane; j < k; j += 64) M[i * ldm + j] *= sc;
+  }
+  __syncthreads();
   tk2 = clock64();
   // R out (upper triangle, zeros below)
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
-  // Inverse X = R^-1 by back substitution, one column per 16-lane group, NO workgroup barriers: column c is
-  // x_c = 1/R_cc, x_i = -(sum_{l=i+1..c} R[i][l] x_l) / R_ii for i < c.  x is written into the (unused)
-  // strictly lower triangle, X[i][c] -> M[c][i], so columns never collide with R or with each other.
-  {
-    const int grp = lane >> 4, gl = lane & 15;
-    for (int c0 = 4 * wave; c0 < k; c0 += 4 * nw) {
-      const int c = c0 + grp;
-      const bool live = c < k;
-      const double xc = live ? invd[c] : 0.0;
-      const int cmax = (c0 + 3 < k) ? c0 + 3 : k - 1;
-      for (int i = cmax - 1; i >= 0; --i) {
-        double sacc = 0.0;
-        if (live && i < c) {
-          const double* ri = M + i * ldm;
-          const double* xr = M + c * ldm;
-          for (int l = i + 1 + gl; l <= c; l += 16) sacc += ri[l] * (l == c ? xc : xr[l]);
+  if constexpr (EPT > 0) {
+    // Inverse X = R^-1, right-looking and bottom-up: once row l of X is final it is published (two alternating LDS
+    // rows, aliasing the dead diag0 / ird0 arrays) and every owned entry (i, c), i < l <= c, accumulates
+    // R[i][l] x_lc; x_ic = -acc / R_ii, x_ii = 1 / R_ii.  One barrier per row; the inverse never touches LDS
+    // except for the published row and the R entries it multiplies.
+    double* xrow0 = diag0;
+    double* xrow1 = ird0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) v[q] = 0.0;
+    for (int l = k - 1; l >= 0; --l) {
+      double* xr = (l & 1) ? xrow1 : xrow0;
+#pragma unroll
+      for (int q = 0; q < NE; ++q)
+        if (bmin[q] <= l && l <= bmax[q] && oi[q] == l) {
+          const double x = (oc[q] == l) ? invd[l] : -invd[l] * v[q];
+          v[q] = x;
+          xr[oc[q]] = x;
         }
-        sacc += __shfl_xor(sacc, 8, 64);
+      __syncthreads();
+      double xa[NE], xb[NE];
+#pragma unroll
+      for (int q = 0; q < NE; ++q)
+        if (bmin[q] < l) {  // wave-uniform: bands made of rows >= l have nothing to accumulate yet
+          xa[q] = M[li[q] * ldm + l];
+          xb[q] = xr[oc[q]];
+        }
+#pragma unroll
+      for (int q = 0; q < NE; ++q)
+        if (bmin[q] < l) v[q] += ((oi[q] < l && oc[q] >= l) ? xa[q] : 0.0) * xb[q];
+    }
+    tk3 = clock64();
+#pragma unroll
+    for (int q = 0; q < NE; ++q)
+      if (oi[q] < k) Rinv[oi[q] * ldo + oc[q]] = v[q];
+    for (int i = wave; i < k; i += nw)
+      for (int j = lane; j < i; j += 64) Rinv[i * ldo + j] = 0.0;
+  } else {
+  // Inverse X = R^-1 by back substitution, one ROW per barrier phase (bottom up): x_cc = 1/R_cc and, for i < c,
+  // x_ic = -(sum_{l=i+1..c} R[i][l] x_lc) / R_ii.  All columns c > i of row i are independent: one 8-lane group per
+  // column, both factors of the dot product contiguous along l (x is kept in the unused strictly lower triangle,
+  // X[i][c] -> M[c][i]).
+  {
+    const int g8 = tid & 7, grp8 = tid >> 3, ngrp8 = nthr >> 3;
+    for (int i = k - 2; i >= 0; --i) {
+      const double* ri = M + i * ldm;
+      const double mi = -invd[i];
+      for (int c = i + 1 + grp8; c < k; c += ngrp8) {
+        const double* xr = M + c * ldm;
+        const double xc = invd[c];
+        double sacc = 0.0;
+        for (int l = i + 1 + g8; l <= c; l += 8) sacc += ri[l] * (l == c ? xc : xr[l]);
         sacc += __shfl_xor(sacc, 4, 64);
         sacc += __shfl_xor(sacc, 2, 64);
         sacc += __shfl_xor(sacc, 1, 64);
-        if (live && i < c && gl == 0) M[c * ldm + i] = -sacc * invd[i];
+        if (g8 == 0) M[c * ldm + i] = sacc * mi;
       }
+      __syncthreads();
     }
   }
   __syncthreads();
   tk3 = clock64();
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) Rinv[i * ldo + j] = (j > i) ? M[j * ldm + i] : (j == i ? invd[i] : 0.0);
+  }
   // diagonal of the running product R = R_p ... R_1 (its ratio to the original column norms exposes
   // numerically dependent columns); the full product only when the caller wants R
   for (int i = tid; i < k; i += nthr) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * M[i * ldm + i];
@@ -245,20 +391,35 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
     status->tick[2] = tk3 - tk2;  // inverse
     status->tick[3] = tk4 - tk3;  // outputs + R product
     status->tick[4] = 0;
+
   }
 }
 
 int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
                     int full_r, double shift_rel, double pivot_tol) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "chol_inv: k=%d out of range", k);
-  const int use_lds = (k <= 139) ? 1 : 0;   // (32 + 256 + 256) * 8 + 139 * 139 * 8 = 158,920 bytes <= 160 KB
-  const size_t shmem = (32 + 256 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  const int use_lds = (k <= 139) ? 1 : 0;   // (32 + 3 * 256) * 8 + 139 * 139 * 8 = 160,968 bytes <= 160 KB (163,840)
+  const size_t shmem = (32 + 3 * 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
-  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
-                     sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
-                     rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX),
-                     sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);
+  const int threads = small_threads();
+  const int ept = use_lds ? (k * (k + 1) / 2 + threads - 1) / threads : 0;   // upper-triangle entries per thread
+#define CHOL_LAUNCH(E)                                                                                                 \
+  do {                                                                                                                 \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
+    hipLaunchKernelGGL(k_chol_inv<E>, dim3(1), dim3(threads), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,    \
+                       sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2),      \
+                       SM_LD, rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds,                   \
+                       sm_ptr(ctx, SM_AUX), sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);                             \
+  } while (0)
+  if (ept == 0 || ept > 10) CHOL_LAUNCH(0);
+  else if (ept <= 1) CHOL_LAUNCH(1);
+  else if (ept <= 2) CHOL_LAUNCH(2);
+  else if (ept <= 3) CHOL_LAUNCH(3);
+  else if (ept <= 4) CHOL_LAUNCH(4);
+  else if (ept <= 6) CHOL_LAUNCH(6);
+  else if (ept <= 8) CHOL_LAUNCH(8);
+  else CHOL_LAUNCH(10);
+#undef CHOL_LAUNCH
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
@@ -276,24 +437,48 @@ int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot) {
 // ------------------------------------------------------------------------------------------------
 // Jacobi eigensolver
 // ------------------------------------------------------------------------------------------------
-// round-robin tournament on n (even) players: round r in [0, n-1), pair p in [0, n/2)
-__device__ __forceinline__ void rr_pair(int n, int r, int p, int& a, int& b) {
-  if (p == 0) {
-    a = n - 1;
-    b = r;
-  } else {
-    a = (r + p) % (n - 1);
-    b = (r - p + (n - 1)) % (n - 1);
-  }
-  if (a > b) {
-    const int t = a;
-    a = b;
-    b = t;
-  }
+// Round-robin tournament on n = 2 np players kept in SLOT order: the players of pair P always sit in the adjacent
+// slots (2P, 2P+1) and the matrix is stored in slot order, S[s][t] = A[player(s)][player(t)].  After a round every
+// player but the one in slot 0 moves one seat along the ring  1 -> 2 -> 4 -> ... -> n-2 -> n-1 -> n-3 -> ... -> 3 -> 1
+// (Brent-Luk): n - 1 rounds meet every pair once and bring every player back to its own slot, so after whole
+// sweeps slot order == player order.  The rotated 2x2 blocks are WRITTEN to their next-round seats, which makes
+// every read of the update phase a fixed, aligned 16-byte pair (no index tables, no bank-conflict lottery).
+__device__ __forceinline__ int jac_next_slot(int s, int n) {
+  if (s == 0 || n == 2) return s;
+  if (s & 1) return s == 1 ? 2 : s - 2;  // bottom row walks left; seat 1 climbs to the top row
+  return s == n - 2 ? n - 1 : s + 2;     // top row walks right; the last seat drops to the bottom row
 }
 
 #define JAC_MAX_SWEEPS 40
 
+// Rotation (c, s) that annihilates the pivot of [[app, apq], [apq, aqq]]:  t = tan(phi) = sign(theta) /
+// (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written with two reciprocal square roots instead of
+// two divisions and two square roots (the dependent chain of this phase is pure latency on one CU):
+// h = hypot(d, 2 apq), cos(2 phi) = |d| / h, c^2 = (1 + |d|/h) / 2, s = sign(d) apq / (h c).
+__device__ __forceinline__ void jac_rotation(double app, double apq, double aqq, double& c, double& s) {
+  c = 1.0;
+  s = 0.0;
+  const double g = 100.0 * fabs(apq);
+  if (apq == 0.0 || (fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq))) return;
+  const double d = aqq - app;
+  const double h2 = d * d + 4.0 * apq * apq;
+  if (!(h2 > 1e-300) || !(h2 < 1e300)) {  // out of the safe range of the squared form: the classical formula
+    const double theta = 0.5 * d / apq;
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    c = rsqrt(t * t + 1.0);
+    s = t * c;
+    return;
+  }
+  const double rh = fast_rsqrt(h2);
+  const double c2 = 0.5 + 0.5 * fabs(d) * rh;
+  const double rc = fast_rsqrt(c2);
+  c = c2 * rc;
+  s = (d >= 0.0 ? apq : -apq) * rh * rc;
+}
+
+// NB = 2x2 blocks per thread in the update phase (ceil(cells / threads)); the block coordinates of a thread never
+// change, so all its addresses are computed once.
+template <int NB, bool LDS>
 __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __restrict__ T, int ldt, int k,
                                                               double* __restrict__ gwork, int use_lds,
                                                               double2* __restrict__ rotlog, double* __restrict__ dvals,
@@ -303,22 +488,29 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   double* red = reinterpret_cast<double*>(smem);                // 32
   double2* rot = reinterpret_cast<double2*>(red + 32);          // 128 (c, s) per pair
   double* Ad = reinterpret_cast<double*>(rot + 128);            // 256 diagonal copy / keys
-  short* pa = reinterpret_cast<short*>(Ad + 256);               // 128 + 128 pair members of the current round
-  short* pb = pa + 128;
-  double* lds_a = reinterpret_cast<double*>(pb + 128);
-  const int lda = use_lds ? (k | 1) : SM_LD;
-  double* A = use_lds ? lds_a : gwork;
+  double* lds_a = Ad + 256;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-  const int n = (k + 1) & ~1;  // players (one dummy if k is odd)
+  const int n = (k + 1) & ~1;  // players (one dummy if k is odd: a zero row/column that is never rotated)
   const int np = n / 2;
+  // even leading dimension: the (2P, 2P+1) column pairs are 16-byte aligned.  LDS is a template parameter so that
+  // the matrix pointer has ONE address space (a runtime LDS/global select would compile to FLAT accesses).
+  int lda;
+  double* A;
+  if constexpr (LDS) {
+    lda = n;
+    A = lds_a;
+  } else {
+    lda = SM_LD;
+    A = gwork;
+  }
   const float inv_np1 = __frcp_rn((float)(np + 1));
   const int cells = ((np + 1) >> 1) * (np + 1);
 
   double fro = 0.0;
-  for (int i = wave; i < k; i += nw)
-    for (int j = lane; j < k; j += 64) {
-      const double v = 0.5 * (T[i * ldt + j] + T[j * ldt + i]);
+  for (int i = wave; i < n; i += nw)
+    for (int j = lane; j < n; j += 64) {
+      const double v = (i < k && j < k) ? 0.5 * (T[i * ldt + j] + T[j * ldt + i]) : 0.0;
       A[i * lda + j] = v;
       fro += v * v;
     }
@@ -326,93 +518,102 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   __syncthreads();
   const double tol2 = EPS_D * EPS_D * fro;
 
+  // this thread's blocks {P <= Q}: read offset of the block's first row and the next-round seat of each of its four
+  // entries.  Only the block-upper triangle (pair(row) <= pair(col)) is stored and read: an entry whose new seat
+  // falls below it is written transposed, so every entry costs ONE LDS store.
+  int rd[NB], P_[NB], Q_[NB], d11[NB], d12[NB], d21[NB], d22[NB];
+  bool live[NB];
+  auto seat = [&](int r, int c) {
+    const bool upper = (r >> 1) != (c >> 1) ? (r >> 1) < (c >> 1) : r <= c;
+    return upper ? r * lda + c : c * lda + r;
+  };
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) {
+    const int e = tid + bi * nthr;
+    int P = 0, Q = 0;
+    live[bi] = e < cells && tri_cell(e, np, inv_np1, P, Q);
+    P_[bi] = P;
+    Q_[bi] = Q;
+    rd[bi] = 2 * P * lda + 2 * Q;
+    const int r1 = jac_next_slot(2 * P, n), r2 = jac_next_slot(2 * P + 1, n);
+    const int c1 = jac_next_slot(2 * Q, n), c2 = jac_next_slot(2 * Q + 1, n);
+    d11[bi] = seat(r1, c1);
+    d12[bi] = seat(r1, c2);
+    d21[bi] = seat(r2, c1);
+    d22[bi] = seat(r2, c2);
+  }
+
   long long tj0 = clock64(), tp1 = 0, tp2 = 0;
   int sweeps = 0;
   double off2 = 0.0;
   for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
     off2 = 0.0;
-    for (int i = wave; i < k; i += nw)
-      for (int j = i + 1 + lane; j < k; j += 64) off2 += 2.0 * A[i * lda + j] * A[i * lda + j];
+    for (int i = wave; i < n; i += nw)
+      for (int j = i + 1 + lane; j < n; j += 64) off2 += 2.0 * A[i * lda + j] * A[i * lda + j];
     off2 = block_sum(off2, red);
     __syncthreads();
     if (off2 <= tol2) break;
     for (int r = 0; r < n - 1; ++r) {
-      // phase 1: the round's pairs (kept in LDS: no modulo arithmetic in the update phase) and one
-      // rotation per pair
+      // phase 1: one rotation per pair from the diagonal block in seats (2P, 2P+1)
       const long long ta = clock64();
+      int any = 0;
       if (tid < np) {
-        int a, b;
-        rr_pair(n, r, tid, a, b);
-        pa[tid] = (short)a;
-        pb[tid] = (short)b;
-        double c = 1.0, s = 0.0;
-        if (b < k) {
-          const double apq = A[a * lda + b];
-          const double app = A[a * lda + a], aqq = A[b * lda + b];
-          const double g = 100.0 * fabs(apq);
-          if (apq != 0.0 && !(fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq))) {
-            const double theta = 0.5 * (aqq - app) / apq;
-            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = rsqrt(t * t + 1.0);
-            s = t * c;
-          }
-        }
-        rot[tid] = make_double2(c, s);
-        rotlog[((size_t)sweeps * (n - 1) + r) * np + tid] = make_double2(c, s);
+        const double2 top = *reinterpret_cast<const double2*>(A + 2 * tid * lda + 2 * tid);
+        const double aqq = A[(2 * tid + 1) * lda + 2 * tid + 1];
+        double c, sn;
+        jac_rotation(top.x, top.y, aqq, c, sn);
+        rot[tid] = make_double2(c, sn);
+        rotlog[((size_t)sweeps * (n - 1) + r) * np + tid] = make_double2(c, sn);
+        any = sn != 0.0;
       }
-      __syncthreads();
+      any = __syncthreads_or(any);
       const long long tb = clock64();
       tp1 += tb - ta;
-      // phase 2: every 2x2 block {P, Q}, P <= Q, <- J_P^T * block * J_Q, mirrored into the lower triangle (full
-      // symmetric storage: no min/max index logic).  The np (np + 1) / 2 blocks are laid onto ALL lanes through the
-      // folded-triangle map -- this phase is fp64-VALU-issue bound, so idle lanes are the main cost.
-      for (int e = tid; e < cells; e += nthr) {
-        int P, Q;
-        if (!tri_cell(e, np, inv_np1, P, Q)) continue;
-        const int p1 = pa[P], q1 = pb[P], p2 = pa[Q], q2 = pb[Q];
-        const int p1r = __mul24(p1, lda), q1r = __mul24(q1, lda), p2r = __mul24(p2, lda), q2r = __mul24(q2, lda);
-        // a dummy player (k odd) has index >= k: its entries read as 0 and are never written; the rotation of
-        // its pair is the identity, so the real member still receives the other pairs' rotations
-        const bool r2 = q1 < k, c2 = q2 < k;
-        const double2 rp = rot[P], rq = rot[Q];
-        const double x11 = A[p1r + p2];
-        const double x12 = c2 ? A[p1r + q2] : 0.0;
-        const double x21 = r2 ? A[q1r + p2] : 0.0;
-        const double x22 = (r2 && c2) ? A[q1r + q2] : 0.0;
-        // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
-        const double y11 = rq.x * x11 - rq.y * x12, y12 = rq.y * x11 + rq.x * x12;
-        const double y21 = rq.x * x21 - rq.y * x22, y22 = rq.y * x21 + rq.x * x22;
-        // rows with J_P
-        const double z11 = rp.x * y11 - rp.y * y21, z21 = rp.y * y11 + rp.x * y21;
-        const double z12 = rp.x * y12 - rp.y * y22, z22 = rp.y * y12 + rp.x * y22;
-        if (P == Q) {
-          A[p1r + p1] = z11;
-          if (r2) {
-            A[q1r + q1] = z22;
-            A[p1r + q1] = 0.0;        // the annihilated pivot
-            A[q1r + p1] = 0.0;
-          }
+      // phase 2: every 2x2 block {P, Q}, P <= Q, <- J_P^T * block * J_Q, written to the seats its players take in
+      // the next round (block-upper triangle only).  All reads precede all writes.
+      // A round whose rotations are all the identity still has to move the players.
+      double z11[NB], z12[NB], z21[NB], z22[NB];
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        if (!live[bi]) continue;
+        const double2 x1 = *reinterpret_cast<const double2*>(A + rd[bi]);
+        double2 x2 = *reinterpret_cast<const double2*>(A + rd[bi] + lda);
+        if (P_[bi] == Q_[bi]) x2.x = x1.y;  // below the diagonal of a diagonal block: not stored
+        if (any) {
+          const double2 rp = rot[P_[bi]], rq = rot[Q_[bi]];
+          // columns: (x_ip, x_iq) <- (c x_ip - s x_iq, s x_ip + c x_iq) with J_Q
+          const double y11 = rq.x * x1.x - rq.y * x1.y, y12 = rq.y * x1.x + rq.x * x1.y;
+          const double y21 = rq.x * x2.x - rq.y * x2.y, y22 = rq.y * x2.x + rq.x * x2.y;
+          // rows with J_P
+          z11[bi] = rp.x * y11 - rp.y * y21;
+          z21[bi] = rp.y * y11 + rp.x * y21;
+          z12[bi] = rp.x * y12 - rp.y * y22;
+          z22[bi] = rp.y * y12 + rp.x * y22;
         } else {
-          A[p1r + p2] = z11;
-          A[p2r + p1] = z11;
-          if (c2) {
-            A[p1r + q2] = z12;
-            A[q2r + p1] = z12;
-          }
-          if (r2) {
-            A[q1r + p2] = z21;
-            A[p2r + q1] = z21;
-          }
-          if (r2 && c2) {
-            A[q1r + q2] = z22;
-            A[q2r + q1] = z22;
-          }
+          z11[bi] = x1.x;
+          z12[bi] = x1.y;
+          z21[bi] = x2.x;
+          z22[bi] = x2.y;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        if (!live[bi]) continue;
+        A[d11[bi]] = z11[bi];
+        A[d22[bi]] = z22[bi];
+        if (P_[bi] == Q_[bi]) {
+          A[d12[bi]] = any ? 0.0 : z12[bi];  // the annihilated pivot (d12 == d21 here)
+        } else {
+          A[d12[bi]] = z12[bi];
+          A[d21[bi]] = z21[bi];
         }
       }
       __syncthreads();
       tp2 += clock64() - tb;
     }
   }
+  // whole sweeps bring every player back to its own slot: slot order == index order here.
   // eigenvalues, sort descending (rank by counting; ties broken by index -> a permutation)
   for (int i = tid; i < k; i += nthr) Ad[i] = A[i * lda + i];
   __syncthreads();
@@ -438,44 +639,31 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   }
 }
 
-// Row i of V = e_i^T * (product of all logged rotations); one workgroup per row, the row lives in LDS.
-// The pair (a, b) of lane p in round r is ((r + p) mod (n-1), (r - p) mod (n-1)) -- advanced by +1 per round
-// with a wrap test instead of a modulo; lane 0 pairs the fixed player n-1 with r.
+// Row i of V = e_i^T * (product of all logged rotations); one workgroup per row.  The row is kept in slot order
+// in two LDS buffers: lane P rotates the adjacent pair (2P, 2P+1) of the current buffer and writes it to the
+// players' next seats in the other one -- one barrier per round, no index arithmetic.
 __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restrict__ rotlog, int k,
                                                         const hfmi_status_words* __restrict__ status,
                                                         const int* __restrict__ perm, double* __restrict__ V, int ldv) {
-  __shared__ double row[SM_MAXK + 2];
+  __shared__ __attribute__((aligned(16))) double row[2][SM_MAXK + 2];
   const int n = (k + 1) & ~1, np = n / 2;
   const int i = blockIdx.x, tid = threadIdx.x;
-  for (int j = tid; j < n; j += blockDim.x) row[j] = (j == i) ? 1.0 : 0.0;
+  for (int j = tid; j < n; j += blockDim.x) row[0][j] = (j == i) ? 1.0 : 0.0;
   __syncthreads();
   const int rounds = status->sweeps * (n - 1);
-  int a = 0, b = 0;
-  if (tid < np) rr_pair(n, 0, tid, a, b);
-  int ua = (tid == 0) ? 0 : tid % (n - 1);                      // un-ordered members for the increment
-  int ub = (tid == 0) ? 0 : (n - 1 - tid) % (n - 1);
-  int r = 0;
+  const int s1 = jac_next_slot(2 * tid, n), s2 = jac_next_slot(2 * tid + 1, n);
+  int cur = 0;
   for (int rr = 0; rr < rounds; ++rr) {
     if (tid < np) {
       const double2 cs = rotlog[(size_t)rr * np + tid];
-      const double va = row[a], vb = row[b];
-      row[a] = cs.x * va - cs.y * vb;
-      row[b] = cs.y * va + cs.x * vb;
-      // next round's pair
-      r = (r + 1 == n - 1) ? 0 : r + 1;
-      if (tid == 0) {
-        a = r;
-        b = n - 1;
-      } else {
-        ua = (ua + 1 == n - 1) ? 0 : ua + 1;
-        ub = (ub + 1 == n - 1) ? 0 : ub + 1;
-        a = ua < ub ? ua : ub;
-        b = ua < ub ? ub : ua;
-      }
+      const double2 v = *reinterpret_cast<const double2*>(&row[cur][2 * tid]);
+      row[cur ^ 1][s1] = cs.x * v.x - cs.y * v.y;
+      row[cur ^ 1][s2] = cs.y * v.x + cs.x * v.y;
     }
     __syncthreads();
+    cur ^= 1;
   }
-  for (int c = tid; c < k; c += blockDim.x) V[i * ldv + c] = row[perm[c]];
+  for (int c = tid; c < k; c += blockDim.x) V[i * ldv + c] = row[cur][perm[c]];
   for (int c = k + tid; c < ((k + 15) & ~15); c += blockDim.x) V[i * ldv + c] = 0.0;
 }
 
@@ -486,6 +674,7 @@ __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restric
 // eig(R^T R)).  Used by accuracyEnhancedSVD (hippylib randomizedSVD; activeSubspaceProjector.py:813-834,1026).
 // One 16-lane group per column pair, one workgroup barrier per round.
 // ------------------------------------------------------------------------------------------------
+template <bool LDS>
 __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_svd(const double* __restrict__ R, int ldr, int k,
                                                               double* __restrict__ gwork, int use_lds,
                                                               double2* __restrict__ rotlog, double* __restrict__ svals,
@@ -494,26 +683,36 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_svd(const double* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);   // 32
   double* sig = red + 32;                          // 256
-  double* lds_w = sig + 256;
-  const int ldw = use_lds ? (k | 1) : SM_LD;
-  double* W = use_lds ? lds_w : gwork;             // column-major: W[col * ldw + row]
+  short* who = reinterpret_cast<short*>(sig + 256);  // [2][264]: player seated in each slot (jac_next_slot schedule)
+  double* lds_w = sig + 256 + 132;
+  int ldw;
+  double* W;                                       // column-major: W[col * ldw + row]; one address space (see k_chol_inv)
+  if constexpr (LDS) {
+    ldw = k | 1;
+    W = lds_w;
+  } else {
+    ldw = SM_LD;
+    W = gwork;
+  }
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int grp = tid >> 4, gl = tid & 15, ngrp = nthr >> 4;
   const int n = (k + 1) & ~1, np = n / 2;
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) W[j * ldw + i] = R[i * ldr + j];
+  for (int j = tid; j < n; j += nthr) who[j] = (short)j;
   __syncthreads();
-  int sweeps = 0;
+  int sweeps = 0, cur = 0;
   double worst = 0.0;
   for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
     double mx = 0.0;
     for (int r = 0; r < n - 1; ++r) {
+      const short* wc = who + cur * 264;
       for (int P = grp; P < np; P += ngrp) {
-        int a, b;
-        rr_pair(n, r, P, a, b);
+        // the pair seated in slots (2P, 2P+1); same schedule and orientation as k_jacobi_vectors replays
+        const int a = wc[2 * P], b = wc[2 * P + 1];
         double c = 1.0, sn = 0.0;
-        if (b < k) {
+        if (a < k && b < k) {
           double* wa = W + a * ldw;
           double* wb = W + b * ldw;
           double al = 0.0, be = 0.0, ga = 0.0;
@@ -546,6 +745,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_svd(const double* __re
         }
         if (gl == 0) rotlog[((size_t)sweeps * (n - 1) + r) * np + P] = make_double2(c, sn);
       }
+      for (int j = tid; j < n; j += nthr) who[(cur ^ 1) * 264 + jac_next_slot(j, n)] = wc[j];
+      cur ^= 1;
       __syncthreads();
     }
     // convergence: every pair of the sweep was already orthogonal to round-off
@@ -591,17 +792,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_svd(const double* __re
 
 int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, double* svals) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_svd: k=%d out of range", k);
-  const int use_lds = (k <= 140) ? 1 : 0;
+  const int use_lds = (k <= 139) ? 1 : 0;   // 139*139*8 + 3.4 KB of tables <= 160 KB
   const int n = (k + 1) & ~1;
   const size_t log_bytes = (size_t)(JAC_MAX_SWEEPS + 1) * (n - 1) * (n / 2) * sizeof(double2) + 1024 * sizeof(int);
   void* logv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_MISC, log_bytes, &logv));
   double2* rotlog = (double2*)logv;
   int* perm = (int*)((char*)logv + (size_t)(JAC_MAX_SWEEPS + 1) * (n - 1) * (n / 2) * sizeof(double2));
-  const size_t shmem = (32 + 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(k_jacobi_svd, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_r), SM_LD, k,
-                     sm_ptr(ctx, SM_TMP), use_lds, rotlog, svals, perm, sm_ptr(ctx, slot_u), SM_LD, ctx->status_dev);
+  const size_t shmem = (32 + 256 + 132) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
+  if (use_lds) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_jacobi_svd<true>, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_r), SM_LD,
+                       k, sm_ptr(ctx, SM_TMP), use_lds, rotlog, svals, perm, sm_ptr(ctx, slot_u), SM_LD, ctx->status_dev);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_jacobi_svd<false>, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_r), SM_LD,
+                       k, sm_ptr(ctx, SM_TMP), use_lds, rotlog, svals, perm, sm_ptr(ctx, slot_u), SM_LD, ctx->status_dev);
+  }
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
                      sm_ptr(ctx, slot_v), SM_LD);
@@ -611,17 +818,36 @@ int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, 
 
 int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_eig: k=%d out of range", k);
-  const int use_lds = (k <= 138) ? 1 : 0;   // 138*139*8 + 4.9 KB of tables = 158.3 KB <= 160 KB
-  const int n = (k + 1) & ~1;
+  const int n = (k + 1) & ~1, np = n / 2;
+  const int use_lds = (n <= 138) ? 1 : 0;   // 138*138*8 + 6.4 KB of tables = 158.8 KB <= 160 KB
   const size_t log_bytes = (size_t)JAC_MAX_SWEEPS * (n - 1) * (n / 2) * sizeof(double2) + 1024 * sizeof(int);
   void* logv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_MISC, log_bytes, &logv));
   double2* rotlog = (double2*)logv;
   int* perm = (int*)((char*)logv + (size_t)JAC_MAX_SWEEPS * (n - 1) * (n / 2) * sizeof(double2));
-  const size_t shmem = (32 + 256 + 256 + 64) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_t), SM_LD, k,
-                     sm_ptr(ctx, SM_TMP), use_lds, rotlog, dvals, perm, sort_by_abs, ctx->status_dev);
+  const size_t shmem = (32 + 256 + 256) * sizeof(double) + (use_lds ? (size_t)n * n * sizeof(double) : 0);
+  const int threads = small_threads();
+  const int cells = ((np + 1) >> 1) * (np + 1);
+  const int nb = (cells + threads - 1) / threads;
+#define JAC_LAUNCH2(NBV, LDSV)                                                                                       \
+  do {                                                                                                               \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_eig<NBV, LDSV>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)shmem));                                                                        \
+    hipLaunchKernelGGL((k_jacobi_eig<NBV, LDSV>), dim3(1), dim3(threads), shmem, ctx->stream, sm_ptr(ctx, slot_t),   \
+                       SM_LD, k, sm_ptr(ctx, SM_TMP), use_lds, rotlog, dvals, perm, sort_by_abs, ctx->status_dev);   \
+  } while (0)
+#define JAC_LAUNCH(NBV)  \
+  do {                   \
+    if (use_lds) JAC_LAUNCH2(NBV, true); \
+    else JAC_LAUNCH2(NBV, false);        \
+  } while (0)
+  if (nb <= 1) JAC_LAUNCH(1);
+  else if (nb <= 2) JAC_LAUNCH(2);
+  else if (nb <= 3) JAC_LAUNCH(3);
+  else if (nb <= 9) JAC_LAUNCH(9);
+  else HFMI_FAIL(HFMI_ERR_INVALID, "jacobi_eig: %d blocks per thread (k=%d, %d threads) not instantiated", nb, k, threads);
+#undef JAC_LAUNCH
+#undef JAC_LAUNCH2
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
                      sm_ptr(ctx, slot_v), SM_LD);
