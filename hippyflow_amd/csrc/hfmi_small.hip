@@ -395,31 +395,276 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_chol_reg: the same contract as k_chol_inv for an LDS-resident matrix (k <= 139), built around what one CU
+// actually charges for: INSTRUCTION ISSUE (one VALU and one scalar instruction per SIMD every 4 cycles, shared by
+// the waves of the SIMD) and the 32-cycle dependent fp64 latency -- not flops.  512 threads; the upper triangle is
+// enumerated bottom row first and dealt cyclically, entry e -> thread e % 512, register slot e / 512, so slot q of
+// all threads is one band of adjacent rows.  A factorisation step publishes the pivot row into a fixed LDS row
+// buffer (static read addresses), takes one barrier, and updates whole slot groups: per entry two ds_reads, one
+// mul, one fma, no mask (an entry whose row is finished is dead: it has been published and may be overwritten
+// with garbage), one wave-uniform test per GROUP of four slots, all loads of a group issued before their first
+// use.  The inverse runs the same way bottom-up (see below).
+// ------------------------------------------------------------------------------------------------
+#define CHOL_REG_THREADS 512
+template <int EPT>
+__global__ __launch_bounds__(CHOL_REG_THREADS) void k_chol_reg(const double* __restrict__ G, int ldg, int k,
+                                                               double* __restrict__ Rout, double* __restrict__ Rinv,
+                                                               double* __restrict__ Rtot, double* __restrict__ Rtmp,
+                                                               int ldo, int rtot_mode, int full_r, double shift_rel,
+                                                               double pivot_tol, double* __restrict__ colnorm0,
+                                                               double* __restrict__ rdiag,
+                                                               hfmi_status_words* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
+  double* diag0 = red + 32;                            // k original diagonal entries
+  double* invd = diag0 + 256;                          // 1 / R_jj
+  double* rb0 = invd + 256;                            // published row, two alternating buffers
+  double* rb1 = rb0 + 256;
+  double* M = rb1 + 256;                               // U, then R (upper triangle), row-major
+  const int ldm = k | 1;
+  constexpr int NT = CHOL_REG_THREADS;
+  constexpr int GQ = 4;                                // slots per group
+  constexpr int NG = (EPT + GQ - 1) / GQ;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+  __shared__ int s_break;
+
+  long long tk0 = clock64(), tk1, tk2, tk3, tk4;
+  for (int i = tid; i < k; i += NT) {
+    diag0[i] = G[i * ldg + i];
+    if (rtot_mode == 1) colnorm0[i] = sqrt(fmax(diag0[i], 0.0));  // norms of the ORIGINAL columns (first pass)
+  }
+  for (int i = tid; i < 512; i += NT) rb0[i] = 0.0;               // both row buffers
+  __syncthreads();
+  for (int i = tid; i < k; i += NT) invd[i] = diag0[i] > 0.0 ? fast_rsqrt(diag0[i]) : 0.0;
+  __syncthreads();
+  double dev = 0.0, tr = 0.0;
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) {
+      const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+      const double x = g * invd[i] * invd[j] - (i == j ? 1.0 : 0.0);
+      dev += x * x;
+      if (i == j) tr += g;
+    }
+  dev = block_sum(dev, red);
+  tr = block_sum(tr, red);
+  tk1 = clock64();
+
+  // owned entries: slot q holds cell e = tid + q * NT; rows counted from the bottom, m (m+1)/2 <= e < (m+1)(m+2)/2
+  const int total = k * (k + 1) / 2;
+  int oi[EPT], oc[EPT];   // row (clamped into the matrix for idle slots: they compute garbage nobody reads), column
+  bool own[EPT];
+  double v[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = tid + q * NT;
+    own[q] = e < total;
+    const int ee = own[q] ? e : 0;
+    int m = (int)((sqrtf(8.0f * (float)ee + 1.0f) - 1.0f) * 0.5f);
+    while (m * (m + 1) / 2 > ee) --m;
+    while ((m + 1) * (m + 2) / 2 <= ee) ++m;
+    oi[q] = k - 1 - m;
+    oc[q] = (k - 1 - m) + (ee - m * (m + 1) / 2);
+    v[q] = 0.0;
+  }
+
+  int shifted = 0, failed = 0;
+  double shift = 0.0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    shift = attempt ? shift_rel * tr : 0.0;
+    if (tid == 0) s_break = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      v[q] = 0.5 * (G[oi[q] * ldg + oc[q]] + G[oc[q] * ldg + oi[q]]);
+      if (oi[q] == oc[q]) v[q] += shift;
+    }
+    // Unscaled (LDL^T-style) right-looking factorisation: U[i][c] = G[i][c] - sum_{j<i} U[j][i] U[j][c] / U[j][j];
+    // R = diag(U)^{-1/2} U is formed by one scaling pass at the end.
+    for (int j = 0; j < k; ++j) {
+      double* rb = (j & 1) ? rb1 : rb0;
+      const int m = k - 1 - j;                            // row j counted from the bottom
+      const int e0 = m * (m + 1) / 2;                     // its cells are e0 .. e0 + m (k - j of them)
+      const int qp0 = e0 / NT, qp1 = (e0 + m) / NT;       // the (at most two) slots that hold them
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (g * GQ <= qp1 && qp0 < g * GQ + GQ) {
+#pragma unroll
+          for (int q = g * GQ; q < g * GQ + GQ && q < EPT; ++q)
+            if (own[q] && oi[q] == j) {                   // row j is final: publish it
+              rb[oc[q]] = v[q];
+              M[j * ldm + oc[q]] = v[q];
+            }
+        }
+      __syncthreads();
+      const double piv = rb[j];
+      const double ref = diag0[j] + shift;
+      if (!(piv > pivot_tol * ref) || !(ref > 0.0)) {     // uniform decision: every thread reads the same words
+        if (tid == 0) s_break = 1;
+        break;
+      }
+      const double inv = fast_rsqrt(piv);
+      const double nrp = -(inv * inv);
+      if (tid == 0) invd[j] = inv;
+      // slots 0 .. qa-1 still hold rows > j (cells below row j are exactly e < e0)
+      const int qa = (e0 + NT - 1) / NT;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (g * GQ < qa) {
+          double xa[GQ], xb[GQ];
+#pragma unroll
+          for (int u = 0; u < GQ; ++u)
+            if (g * GQ + u < EPT) {
+              xa[u] = rb[oi[g * GQ + u]];
+              xb[u] = rb[oc[g * GQ + u]];
+            }
+#pragma unroll
+          for (int u = 0; u < GQ; ++u)
+            if (g * GQ + u < EPT) v[g * GQ + u] = fma(xa[u] * nrp, xb[u], v[g * GQ + u]);
+        }
+    }
+    __syncthreads();
+    if (!s_break) break;
+    if (attempt == 0) shifted = 1;
+    else failed = 1;
+    __syncthreads();
+  }
+  if (failed) {
+    if (tid == 0) {
+      status->min_pivot_ratio = 0.0;
+      status->gram_dev = sqrt(dev);
+      status->shifted = shifted;
+      status->failed = 1;
+    }
+    return;
+  }
+  // smallest pivot relative to the (shifted) original diagonal: piv_j = 1 / invd_j^2
+  double ratio = 1e300;
+  for (int j = tid; j < k; j += NT) ratio = fmin(ratio, 1.0 / (invd[j] * invd[j] * (diag0[j] + shift)));
+  const double min_ratio = block_min(ratio, red);
+  // R = diag(U)^{-1/2} U
+  for (int i = wave; i < k; i += nw) {
+    const double sc = invd[i];
+    for (int j = i + lane; j < k; j += 64) M[i * ldm + j] *= sc;
+  }
+  for (int i = tid; i < 512; i += NT) rb0[i] = 0.0;  // the inverse relies on zeros left of the published row
+  __syncthreads();
+  tk2 = clock64();
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+  // Inverse X = R^-1, right-looking and bottom-up: once row l of X is final (x_ll = 1/R_ll, x_lc = -acc / R_ll) it
+  // goes to the output and into the row buffer, and every entry (i, c) with i < l accumulates R[i][l] x_lc -- x_lc
+  // reads as 0 for c < l (the buffers are zeroed and row l only writes c >= l), finished entries (i >= l) are
+  // dead, so again no masks.
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) v[q] = 0.0;
+  for (int l = k - 1; l >= 0; --l) {
+    double* xr = (l & 1) ? rb1 : rb0;
+    const int m = k - 1 - l;
+    const int e0 = m * (m + 1) / 2;
+    const int qp0 = e0 / NT, qp1 = (e0 + m) / NT;
+    const double il = invd[l];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (g * GQ <= qp1 && qp0 < g * GQ + GQ) {
+#pragma unroll
+        for (int q = g * GQ; q < g * GQ + GQ && q < EPT; ++q)
+          if (own[q] && oi[q] == l) {
+            const double x = (oc[q] == l) ? il : -il * v[q];
+            xr[oc[q]] = x;
+            Rinv[l * ldo + oc[q]] = x;
+          }
+      }
+    __syncthreads();
+    // slots qs .. EPT-1 hold rows < l (cells of rows above row l are exactly e >= e0 + m + 1)
+    const int qs = (e0 + m + 1) / NT;
+    const double* ml = M + l;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (g * GQ + GQ > qs) {
+        double xa[GQ], xb[GQ];
+#pragma unroll
+        for (int u = 0; u < GQ; ++u)
+          if (g * GQ + u < EPT) {
+            xa[u] = ml[oi[g * GQ + u] * ldm];
+            xb[u] = xr[oc[g * GQ + u]];
+          }
+#pragma unroll
+        for (int u = 0; u < GQ; ++u)
+          if (g * GQ + u < EPT) v[g * GQ + u] = fma(xa[u], xb[u], v[g * GQ + u]);
+      }
+  }
+  __syncthreads();
+  tk3 = clock64();
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < i; j += 64) Rinv[i * ldo + j] = 0.0;
+  // diagonal of the running product R = R_p ... R_1 (its ratio to the original column norms exposes
+  // numerically dependent columns); the full product only when the caller wants R
+  for (int i = tid; i < k; i += NT) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * M[i * ldm + i];
+  if (full_r) {
+    if (rtot_mode == 1) {
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+    } else {
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) {
+          double acc = 0.0;
+          if (j >= i)
+            for (int l = i; l <= j; ++l) acc += M[i * ldm + l] * Rtot[l * ldo + j];
+          Rtmp[i * ldo + j] = acc;
+        }
+      __syncthreads();
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rtmp[i * ldo + j];
+    }
+  }
+  tk4 = clock64();
+  if (tid == 0) {
+    status->min_pivot_ratio = min_ratio;
+    status->gram_dev = sqrt(dev);
+    status->shifted = shifted;
+    status->failed = 0;
+    status->tick[0] = tk1 - tk0;  // load + defect
+    status->tick[1] = tk2 - tk1;  // Cholesky
+    status->tick[2] = tk3 - tk2;  // inverse
+    status->tick[3] = tk4 - tk3;  // outputs + R product
+    status->tick[4] = 0;
+  }
+}
+
 int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
                     int full_r, double shift_rel, double pivot_tol) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "chol_inv: k=%d out of range", k);
   const int use_lds = (k <= 139) ? 1 : 0;   // (32 + 3 * 256) * 8 + 139 * 139 * 8 = 160,968 bytes <= 160 KB (163,840)
   const size_t shmem = (32 + 3 * 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
-  const int threads = small_threads();
-  const int ept = use_lds ? (k * (k + 1) / 2 + threads - 1) / threads : 0;   // upper-triangle entries per thread
-#define CHOL_LAUNCH(E)                                                                                                 \
-  do {                                                                                                                 \
-    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
-    hipLaunchKernelGGL(k_chol_inv<E>, dim3(1), dim3(threads), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,    \
-                       sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2),      \
-                       SM_LD, rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds,                   \
-                       sm_ptr(ctx, SM_AUX), sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);                             \
+  if (use_lds && !getenv("HFMI_CHOL_GENERIC")) {
+    const int ept = (k * (k + 1) / 2 + CHOL_REG_THREADS - 1) / CHOL_REG_THREADS;   // <= 19 for k <= 139
+    const size_t shm = (32 + 4 * 256) * sizeof(double) + (size_t)k * (k | 1) * sizeof(double);
+#define CHOL_REG(E)                                                                                                   \
+  do {                                                                                                                \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_reg<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));   \
+    hipLaunchKernelGGL(k_chol_reg<E>, dim3(1), dim3(CHOL_REG_THREADS), shm, ctx->stream, sm_ptr(ctx, slot_gram),      \
+                       SM_LD, k, sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot),                 \
+                       sm_ptr(ctx, SM_TMP2), SM_LD, rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_AUX),     \
+                       sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);                                                 \
   } while (0)
-  if (ept == 0 || ept > 10) CHOL_LAUNCH(0);
-  else if (ept <= 1) CHOL_LAUNCH(1);
-  else if (ept <= 2) CHOL_LAUNCH(2);
-  else if (ept <= 3) CHOL_LAUNCH(3);
-  else if (ept <= 4) CHOL_LAUNCH(4);
-  else if (ept <= 6) CHOL_LAUNCH(6);
-  else if (ept <= 8) CHOL_LAUNCH(8);
-  else CHOL_LAUNCH(10);
-#undef CHOL_LAUNCH
+    if (ept <= 1) CHOL_REG(1);
+    else if (ept <= 2) CHOL_REG(2);
+    else if (ept <= 4) CHOL_REG(4);
+    else if (ept <= 6) CHOL_REG(6);
+    else if (ept <= 8) CHOL_REG(8);
+    else if (ept <= 12) CHOL_REG(12);
+    else if (ept <= 16) CHOL_REG(16);
+    else CHOL_REG(20);
+#undef CHOL_REG
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_chol_inv<0>, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
+                       sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
+                       rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX),
+                       sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);
+  }
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
