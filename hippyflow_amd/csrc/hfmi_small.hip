@@ -408,7 +408,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
 // ------------------------------------------------------------------------------------------------
 #define CHOL_REG_THREADS 512
 template <int EPT>
-__global__ __launch_bounds__(CHOL_REG_THREADS) void k_chol_reg(const double* __restrict__ G, int ldg, int k,
+__global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_reg(const double* __restrict__ G, int ldg, int k,
                                                                double* __restrict__ Rout, double* __restrict__ Rinv,
                                                                double* __restrict__ Rtot, double* __restrict__ Rtmp,
                                                                int ldo, int rtot_mode, int full_r, double shift_rel,

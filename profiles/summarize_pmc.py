@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel PMC summary from rocprofv3 --pmc CSV output (counter_collection.csv): mean counter values per
 launch of each kernel, plus derived figures (effective clock, MFMA pipe utilisation, HBM bytes with the gfx950
-FETCH_SIZE x2 correction of MI355X_MICROARCH.md section HBM).  Usage: summarize_pmc.py <dir with pmc_*/...csv>"""
+FETCH_SIZE x2 correction of MI355X_MICROARCH.md section HBM).
+Usage: summarize_pmc.py <dir with pmc_*/...csv> [min kernel duration in ms, default 1.0]"""
 import collections
 import csv
 import glob
@@ -54,4 +55,4 @@ def main(root, min_ms=1.0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
