@@ -450,6 +450,31 @@ extern "C" int hfmi_csr_create(hfmi_ctx* ctx, int64_t nrows, int64_t ncols, int6
   m->ncols = ncols;
   m->nnz = nnz;
   m->inv_diag = nullptr;
+  m->ell_w = 0;
+  m->ell_idx = nullptr;
+  m->ell_val = nullptr;
+  {
+    // ELL image when the longest row is short and the padding stays below 1.5x (FEM mass / stiffness matrices)
+    int64_t wmax = 0;
+    for (int64_t i = 0; i < nrows; ++i) wmax = std::max(wmax, indptr[i + 1] - indptr[i]);
+    if (wmax > 0 && wmax <= 64 && wmax * nrows <= nnz + nnz / 2 + 1024 && nrows < (int64_t)1 << 31) {
+      std::vector<int32_t> ei((size_t)wmax * nrows);
+      std::vector<double> ev((size_t)wmax * nrows);
+      for (int64_t i = 0; i < nrows; ++i) {
+        const int64_t b = indptr[i], e = indptr[i + 1];
+        for (int64_t s = 0; s < wmax; ++s) {
+          const bool in = b + s < e;
+          ei[(size_t)s * nrows + i] = in ? indices[b + s] : (e > b ? indices[b] : 0);   // padding: a valid column, value 0
+          ev[(size_t)s * nrows + i] = in ? data[b + s] : 0.0;
+        }
+      }
+      HIP_TRY(hipMalloc((void**)&m->ell_idx, ei.size() * sizeof(int32_t)));
+      HIP_TRY(hipMalloc((void**)&m->ell_val, ev.size() * sizeof(double)));
+      HIP_TRY(hipMemcpy(m->ell_idx, ei.data(), ei.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(m->ell_val, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
+      m->ell_w = (int)wmax;
+    }
+  }
   HIP_TRY(hipMalloc((void**)&m->indptr, (size_t)(nrows + 1) * sizeof(int64_t)));
   HIP_TRY(hipMalloc((void**)&m->indices, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
   HIP_TRY(hipMalloc((void**)&m->data, (size_t)std::max<int64_t>(nnz, 1) * sizeof(double)));
@@ -466,6 +491,8 @@ extern "C" int hfmi_csr_destroy(hfmi_csr* m) {
   (void)hipFree(m->indices);
   (void)hipFree(m->data);
   if (m->inv_diag) (void)hipFree(m->inv_diag);
+  if (m->ell_idx) (void)hipFree(m->ell_idx);
+  if (m->ell_val) (void)hipFree(m->ell_val);
   delete m;
   return HFMI_OK;
 }
@@ -605,8 +632,8 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)5 * k * sizeof(double), &sc));
   double* rz = (double*)sc;       // r.z
   double* rz_new = rz + k;
-  double* pap = rz + 2 * k;
-  double* rr = rz + 3 * k;
+  double* rr = rz + 2 * k;        // must follow rz_new (launch_pcg_update fills both with one final pass)
+  double* pap = rz + 3 * k;
   double* bb = rz + 4 * k;
   std::vector<double> h_rr(k), h_bb(k);
   // x0 = 0, r = b
@@ -620,6 +647,21 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
   int it = 0;
   bool done = false;
   for (; it < op->max_iter && !done; ++it) {
+    if (M->ell_w > 0) {
+      // three passes over the blocks per iteration: A p fused with p . A p; (x, r) update fused with both residual
+      // dots; the new direction with z = D^-1 r recomputed on the fly (never stored)
+      HFMI_TRY(launch_ell_spmm_dot(ctx, M, P->p, P->ld, AP->p, AP->ld, k, pap));
+      HFMI_TRY(launch_pcg_update(ctx, Y->p, Y->ld, R->p, R->ld, P->p, P->ld, AP->p, AP->ld, M->inv_diag, N, k, rz, pap, rz_new, rr));
+      HFMI_TRY(launch_pcg_direction(ctx, P->p, P->ld, R->p, R->ld, M->inv_diag, N, k, rz_new, rz));
+      HIP_TRY(hipMemcpyAsync(rz, rz_new, (size_t)k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      if ((it & 3) == 3 || it + 1 == op->max_iter) {
+        HFMI_TRY(read_back(ctx, rr, k, h_rr.data()));
+        done = true;
+        for (int j = 0; j < k; ++j)
+          if (h_rr[j] > op->rel_tol * op->rel_tol * h_bb[j]) done = false;
+      }
+      continue;
+    }
     HFMI_TRY(launch_csr_spmm(ctx, M, P->p, P->ld, AP->p, AP->ld, k, false));
     HFMI_TRY(launch_col_dots(ctx, P->p, P->ld, AP->p, AP->ld, N, k, pap));
     HFMI_TRY(launch_col_axpy_dev(ctx, Y->p, Y->ld, P->p, P->ld, N, k, rz, pap, 1.0));

@@ -93,6 +93,11 @@ struct hfmi_csr {
   int32_t* indices;
   double* data;
   double* inv_diag;  // Jacobi preconditioner (lazy)
+  // ELLPACK image (slot-major: entry s of row i at [s * nrows + i]) built at creation when the rows are short and
+  // even (FEM matrices): consecutive lanes then read consecutive (index, value) pairs.  ell_w == 0: CSR kernel only.
+  int ell_w;
+  int32_t* ell_idx;
+  double* ell_val;
 };
 
 enum hfmi_op_kind { OP_SNAPSHOT_GRAM, OP_JTJ, OP_JJT, OP_DENSE_SYM, OP_CSR, OP_CSR_PCG, OP_COMPOSE3, OP_HOST };
@@ -149,6 +154,17 @@ int launch_block_to_dense_ld(hfmi_ctx* ctx, const double* p, int64_t ld, double*
 int launch_csr_spmm(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec,
                     bool accumulate);
 int launch_csr_diag_inv(hfmi_ctx* ctx, hfmi_csr* M);
+// Y = M X fused with the per-column dots dots[j] = <X_j, Y_j> (PCG: p . A p); needs the ELL image
+int launch_ell_spmm_dot(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec,
+                        double* dots);
+// One fused PCG update per column j (alpha_j = rz_j / pap_j): y += alpha p, r -= alpha ap, then
+// rz_new_j = <r, D^-1 r> and rr_j = <r, r> (device outputs, fixed summation order)
+int launch_pcg_update(hfmi_ctx* ctx, double* y, int64_t ldy, double* r, int64_t ldr, const double* p, int64_t ldp,
+                      const double* ap, int64_t ldap, const double* inv_diag, int64_t N, int nvec, const double* rz,
+                      const double* pap, double* rz_new, double* rr);
+// p_j = D^-1 r_j + (rz_new_j / rz_j) p_j
+int launch_pcg_direction(hfmi_ctx* ctx, double* p, int64_t ldp, const double* r, int64_t ldr, const double* inv_diag,
+                         int64_t N, int nvec, const double* rz_new, const double* rz);
 // out[j] = <A_j, B_j> for j < nvec (device out)
 int launch_col_dots(hfmi_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t N, int nvec,
                     double* out);

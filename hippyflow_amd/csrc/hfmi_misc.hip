@@ -212,6 +212,56 @@ int launch_block_to_dense(hfmi_ctx* ctx, const double* p, int64_t ld, double* de
   return launch_block_to_dense_ld(ctx, p, ld, dense, nvec, N, nvec);
 }
 
+// ELL variant: thread = row, the (index, value) pairs of a slot are contiguous across the rows of a wave, SPMM_EB
+// vectors per pass.  DOT: also emit this workgroup's part of <X_j, Y_j> (the p . A p of PCG) -- one partial per
+// (vector, workgroup), summed in a fixed order by k_col_dots_final.
+constexpr int SPMM_EB = 12;
+template <bool DOT>
+__global__ __launch_bounds__(256) void k_ell_spmm(const int32_t* __restrict__ eidx, const double* __restrict__ eval,
+                                                  int w, int64_t nrows, const double* __restrict__ X, int64_t ldx,
+                                                  double* __restrict__ Y, int64_t ldy, int nvec, int accumulate,
+                                                  double* __restrict__ part) {
+  __shared__ double wsum[4][SPMM_EB];
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = row < nrows;
+  const int64_t r = live ? row : nrows - 1;
+  for (int j0 = blockIdx.y * SPMM_EB; j0 < nvec; j0 += gridDim.y * SPMM_EB) {
+    double acc[SPMM_EB];
+#pragma unroll
+    for (int jj = 0; jj < SPMM_EB; ++jj) acc[jj] = 0.0;
+    for (int s = 0; s < w; ++s) {
+      const double v = eval[(int64_t)s * nrows + r];
+      const double* xr = X + eidx[(int64_t)s * nrows + r];
+#pragma unroll
+      for (int jj = 0; jj < SPMM_EB; ++jj) {
+        const int j = j0 + jj < nvec ? j0 + jj : nvec - 1;
+        acc[jj] += v * xr[(int64_t)j * ldx];
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < SPMM_EB; ++jj)
+      if (live && j0 + jj < nvec) {
+        double* y = Y + (int64_t)(j0 + jj) * ldy + row;
+        *y = accumulate ? *y + acc[jj] : acc[jj];
+      }
+    if (DOT) {
+#pragma unroll
+      for (int jj = 0; jj < SPMM_EB; ++jj) {
+        const int j = j0 + jj < nvec ? j0 + jj : nvec - 1;
+        double d = live ? acc[jj] * X[(int64_t)j * ldx + row] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][jj] = d;
+      }
+      __syncthreads();
+      if (threadIdx.x < SPMM_EB && j0 + threadIdx.x < nvec)
+        part[(int64_t)(j0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+            (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------ CSR SpMM: Y[:, j] (+)= M X[:, j]
 // One lane per matrix row (consecutive lanes -> consecutive rows: coalesced Y stores; the gathers of X hit
 // neighbouring rows for FEM matrices), 8 vectors per pass so the row's (index, value) pairs are read once per 8.
@@ -243,6 +293,13 @@ __global__ void k_csr_spmm(const int64_t* __restrict__ indptr, const int32_t* __
 }
 int launch_csr_spmm(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec, bool accumulate) {
   if (M->nrows <= 0 || nvec <= 0) return HFMI_OK;
+  if (M->ell_w > 0) {
+    dim3 grid((unsigned)((M->nrows + 255) / 256), (unsigned)((nvec + SPMM_EB - 1) / SPMM_EB));
+    hipLaunchKernelGGL((k_ell_spmm<false>), grid, dim3(256), 0, ctx->stream, M->ell_idx, M->ell_val, M->ell_w, M->nrows, X,
+                       ldx, Y, ldy, nvec, accumulate ? 1 : 0, (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return HFMI_OK;
+  }
   int gy = (nvec + SPMM_JB - 1) / SPMM_JB;
   dim3 grid((unsigned)((M->nrows + 255) / 256), (unsigned)gy);
   hipLaunchKernelGGL(k_csr_spmm, grid, dim3(256), 0, ctx->stream, M->indptr, M->indices, M->data, M->nrows, X, ldx, Y, ldy, nvec, accumulate ? 1 : 0);
@@ -289,12 +346,18 @@ __global__ void k_col_dots_partial(const double* __restrict__ A, int64_t lda, co
     __syncthreads();
   }
 }
-__global__ void k_col_dots_final(const double* __restrict__ part, int nchunks, int nvec, double* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output: lanes stride over the partials, then a fixed-order shuffle tree (deterministic); the serial
+// version of this loop cost 50-100 us per call once a fused kernel produced a few hundred partials per vector
+__global__ __launch_bounds__(64) void k_col_dots_final(const double* __restrict__ part, int nchunks, int nvec,
+                                                       double* __restrict__ out) {
+  const int j = blockIdx.x;
   if (j >= nvec) return;
+  const double* p = part + (int64_t)j * nchunks;
   double s = 0.0;
-  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)j * nchunks + c];
-  out[j] = s;
+  for (int c = threadIdx.x; c < nchunks; c += 64) s += p[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (threadIdx.x == 0) out[j] = s;
 }
 int launch_col_dots(hfmi_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t N, int nvec, double* out) {
   if (nvec <= 0) return HFMI_OK;
@@ -303,7 +366,7 @@ int launch_col_dots(hfmi_ctx* ctx, const double* A, int64_t lda, const double* B
   dim3 grid(DOT_CHUNKS, nvec < 1024 ? nvec : 1024);
   hipLaunchKernelGGL(k_col_dots_partial, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, N, nvec, (double*)part);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_col_dots_final, dim3((nvec + 63) / 64), dim3(64), 0, ctx->stream, (const double*)part, DOT_CHUNKS, nvec, out);
+  hipLaunchKernelGGL(k_col_dots_final, dim3(nvec), dim3(64), 0, ctx->stream, (const double*)part, DOT_CHUNKS, nvec, out);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
@@ -365,6 +428,116 @@ __global__ void k_diag_scale(double* __restrict__ z, int64_t ldz, const double* 
 int launch_diag_scale(hfmi_ctx* ctx, double* z, int64_t ldz, const double* r, int64_t ldr, const double* inv_diag, int64_t N, int nvec) {
   if (N <= 0 || nvec <= 0) return HFMI_OK;
   hipLaunchKernelGGL(k_diag_scale, ew_grid(2 * N, nvec), dim3(256), 0, ctx->stream, z, ldz, r, ldr, inv_diag, N, nvec);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+int launch_ell_spmm_dot(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec,
+                        double* dots) {
+  if (M->ell_w <= 0) HFMI_FAIL(HFMI_ERR_INVALID, "ell_spmm_dot: matrix has no ELL image");
+  const unsigned gx = (unsigned)((M->nrows + 255) / 256);
+  void* part = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nvec * gx * sizeof(double), &part));
+  dim3 grid(gx, (unsigned)((nvec + SPMM_EB - 1) / SPMM_EB));
+  hipLaunchKernelGGL((k_ell_spmm<true>), grid, dim3(256), 0, ctx->stream, M->ell_idx, M->ell_val, M->ell_w, M->nrows, X, ldx,
+                     Y, ldy, nvec, 0, (double*)part);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_col_dots_final, dim3(nvec), dim3(64), 0, ctx->stream, (const double*)part, (int)gx, nvec, dots);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// Fused PCG update (one pass over y, r, p, ap instead of four kernels): per column j, alpha = rz_j / pap_j,
+// y += alpha p, r -= alpha ap, partial sums of <r, D^-1 r> and <r, r>.  z = D^-1 r is never stored.
+constexpr int PCG_CHUNKS = 128;
+__global__ __launch_bounds__(256) void k_pcg_update(double* __restrict__ y, int64_t ldy, double* __restrict__ r, int64_t ldr,
+                                                    const double* __restrict__ p, int64_t ldp,
+                                                    const double* __restrict__ ap, int64_t ldap,
+                                                    const double* __restrict__ dinv, int64_t N, int nvec,
+                                                    const double* __restrict__ rz, const double* __restrict__ pap,
+                                                    double* __restrict__ part) {
+  __shared__ double wsum[4][2];
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    const double a = pap[j] != 0.0 ? rz[j] / pap[j] : 0.0;
+    double* yc = y + (int64_t)j * ldy;
+    double* rc = r + (int64_t)j * ldr;
+    const double* pc = p + (int64_t)j * ldp;
+    const double* ac = ap + (int64_t)j * ldap;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 yv = *reinterpret_cast<d2*>(yc + t), rv = *reinterpret_cast<d2*>(rc + t);
+        const d2 pv = *reinterpret_cast<const d2*>(pc + t), av = *reinterpret_cast<const d2*>(ac + t);
+        const d2 dv = *reinterpret_cast<const d2*>(dinv + t);
+        yv.x += a * pv.x; yv.y += a * pv.y;
+        rv.x -= a * av.x; rv.y -= a * av.y;
+        *reinterpret_cast<d2*>(yc + t) = yv;
+        *reinterpret_cast<d2*>(rc + t) = rv;
+        s1 += rv.x * (dv.x * rv.x) + rv.y * (dv.y * rv.y);
+        s2 += rv.x * rv.x + rv.y * rv.y;
+      } else {
+        yc[t] += a * pc[t];
+        const double rv = rc[t] - a * ac[t];
+        rc[t] = rv;
+        s1 += rv * (dinv[t] * rv);
+        s2 += rv * rv;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_down(s1, off, 64);
+      s2 += __shfl_down(s2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      wsum[threadIdx.x >> 6][0] = s1;
+      wsum[threadIdx.x >> 6][1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+      part[((int64_t)threadIdx.x * nvec + j) * gridDim.x + blockIdx.x] =
+          (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+int launch_pcg_update(hfmi_ctx* ctx, double* y, int64_t ldy, double* r, int64_t ldr, const double* p, int64_t ldp,
+                      const double* ap, int64_t ldap, const double* inv_diag, int64_t N, int nvec, const double* rz,
+                      const double* pap, double* rz_new, double* rr) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  if (rr != rz_new + nvec) HFMI_FAIL(HFMI_ERR_INVALID, "pcg_update: rr must follow rz_new in memory");
+  void* part = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)2 * nvec * PCG_CHUNKS * sizeof(double), &part));
+  dim3 grid(PCG_CHUNKS, nvec < 1024 ? nvec : 1024);
+  hipLaunchKernelGGL(k_pcg_update, grid, dim3(256), 0, ctx->stream, y, ldy, r, ldr, p, ldp, ap, ldap, inv_diag, N, nvec, rz,
+                     pap, (double*)part);
+  HIP_TRY(hipGetLastError());
+  // the two partial arrays are laid out back to back as 2 * nvec "vectors": one final pass fills rz_new | rr
+  hipLaunchKernelGGL(k_col_dots_final, dim3(2 * nvec), dim3(64), 0, ctx->stream, (const double*)part, PCG_CHUNKS, 2 * nvec,
+                     rz_new);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+__global__ void k_pcg_direction(double* __restrict__ p, int64_t ldp, const double* __restrict__ r, int64_t ldr,
+                                const double* __restrict__ dinv, int64_t N, int nvec, const double* __restrict__ num,
+                                const double* __restrict__ den) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    const double b = den[j] != 0.0 ? num[j] / den[j] : 0.0;
+    double* pc = p + (int64_t)j * ldp;
+    const double* rc = r + (int64_t)j * ldr;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      if (t + 1 < N) {
+        d2 pv = *reinterpret_cast<d2*>(pc + t);
+        const d2 rv = *reinterpret_cast<const d2*>(rc + t), dv = *reinterpret_cast<const d2*>(dinv + t);
+        pv.x = dv.x * rv.x + b * pv.x;
+        pv.y = dv.y * rv.y + b * pv.y;
+        *reinterpret_cast<d2*>(pc + t) = pv;
+      } else pc[t] = dinv[t] * rc[t] + b * pc[t];
+    }
+  }
+}
+int launch_pcg_direction(hfmi_ctx* ctx, double* p, int64_t ldp, const double* r, int64_t ldr, const double* inv_diag,
+                         int64_t N, int nvec, const double* rz_new, const double* rz) {
+  if (N <= 0 || nvec <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_pcg_direction, ew_grid(N, nvec), dim3(256), 0, ctx->stream, p, ldp, r, ldr, inv_diag, N, nvec, rz_new, rz);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Kernel trace of the per-GPU share of the 8-GPU config-4 run (64 of the 512 samples on one GPU): what does NOT scale.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out; mkdir -p $out
+rm -rf /tmp/prof_shard
+( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py --samples-total 64 --steps 5 --warmup 2 --no-cpu-baseline --no-check > $out/shard_bench.json 2> $out/shard_prof.err )
+db=$(find /tmp/prof_shard -name "*.db" | head -1)
+python3 $R/profiles/summarize_rocpd.py $db > $out/shard_kernel_stats.csv
+python3 - <<PY
+import sqlite3, json
+db = sqlite3.connect("$db"); cur = db.cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+# last full step: find the last 3 launches of the big tn/nn and print the timeline from the first of them
+big = [i for i, r in enumerate(rows) if ("k_tsgemm_tn" in r[0] or "k_tsgemm_nn" in r[0]) and (r[2] - r[1]) > 2e6]
+start = big[-3]
+t0 = rows[start][1]
+prev_end = t0
+busy = 0
+print("timeline of the last step (us from its first big launch): name, start, duration, gap before")
+for r in rows[start:]:
+    name = r[0].split("(")[0][:60]
+    print("%-60s %10.1f %9.1f %8.1f" % (name, (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3))
+    prev_end = r[2]
+PY
