@@ -296,7 +296,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
 // tallest wave tile (in 16-row MFMA tiles) for a panel of nt column tiles
 static inline int tn_mt_max(int nt, int waves) {
   static const int t4[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
-  static const int t8[17] = {0, 5, 5, 5, 4, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+  static const int t8[17] = {0, 5, 5, 5, 4, 3, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1};   // A/B (r01e): <3,6> and <2,9> beat <2,6> / <1,9>; <4,5> does not beat <3,5>
   return waves == 4 ? t4[nt] : t8[nt];
 }
 
@@ -328,7 +328,7 @@ template <int NT, int WAVES>
 static int tn_dispatch_mt(hfmi_ctx* ctx, int mt, bool tr, const double* A, int64_t lda, int m, const double* B,
                           int64_t ldb, int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad,
                           int kpad) {
-  constexpr int LIM = (WAVES == 8) ? 16 : 32;
+  constexpr int LIM = (WAVES == 8) ? 20 : 32;
 #define TN_CASE(M)                                                                                                 \
   case M:                                                                                                          \
     if constexpr (M * NT <= LIM)                                                                                   \
