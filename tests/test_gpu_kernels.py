@@ -213,6 +213,32 @@ def test_csr_spmm_and_pcg(ctx, N, k):
     assert rel(Z.to_dense(), ref) < 1e-10
 
 
+@pytest.mark.parametrize("k", [1, 13, 84])
+def test_csr_irregular_rows_use_the_csr_kernel(ctx, k):
+    """A matrix with one dense row and empty rows has no ELL image (padding > 1.5x): SpMM and PCG must take the
+    CSR kernels and agree with scipy; an SPD arrow matrix keeps PCG meaningful."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    N = 3001
+    rng = np.random.default_rng(k)
+    R = sp.random(N, N, density=2e-3, random_state=3, format="lil")
+    R[7, :] = rng.standard_normal(N)            # one full row
+    R[11, :] = 0.0                              # an empty row
+    R = R.tocsr()
+    X = rng.standard_normal((N, k))
+    Xmv, Y = hf.MultiVector.from_dense(X), hf.MultiVector(N, k)
+    hf.CsrOperator(R).matMvMult(Xmv, Y)
+    scale = np.abs(R) @ np.abs(X) + 1e-300
+    assert np.max(np.abs(Y.to_dense() - R @ X) / scale) < 1e-13
+    arrow = sp.diags(np.linspace(2.0, 3.0, N), format="lil")
+    arrow[0, 1:] = 1e-2
+    arrow[1:, 0] = 1e-2
+    arrow = arrow.tocsr()
+    Z = hf.MultiVector(N, k)
+    hf.CsrPCGSolver(arrow, rel_tol=1e-13).matMvMult(Xmv, Z)
+    assert rel(Z.to_dense(), spla.splu(arrow.tocsc()).solve(X)) < 1e-10
+
+
 # ------------------------------------------------------------------ QR (a7)
 @pytest.mark.parametrize("N,k,cond", [(300, 20, 1e0), (4225, 30, 1e3), (4225, 30, 1e9), (20000, 138, 1e5), (1000, 200, 1e2)])
 def test_orthogonalize_matches_reference_mgs(ctx, N, k, cond):
