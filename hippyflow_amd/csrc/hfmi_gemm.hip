@@ -49,7 +49,7 @@ constexpr int TN_LDB = 34;  // LDS leading dimension (doubles): 16-byte aligned 
 // up to 16 tiles each -- same workgroup tile, but while one wave of a SIMD sits in a barrier / LDS / HBM wait the
 // other keeps the matrix pipe busy.
 template <int MT, int NT, bool TR, int WAVES, int RING>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
                                                                     const double* __restrict__ B, int64_t ldb, int k,
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ part, int mpad, int kpad) {
@@ -266,12 +266,12 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 // hfmi_tuning_set at run time).
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
 //   ring : register prefetch ring of the streamed operand in tsgemm_tn (2 = distance 1, 4 = distance 3)
-static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 8 column tiles, else 8)
+static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
   if (g_waves) return;
   const char* e = getenv("HFMI_GEMM_WAVES");
-  g_waves = (e && atoi(e) == 4) ? 4 : 8;   // measured: 8 waves + ring 2 is best or equal on every shape (scripts/gemm_ab.py)
+  g_waves = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 44) ? 44 : 8;   // measured: 8 waves + ring 2 is best or equal on every shape (scripts/gemm_ab.py)
   e = getenv("HFMI_GEMM_RING");
   g_ring = (e && atoi(e) == 4) ? 4 : 2;
 }
@@ -285,7 +285,7 @@ static int gemm_ring() {
 }
 extern "C" int hfmi_tuning_set(const char* key, int value) {
   tuning_init();
-  if (key && !strcmp(key, "waves") && (value == 4 || value == 8)) g_waves = value;
+  if (key && !strcmp(key, "waves") && (value == 4 || value == 8 || value == 44)) g_waves = value;
   else if (key && !strcmp(key, "ring") && (value == 2 || value == 4)) g_ring = value;
   else if (key && !strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
@@ -351,9 +351,14 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
     HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: leading dimensions must be multiples of 32 and >= round_up(N,32)");
   const bool tr = (rs == 1 && cs != 1);  // column-major output: coalesce along i
   // wave tile height: as tall as the accumulator budget allows, but no taller than the problem needs
-  const int waves = (nt > 11) ? 4 : gemm_waves();   // very wide panels: the 2-waves/SIMD register budget is too tight
+  // waves: 8 = one 8-wave workgroup per CU (two waves per SIMD); 4 = one 4-wave workgroup with big tiles;
+  // 44 = 4-wave workgroups with the small (two-per-SIMD) tiles, TWO workgroups per CU: their stage barriers are not
+  // synchronised with each other, so one workgroup's MFMAs cover the other's barrier / staging bubbles
+  const int wcfg = (nt > 11) ? 4 : gemm_waves();   // very wide panels: the 2-waves/SIMD register budget is too tight
+  const bool small4 = wcfg == 44;
+  const int waves = small4 ? 4 : wcfg;
   const int row_tiles = (m + 15) / 16;
-  int mt = tn_mt_max(nt, waves);
+  int mt = tn_mt_max(nt, small4 ? 8 : waves);
   const int need = (row_tiles + waves - 1) / waves;
   if (need < mt) mt = need;
   if (mt == 7) mt = 6;
@@ -362,7 +367,7 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   const int nrb = (m + rows_per_block - 1) / rows_per_block;
   const int mpad = nrb * rows_per_block;
   // split the long axis so that the grid fills the chip in (nearly) whole rounds of CUs
-  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int cus = (ctx->num_cus > 0 ? ctx->num_cus : 256) * (small4 ? 2 : 1);   // resident workgroup slots
   int nsplit = nsplit_req;
   if (nsplit <= 0) {
     const int64_t stages = Npad / TN_BK;
@@ -717,7 +722,7 @@ static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
                     int64_t ldy, int64_t N) {
   const int nt = (r + 15) / 16;
   tuning_init();
-  const int waves = g_nn_waves ? g_nn_waves : (nt >= 9 ? 8 : 4);
+  const int waves = g_nn_waves ? g_nn_waves : (nt >= 10 ? 8 : 4);   // A/B (scripts/gemm_ab.py, r01e): 4 waves win up to 9 column tiles
 #define NN_CASE(NTV, TT4, TT8)                                                             \
   case NTV:                                                                                \
     if (waves == 8) return nn_launch_w8<NTV, TT8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);  \
