@@ -890,15 +890,31 @@ __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restric
   const int rounds = status->sweeps * (n - 1);
   const int s1 = jac_next_slot(2 * tid, n), s2 = jac_next_slot(2 * tid + 1, n);
   int cur = 0;
-  for (int rr = 0; rr < rounds; ++rr) {
-    if (tid < np) {
-      const double2 cs = rotlog[(size_t)rr * np + tid];
-      const double2 v = *reinterpret_cast<const double2*>(&row[cur][2 * tid]);
-      row[cur ^ 1][s1] = cs.x * v.x - cs.y * v.y;
-      row[cur ^ 1][s2] = cs.y * v.x + cs.x * v.y;
+  // the (c, s) pairs come from global memory and depend on nothing: keep PF rounds of them in flight in registers,
+  // otherwise every round pays a full memory round trip between two barriers
+  constexpr int PF = 8;
+  const bool act = tid < np;
+  const double2* lg = rotlog + (act ? tid : 0);
+  double2 ring[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) ring[u] = (u < rounds) ? lg[(size_t)u * np] : make_double2(1.0, 0.0);
+  for (int r0 = 0; r0 < rounds; r0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int rr = r0 + u;
+      if (rr < rounds) {   // uniform
+        const double2 cs = ring[u];
+        const int nx = rr + PF;
+        ring[u] = (nx < rounds) ? lg[(size_t)nx * np] : make_double2(1.0, 0.0);
+        if (act) {
+          const double2 v = *reinterpret_cast<const double2*>(&row[cur][2 * tid]);
+          row[cur ^ 1][s1] = cs.x * v.x - cs.y * v.y;
+          row[cur ^ 1][s2] = cs.y * v.x + cs.x * v.y;
+        }
+        __syncthreads();
+        cur ^= 1;
+      }
     }
-    __syncthreads();
-    cur ^= 1;
   }
   for (int c = tid; c < k; c += blockDim.x) V[i * ldv + c] = row[cur][perm[c]];
   for (int c = k + tid; c < ((k + 15) & ~15); c += blockDim.x) V[i * ldv + c] = 0.0;
