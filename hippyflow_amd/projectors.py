@@ -421,8 +421,14 @@ class PODProjectorFromData:
     """Deterministic mass-weighted POD from a snapshot matrix (PODProjector.py:666-852).
     ``method='hep'`` (n << N) runs on the device: the n x n Gram matrix X^T M X and the back-transform
     phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is the Jacobi kernel
-    (n <= 256) -- same steps as :812-833.  'ghep' / 'inverse_ghep' (ARPACK Lanczos on the host in the
-    reference) are not provided: there is no CPU path in this package."""
+    (n <= 256) -- same steps as :812-833.
+
+    ``method='ghep'`` (H = M X (M X)^T / n against M, :743-773) and ``'inverse_ghep'`` (H = X X^T / n against
+    M^-1, :775-810) are ARPACK Lanczos iterations on the host in the reference.  Both pencils have their
+    eigenvectors in range(X): with phi = X c they reduce to the SAME n x n problem (X^T M X) c = n lambda c that
+    'hep' solves, with the same normalisation phi^T M phi = 1 (ghep: eigsh's M-orthonormality; inverse_ghep:
+    (M phi)^T M^-1 (M phi) = 1).  They are therefore served by the device Gram route too; results agree with the
+    reference's Lanczos output up to the sign of each mode and its iteration tolerance (tests/golden)."""
 
     def __init__(self, Vh=None, M_output=None, ctx=None):
         import scipy.sparse as sp
@@ -441,9 +447,9 @@ class PODProjectorFromData:
             u_data = u_data - u_shift
         else:
             u_shift = np.zeros(u_data.shape[1])
-        if method == 'hep':
+        if method in ('hep', 'ghep', 'inverse_ghep'):
             if n_data > 256:
-                raise NotImplementedError("hep on the device handles up to 256 snapshots (one-workgroup eigensolve); "
+                raise NotImplementedError("the device Gram route handles up to 256 snapshots (one-workgroup eigensolve); "
                                           "use PODProjector (randomized) for larger snapshot sets")
             X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector
             Mop = CsrOperator(self.M_csr, ctx=self.ctx)
@@ -462,10 +468,6 @@ class PODProjectorFromData:
             MvDSmatMult(X, np.ascontiguousarray(U / norms), phi_mv)    # phi / ||phi||_M
             Mop.matMvMult(phi_mv, Mphi_mv)                             # :830
             phi, Mphi = phi_mv.to_dense(), Mphi_mv.to_dense()
-        elif method in ('ghep', 'inverse_ghep'):
-            raise NotImplementedError("method=%r is an ARPACK Lanczos iteration on the host in the reference "
-                                      "(PODProjector.py:743-810); the device path provides 'hep' (n <= 256 snapshots) "
-                                      "and the randomized PODProjector" % method)
         else:
             raise ValueError("Unavailable method")
         if verify:

@@ -254,13 +254,17 @@ def test_double_pass_g_kle_mass(ctx, binv):
 
 
 # ------------------------------------------------------------------ projectors
+@pytest.mark.parametrize("method", ["hep", "ghep", "inverse_ghep"])
 @pytest.mark.parametrize("shifted", [True, False])
-def test_pod_from_data_hep_matches_reference_golden(ctx, golden_dir, shifted):
+def test_pod_from_data_matches_reference_golden(ctx, golden_dir, shifted, method):
+    """All three methods of PODProjectorFromData.construct_subspace against the reference's own outputs (the
+    reference runs numpy eigh for 'hep' and ARPACK for the two generalized forms; the device serves all three
+    through the n x n Gram problem they share)."""
     g = np.load(os.path.join(golden_dir, "pod_from_data.npz"))
     N, r = int(g["N"]), int(g["r"])
     M = _csr(g, N)
-    d, phi, Mphi, shift = hf.PODProjectorFromData(None, M).construct_subspace(g["u_data"].copy(), r, shifted=shifted, method="hep")
-    tag = "hep_%d" % int(shifted)
+    d, phi, Mphi, shift = hf.PODProjectorFromData(None, M).construct_subspace(g["u_data"].copy(), r, shifted=shifted, method=method)
+    tag = "%s_%d" % (method, int(shifted))
     np.testing.assert_allclose(shift, g["shift_" + tag], atol=1e-14)
     np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-7, atol=1e-12 * g["d_" + tag][0])
     cos = np.abs(np.einsum("ij,ij->j", phi[:, :6], M @ g["phi_" + tag][:, :6]))
@@ -269,8 +273,8 @@ def test_pod_from_data_hep_matches_reference_golden(ctx, golden_dir, shifted):
     assert np.linalg.norm(eye - phi.T @ Mphi) / np.linalg.norm(eye) < 1e-8        # test_PODProjector.py:154-168
     assert np.linalg.norm(M @ phi - Mphi) / np.linalg.norm(Mphi) < 1e-8           # :170-174
     assert (not np.allclose(shift, 0)) == shifted                                 # :176-186
-    with pytest.raises(NotImplementedError):
-        hf.PODProjectorFromData(None, M).construct_subspace(g["u_data"].copy(), r, method="ghep")
+    with pytest.raises(ValueError):
+        hf.PODProjectorFromData(None, M).construct_subspace(g["u_data"].copy(), r, method="lanczos")
 
 
 def test_pod_projector_class(ctx, tmp_path):
