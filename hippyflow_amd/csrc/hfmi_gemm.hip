@@ -54,10 +54,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ part, int mpad, int kpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][TN_LDB]
+  // RING selects the stage length: 2 -> 32 reduction indices per LDS stage, 4 -> 64 (half as many barriers; only
+  // launched when the padded length is a multiple of 64).  The streamed operand always runs one 8-index
+  // iteration ahead in a two-deep register ring.
+  constexpr int BK = (RING == 4) ? 64 : TN_BK;
+  constexpr int LDB = BK + 2;
+  constexpr int CSH = (RING == 4) ? 5 : 4;        // log2(16-byte chunks per column per stage)
+  double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][LDB]
   constexpr int COLS = NT * 16;
   constexpr int NTHR = WAVES * 64;
-  constexpr int CH = COLS * 16;                   // 16-byte chunks per stage
+  constexpr int CH = COLS * (BK / 2);             // 16-byte chunks per stage
   constexpr int NQ = (CH + NTHR - 1) / NTHR;      // chunks per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kk = lane >> 4;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
   const int64_t t_begin = (int64_t)sp * chunk;
   int64_t t_end = t_begin + chunk;
   if (t_end > Npad) t_end = Npad;
-  const int nstages = (int)((t_end - t_begin) / TN_BK);
+  const int nstages = (int)((t_end - t_begin) / BK);
   const int64_t t_last = t_end - 8;  // last iteration base that is safe to fetch
   const int rowbase = rb * (16 * MT * WAVES) + wave * (16 * MT);
 
@@ -83,9 +89,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
   for (int qd = 0; qd < NQ; ++qd) {
     int c = tid + NTHR * qd;
     if (c > CH - 1) c = CH - 1;
-    int col = c >> 4;
+    int col = c >> CSH;
     if (col > k - 1) col = k - 1;
-    b_ptr[qd] = B + (int64_t)col * ldb + (c & 15) * 2;
+    b_ptr[qd] = B + (int64_t)col * ldb + (c & ((1 << CSH) - 1)) * 2;
   }
 
   d4 acc[MT][NT];
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
       const int c = tid + NTHR * qd;
-      if (CH % NTHR == 0 || c < CH) *reinterpret_cast<d2*>(L + (c >> 4) * TN_LDB + (c & 15) * 2) = breg[qd];
+      if (CH % NTHR == 0 || c < CH) *reinterpret_cast<d2*>(L + (c >> CSH) * LDB + (c & ((1 << CSH) - 1)) * 2) = breg[qd];
     }
   };
   auto load_a = [&](d2(&dst)[MT], int64_t t) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
   auto ldsb = [&](d2(&bf)[NT], const double* L, int it) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      bf[nt] = *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * TN_LDB + it * 8 + kk * 2);
+      bf[nt] = *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * LDB + it * 8 + kk * 2);
   };
   auto mma = [&](const d2(&a)[MT], const d2(&bf)[NT]) {
 #pragma unroll
@@ -139,55 +145,26 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     stage_store(lds);
     __syncthreads();
   }
-  // streamed operand: register ring over iterations of 8 reduction indices; RING = 2: prefetch distance 1,
-  // RING = 4: prefetch distance 3
-  d2 bf0[NT], bf1[NT];
-  if constexpr (RING == 2) {
-    d2 a0[MT], a1[MT];
-    load_a(a0, t_begin);
+  // streamed operand: two-deep register ring over iterations of 8 reduction indices (prefetch distance 1); the LDS
+  // fragments of iteration it+1 are read before the MFMAs of iteration it
+  {
+    constexpr int NIT = BK / 8;
+    d2 bf[2][NT];
+    d2 a[2][MT];
+    load_a(a[0], t_begin);
     for (int s = 0; s < nstages; ++s) {
-      const int64_t ts = t_begin + (int64_t)s * TN_BK;
+      const int64_t ts = t_begin + (int64_t)s * BK;
       const bool has_next = s + 1 < nstages;
-      if (has_next) stage_load(ts + TN_BK);
-      const double* L = lds + (s & 1) * COLS * TN_LDB;
-      ldsb(bf0, L, 0);
-      load_a(a1, ts + 8);
-      ldsb(bf1, L, 1);
-      mma(a0, bf0);
-      load_a(a0, ts + 16);
-      ldsb(bf0, L, 2);
-      mma(a1, bf1);
-      load_a(a1, ts + 24);
-      ldsb(bf1, L, 3);
-      mma(a0, bf0);
-      load_a(a0, ts + 32);
-      mma(a1, bf1);
-      if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * TN_LDB);
-      __syncthreads();
-    }
-  } else {
-    d2 a0[MT], a1[MT], a2[MT], a3[MT];
-    load_a(a0, t_begin);
-    load_a(a1, t_begin + 8);
-    load_a(a2, t_begin + 16);
-    for (int s = 0; s < nstages; ++s) {
-      const int64_t ts = t_begin + (int64_t)s * TN_BK;
-      const bool has_next = s + 1 < nstages;
-      if (has_next) stage_load(ts + TN_BK);
-      const double* L = lds + (s & 1) * COLS * TN_LDB;
-      ldsb(bf0, L, 0);
-      load_a(a3, ts + 24);
-      ldsb(bf1, L, 1);
-      mma(a0, bf0);
-      load_a(a0, ts + 32);
-      ldsb(bf0, L, 2);
-      mma(a1, bf1);
-      load_a(a1, ts + 40);
-      ldsb(bf1, L, 3);
-      mma(a2, bf0);
-      load_a(a2, ts + 48);
-      mma(a3, bf1);
-      if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * TN_LDB);
+      if (has_next) stage_load(ts + BK);
+      const double* L = lds + (s & 1) * COLS * LDB;
+      ldsb(bf[0], L, 0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        load_a(a[(it + 1) & 1], ts + 8 * (it + 1));
+        if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
+        mma(a[it & 1], bf[it & 1]);
+      }
+      if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * LDB);
       __syncthreads();
     }
   }
@@ -265,7 +242,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 // Tuning knobs of the MFMA kernels (A/B measurements: environment HFMI_GEMM_WAVES / HFMI_GEMM_RING, or
 // hfmi_tuning_set at run time).
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
-//   ring : register prefetch ring of the streamed operand in tsgemm_tn (2 = distance 1, 4 = distance 3)
+//   ring : stage length of tsgemm_tn (2 = 32 reduction indices per LDS stage, 4 = 64 where the length allows)
 static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
@@ -303,7 +280,7 @@ static inline int tn_mt_max(int nt, int waves) {
 template <int MT, int NT, int WAVES, bool TR, int RING>
 static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t N,
                          int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  const size_t shmem = (size_t)2 * NT * 16 * TN_LDB * sizeof(double);
+  const size_t shmem = (size_t)2 * NT * 16 * ((RING == 4 ? 64 : TN_BK) + 2) * sizeof(double);
   auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, RING>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,
@@ -315,7 +292,8 @@ static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
 template <int MT, int NT, int WAVES>
 static int tn_launch_inst(hfmi_ctx* ctx, bool tr, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
                           int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  const bool ring4 = gemm_ring() == 4;
+  // long (64-index) stages: only when every slice is a whole number of them and the two buffers fit in LDS
+  const bool ring4 = gemm_ring() == 4 && N % 64 == 0 && chunk % 64 == 0 && NT <= 9;
   if (tr) {
     if (ring4) return tn_launch_one<MT, NT, WAVES, true, 4>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
     return tn_launch_one<MT, NT, WAVES, true, 2>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
@@ -387,8 +365,9 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
     }
     nsplit = best;
   }
-  int64_t chunk = round_up((Npad + nsplit - 1) / nsplit, TN_BK);
-  if (chunk < TN_BK) chunk = TN_BK;
+  const int64_t stage_len = (gemm_ring() == 4 && Npad % 64 == 0 && nt <= 9) ? 64 : TN_BK;
+  int64_t chunk = round_up((Npad + nsplit - 1) / nsplit, stage_len);
+  if (chunk < stage_len) chunk = stage_len;
   nsplit = (int)((Npad + chunk - 1) / chunk);
   if (nsplit < 1) nsplit = 1;
   void* partv = nullptr;

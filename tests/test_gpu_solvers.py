@@ -633,3 +633,45 @@ def test_projection_errors_and_downstream_formats(ctx, tmp_path):
     np.testing.assert_allclose(G, np.eye(6) * G[0, 0], atol=1e-12 * G[0, 0])          # orthogonal, equal norms
     np.testing.assert_allclose(np.linalg.norm(pin), 1.0 / (N / (32.0 * 6)), rtol=1e-12)
     np.testing.assert_allclose(np.linalg.norm(pout), 1.0, rtol=1e-12)
+
+
+# ------------------------------------------------------------------ derivative training data
+def test_derivative_datasets_from_stored_jacobians(ctx, tmp_path):
+    """The three derivative products DataGenerator dumps (dataGenerator.py:163-191) from stored Jacobians, and the
+    .npz files compress_dataset writes (:634-655) with the key names the training scripts load."""
+    rng = np.random.default_rng(5)
+    ndata, q, N, r_in, r_out, rM = 6, 24, 1500, 9, 7, 5
+    # numerically rank-rM Jacobians (graded singular values + 1e-11 noise): the randomized SVD with rM probe vectors
+    # and no oversampling -- what the reference runs -- is then exact to the noise level
+    left = np.linalg.qr(rng.standard_normal((ndata, q, rM)))[0] * np.logspace(1, -1, rM)
+    J = left @ np.linalg.qr(rng.standard_normal((N, rM)))[0].T + 1e-11 * rng.standard_normal((ndata, q, N))
+    Psi = np.linalg.qr(rng.standard_normal((N, r_in)))[0]
+    Phi = np.linalg.qr(rng.standard_normal((q, r_out)))[0]
+    MPhi = Phi * np.linspace(1.0, 2.0, q)[:, None]                      # a diagonal "mass" on the outputs
+    JPsi = hf.jacobian_times_input_basis(J, Psi)
+    assert JPsi.shape == (ndata, q, r_in)
+    assert rel(JPsi, np.einsum("iqn,nr->iqr", J, Psi)) < 1e-13
+    JsP = hf.jacobian_transpose_times_output_basis(J, MPhi)
+    assert JsP.shape == (ndata, N, r_out)
+    assert rel(JsP, np.einsum("iqn,qr->inr", J, MPhi)) < 1e-13
+    U, sig, V = hf.jacobian_svds(J, rM, seed=3)
+    assert U.shape == (ndata, q, rM) and sig.shape == (ndata, rM) and V.shape == (ndata, N, rM)
+    for i in range(ndata):
+        s_ref = np.linalg.svd(J[i], compute_uv=False)[:rM]
+        np.testing.assert_allclose(sig[i], s_ref, rtol=1e-7)
+        assert np.linalg.norm(U[i].T @ U[i] - np.eye(rM)) < 1e-10 and np.linalg.norm(V[i].T @ V[i] - np.eye(rM)) < 1e-10
+        assert np.linalg.norm(J[i] @ V[i] - U[i] * sig[i]) / np.linalg.norm(sig[i]) < 1e-6
+    m_data, q_data = rng.standard_normal((ndata, N)), rng.standard_normal((ndata, q))
+    d = str(tmp_path) + "/"
+    hf.derivative_dataset(d, J, m_data, q_data, output_decoder=Phi, output_encoder=MPhi)
+    hf.derivative_dataset(d, J, input_decoder=Psi, input_encoder=Psi)
+    hf.derivative_dataset(d, J, svd_rank=rM, seed=3)
+    mq = np.load(d + "mq_data.npz")
+    assert sorted(mq.files) == ["m_data", "q_data"] and mq["m_data"].shape == (ndata, N)
+    f = np.load(d + "JstarPhi_data.npz")
+    assert sorted(f.files) == ["JstarPhi_data", "MPhi", "Phi"] and rel(f["JstarPhi_data"], JsP) == 0.0
+    f = np.load(d + "JPsi_data.npz")
+    assert sorted(f.files) == ["JPsi_data", "Psi", "input_encoder"] and rel(f["JPsi_data"], JPsi) == 0.0
+    f = np.load(d + "Jsvd_data.npz")
+    assert sorted(f.files) == ["U_data", "V_data", "sigma_data"]
+    np.testing.assert_allclose(f["sigma_data"], sig, rtol=1e-12)         # same seed -> same Omega -> same factors
