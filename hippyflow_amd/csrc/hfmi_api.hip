@@ -1076,21 +1076,38 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   Y.nvec = k;
   // power iterations: Q <- (B^-1) A Q, starting from Omega (never modified)
   const hfmi_block* cur = Omega;
-  for (int it = 0; it < s; ++it) {
-    if (Binv) {
-      HFMI_TRY(hfmi_op_apply(A, cur, &Y, 0));
-      HFMI_TRY(hfmi_op_apply(Binv, &Y, &Q, 0));
-      cur = &Q;
-    } else {
-      hfmi_block* dst = (cur == &Q) ? &Y : &Q;
-      HFMI_TRY(hfmi_op_apply(A, cur, dst, 0));
-      cur = dst;
+  auto power_iterations = [&]() -> int {
+    cur = Omega;
+    for (int it = 0; it < s; ++it) {
+      if (Binv) {
+        HFMI_TRY(hfmi_op_apply(A, cur, &Y, 0));
+        HFMI_TRY(hfmi_op_apply(Binv, &Y, &Q, 0));
+        cur = &Q;
+      } else {
+        hfmi_block* dst = (cur == &Q) ? &Y : &Q;
+        HFMI_TRY(hfmi_op_apply(A, cur, dst, 0));
+        cur = dst;
+      }
     }
-  }
+    return HFMI_OK;
+  };
+  HFMI_TRY(power_iterations());
   hfmi_block* Qp = const_cast<hfmi_block*>(cur);           // holds the block to orthogonalise
   hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
-  const int method = (flags & 2) ? HFMI_QR_MGS : HFMI_QR_AUTO;
-  HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, method, nullptr));
+  if (flags & 2) {
+    HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, HFMI_QR_MGS, nullptr));
+  } else {
+    // Cholesky-QR in place WITHOUT the safety copy hfmi_borth_qr(AUTO) keeps (a pass over N x k): if a column turns
+    // out to be numerically dependent, the block is recomputed from Omega (deterministic, every rank takes the same
+    // branch) and handed to the reference's Gram-Schmidt rule
+    const int qs = hfmi_borth_qr(Qp, B, nullptr, nullptr, HFMI_QR_CHOL, nullptr);
+    if (qs == HFMI_ERR_NUMERIC) {
+      HFMI_TRY(power_iterations());
+      HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, HFMI_QR_MGS, nullptr));
+    } else if (qs != HFMI_OK) {
+      return qs;
+    }
+  }
   if (op_has_gram_form(A) && !(flags & 4)) {
     HFMI_TRY(op_rayleigh_quotient_gram(A, Qp, SM_T));
   } else {
