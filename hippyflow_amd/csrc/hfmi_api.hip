@@ -88,6 +88,8 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_status, hipEventDisableTiming));
   HIP_TRY(hipMalloc((void**)&c->small, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->small, 0, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double), c->stream));
   HIP_TRY(hipMalloc((void**)&c->status_dev, sizeof(hfmi_status_words)));
@@ -115,6 +117,8 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   (void)hipHostFree(ctx->status_host);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  (void)hipEventDestroy(ctx->ev_status);
+  (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return HFMI_OK;
@@ -360,10 +364,30 @@ static int read_back(hfmi_ctx* ctx, const double* dev, size_t count, double* hos
   memcpy(host, pin, count * sizeof(double));
   return HFMI_OK;
 }
+// Split read-back: `begin` snapshots the status words at the current point of the main stream (event + copy on the
+// auxiliary stream), `finish` waits for that copy only -- kernels queued on the main stream in between keep running
+// while the host looks at the words and decides what to launch next.
+static int read_status_begin(hfmi_ctx* ctx) {
+  HIP_TRY(hipEventRecord(ctx->ev_status, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_status, 0));
+  HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->aux_stream));
+  return HFMI_OK;
+}
+static void print_status_dbg(const hfmi_status_words* out);
+static int read_status_finish(hfmi_ctx* ctx, hfmi_status_words* out) {
+  HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+  *out = *ctx->status_host;
+  print_status_dbg(out);
+  return HFMI_OK;
+}
 static int read_status(hfmi_ctx* ctx, hfmi_status_words* out) {
   HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   *out = *ctx->status_host;
+  print_status_dbg(out);
+  return HFMI_OK;
+}
+static void print_status_dbg(const hfmi_status_words* out) {
   static const bool dbg = getenv("HFMI_DEBUG_TIMING") != nullptr;
   if (dbg)
     fprintf(stderr, "[hfmi timing] %s cycles: %lld %lld %lld %lld\n", out->tick[4] ? "jacobi(total,phase1,phase2,sweeps)" : "chol(load,chol,inv,out)",
@@ -371,7 +395,6 @@ static int read_status(hfmi_ctx* ctx, hfmi_status_words* out) {
   if (dbg && !out->tick[4])
     fprintf(stderr, "[hfmi timing]   chol status: min pivot ratio %.3e, input defect %.3e, shifted %d\n", out->min_pivot_ratio,
             out->gram_dev, out->shifted);
-  return HFMI_OK;
 }
 
 extern "C" int hfmi_block_norms(const hfmi_block* b, double* host_norms) {
@@ -833,10 +856,14 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     HFMI_TRY(launch_tsgemm_tn(ctx, Q->p, Q->ld, k, right->p, right->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_GRAM), SM_LD, 1, 0));
     const int rtot_mode = (passes == 0) ? 1 : 2;   // always track R = R_p ... R_1: its diagonal exposes dependent columns
     HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol));
-    hfmi_status_words st;
-    HFMI_TRY(read_status(ctx, &st));
-    if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
+    // snapshot the status words on the auxiliary stream and enqueue Q <- Q R^-1 BEFORE waiting for them: the host
+    // round trip then overlaps the contraction.  If the factorisation failed, R^-1 was never written by this pass and Q is
+    // about to be discarded anyway (the callers restore / recompute the block on HFMI_ERR_NUMERIC).
+    HFMI_TRY(read_status_begin(ctx));
     HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
+    hfmi_status_words st;
+    HFMI_TRY(read_status_finish(ctx, &st));
+    if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
     ++passes;
     // The input of this pass had orthonormality defect st.gram_dev (column-scaled).  If it was already
     // small and no shift was needed, the output is orthonormal to round-off: done.

@@ -64,6 +64,8 @@ struct hfmi_ctx {
   hipStream_t stream;
   bool own_stream;
   hipEvent_t ev0, ev1;
+  hipStream_t aux_stream;         // status read-backs that overlap work queued on `stream`
+  hipEvent_t ev_status;
   int num_cus;
   void* ws[WS_NSLOTS];
   size_t ws_bytes[WS_NSLOTS];
