@@ -244,6 +244,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
 //   ring : stage length of tsgemm_tn (2 = 32 reduction indices per LDS stage, 4 = 64 where the length allows)
 static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
+static int g_nn_tt = 0;                              // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
   if (g_waves) return;
@@ -266,6 +267,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   else if (key && !strcmp(key, "ring") && (value == 2 || value == 4)) g_ring = value;
   else if (key && !strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
+  else if (key && !strcmp(key, "nn_tt") && value >= 0 && value <= 3) g_nn_tt = value;
   else if (key && !strcmp(key, "ss_percu") && value >= 1 && value <= 4) tsgemm_ss_set_percu(value);
   else HFMI_FAIL(HFMI_ERR_INVALID, "tuning_set: unknown key/value");
   return HFMI_OK;
@@ -684,6 +686,9 @@ static int nn_launch_w4(hfmi_ctx* ctx, const double* A, int64_t lda, int m, cons
   const double c0 = nn_plan(ctx, 64 * TMAX, m, r, N, 1.0, &ms0);
   const double c1 = (T1 != TMAX) ? nn_plan(ctx, 64 * T1, m, r, N, 0.98, &ms1) : 1e300;
   const double c2 = (T2 != T1) ? nn_plan(ctx, 64 * T2, m, r, N, 0.96, &ms2) : 1e300;
+  if (g_nn_tt == 1) return nn_launch_inst<TMAX, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms0);
+  if (g_nn_tt == 2) return nn_launch_inst<T1, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms1);
+  if (g_nn_tt == 3) return nn_launch_inst<T2, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms2);
   if (c0 <= c1 && c0 <= c2) return nn_launch_inst<TMAX, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms0);
   if (c1 <= c2) return nn_launch_inst<T1, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms1);
   return nn_launch_inst<T2, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms2);

@@ -195,9 +195,13 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
 /* per-launch HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from the
  * timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by events on
  * the context's stream.  end() synchronises and returns one record per distinct (kernel, shape):
- * kind[g] 0 = k_tsgemm_tn, 1 = k_tsgemm_nn; shape[3*g..] = (short-side rows m, columns k, long axis N);
+ * kind[g] 0 = k_tsgemm_tn (or k_tsgemm_ss for skinny x skinny shapes), 1 = k_tsgemm_nn; shape[3*g..] = (short-side rows m, columns k, long axis N);
  * total milliseconds, launches, and the ALGORITHMIC flops / bytes of one launch. */
-/* kernel tuning knobs for A/B measurements: ("waves", 4|8), ("ring", 2|4); see csrc/hfmi_gemm.hip */
+/* kernel tuning knobs for in-process A/B measurements (defaults are the measured winners; scripts/gemm_ab.py,
+ * scripts/ss_ab.py, scripts/nn_tt_probe.py): ("waves", 8|4|44) tsgemm_tn workgroup shape (44 = two 4-wave workgroups
+ * per CU); ("ring", 2|4) tsgemm_tn LDS stage of 32 | 64 reduction indices; ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
+ * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("ss", 0|1) route skinny x skinny contractions to
+ * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized. */
 int hfmi_tuning_set(const char* key, int value);
 int hfmi_profile_begin(hfmi_ctx* ctx);
 int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int* kind, int64_t* shape, double* ms,
