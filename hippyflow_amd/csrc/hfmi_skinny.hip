@@ -201,15 +201,32 @@ __global__ __launch_bounds__(SS_THREADS, (TPW <= 4 ? 4 : 2)) void k_tsgemm_ss(
     __syncthreads();
   }
 
-  // this wave's output tiles: linear ids wave, wave+8, ...; only the last one can fall outside the tile grid
-  const int ntiles = rt * ct;
+  // this wave's output tiles: linear ids wave, wave+8, ...; only the last one can fall outside the tile list.
+  // Two distinct operands: the full rt x ct grid, row-major.  One operand (Gram matrix): only the tiles r <= c,
+  // row r holding rt - r of them -- the mirror images are written by the epilogue, so Q^T Q costs rt (rt + 1) / 2
+  // instead of rt^2 tiles of MFMAs and is symmetric to the last bit.
+  const int ntiles = same ? rt * (rt + 1) / 2 : rt * ct;
   const bool last_valid = wave + 8 * (TPW - 1) < ntiles;
+  auto tile_rc = [&](int id, int& r, int& c) {
+    if (same) {
+      r = 0;
+      while (id >= rt - r) {
+        id -= rt - r;
+        ++r;
+      }
+      c = r + id;
+    } else {
+      r = id / ct;
+      c = id - r * ct;
+    }
+  };
   int toa[TPW], tob[TPW];
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
     int id = wave + 8 * ti;
     if (id > ntiles - 1) id = ntiles - 1;
-    const int r = id / ct, c = id - r * ct;
+    int r, c;
+    tile_rc(id, r, c);
     toa[ti] = r * 32;
     tob[ti] = (bcol0 + c * 16) * 2;
   }
@@ -231,9 +248,14 @@ __global__ __launch_bounds__(SS_THREADS, (TPW <= 4 ? 4 : 2)) void k_tsgemm_ss(
   for (int ti = 0; ti < TPW; ++ti) {
     const int id = wave + 8 * ti;
     if (id < ntiles) {
-      const int r = id / ct, c = id - r * ct;
+      int r, c;
+      tile_rc(id, r, c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) P[(int64_t)(r * 16 + kk + 4 * e) * kpad + c * 16 + r16] = acc[ti][e];
+      if (same && r != c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P[(int64_t)(c * 16 + r16) * kpad + r * 16 + kk + 4 * e] = acc[ti][e];
+      }
     }
   }
 }
@@ -269,7 +291,7 @@ int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   const int64_t Npad = round_up(N, SS_BK);
   if (lda % 32 != 0 || ldb % 32 != 0 || lda < Npad || ldb < Npad)
     HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_ss: leading dimensions must be multiples of 32 and >= round_up(N,32)");
-  const int tpw = (rt * ct + 7) / 8;
+  const int tpw = ((same ? rt * (rt + 1) / 2 : rt * ct) + 7) / 8;
   const int nq = (ctot + 31) / 32;  // staged columns are padded to 32 (one 16-byte chunk per thread per 32 columns)
   // unpadded stage buffers: one for the HBM-bound variants (PF = 2), two plus the column pointer table otherwise
   const size_t stage_bytes = (size_t)nq * 32 * SS_BK * sizeof(double);
@@ -291,6 +313,10 @@ int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nsplit * mpad * kpad * sizeof(double), &partv));
   double* part = (double*)partv;
   const int pidx = prof_start(ctx, 0, m, k, N);
+  if (same && pidx >= 0) {   // symmetric output from ONE operand: algorithmic work N k (k + 1) flops, 8 (N k + k^2) bytes
+    ctx->prof[pidx].flops = (double)N * k * (k + 1);
+    ctx->prof[pidx].bytes = 8.0 * ((double)N * k + (double)k * k);
+  }
   int rc = HFMI_ERR_INVALID;
 #define SS_CASE(T, Q)                                                                                              \
   if (tpw == T && nq == Q)                                                                                         \
@@ -301,6 +327,8 @@ int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   SS_CASE(2, 5) SS_CASE(2, 6) SS_CASE(3, 5) SS_CASE(3, 6) SS_CASE(4, 3) SS_CASE(4, 5) SS_CASE(4, 6) SS_CASE(4, 7)
   SS_CASE(5, 3) SS_CASE(5, 6) SS_CASE(5, 7) SS_CASE(6, 7) SS_CASE(7, 4) SS_CASE(7, 7) SS_CASE(7, 8) SS_CASE(8, 4)
   SS_CASE(8, 8) SS_CASE(9, 9) SS_CASE(10, 9) SS_CASE(11, 5) SS_CASE(11, 9) SS_CASE(13, 5)
+  // one-operand (Gram) tile lists: rt (rt + 1) / 2 tiles, rt * 16 staged columns
+  SS_CASE(3, 3) SS_CASE(4, 4) SS_CASE(5, 4) SS_CASE(6, 5) SS_CASE(7, 5)
   { hfmi_set_error("tsgemm_ss: no instance for tiles/wave=%d chunks/thread=%d", tpw, nq); }
 #undef SS_CASE
   HFMI_TRY(rc);
