@@ -821,7 +821,10 @@ extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, in
 }
 
 // ------------------------------------------------------------------ QR
-static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* passes_out) {
+// deferred (optional): if non-null and B == null, the LAST pass (the one whose input is already orthonormal to 1e-2 and
+// needs no shift) does not apply its R^-1: *deferred = true and R^-1 stays in SM_RINV for the caller to fold into
+// the small matrices downstream (Q = Q_in R^-1 is never formed: one N x k x k contraction less).
+static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* passes_out, bool* deferred = nullptr) {
   hfmi_ctx* ctx = Q->ctx;
   const int64_t N = Q->N;
   const int k = Q->nvec;
@@ -856,14 +859,27 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     HFMI_TRY(launch_tsgemm_tn(ctx, Q->p, Q->ld, k, right->p, right->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_GRAM), SM_LD, 1, 0));
     const int rtot_mode = (passes == 0) ? 1 : 2;   // always track R = R_p ... R_1: its diagonal exposes dependent columns
     HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol));
-    // snapshot the status words on the auxiliary stream and enqueue Q <- Q R^-1 BEFORE waiting for them: the host
-    // round trip then overlaps the contraction.  If the factorisation failed, R^-1 was never written by this pass and Q is
-    // about to be discarded anyway (the callers restore / recompute the block on HFMI_ERR_NUMERIC).
-    HFMI_TRY(read_status_begin(ctx));
-    HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
     hfmi_status_words st;
-    HFMI_TRY(read_status_finish(ctx, &st));
-    if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
+    if (deferred && !B && passes >= 1) {
+      // candidate last pass: look at the status words first (the read-back is not hidden here) and stop WITHOUT
+      // applying R^-1 if this pass would have been the last one anyway
+      HFMI_TRY(read_status(ctx, &st));
+      if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
+      if (!st.shifted && st.gram_dev < 1e-2) {
+        ++passes;
+        *deferred = true;
+        break;
+      }
+      HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
+    } else {
+      // snapshot the status words on the auxiliary stream and enqueue Q <- Q R^-1 BEFORE waiting for them: the host
+      // round trip then overlaps the contraction.  If the factorisation failed, R^-1 was never written by this pass
+      // and Q is about to be discarded anyway (the callers restore / recompute the block on HFMI_ERR_NUMERIC).
+      HFMI_TRY(read_status_begin(ctx));
+      HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
+      HFMI_TRY(read_status_finish(ctx, &st));
+      if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
+    }
     ++passes;
     // The input of this pass had orthonormality defect st.gram_dev (column-scaled).  If it was already
     // small and no shift was needed, the output is orthonormal to round-off: done.
@@ -1051,7 +1067,9 @@ extern "C" int hfmi_svd_small(hfmi_ctx* ctx, const double* host_R, int k, double
 // second all-reduce of the solve shrinks from N x k to k x k.
 static bool op_has_gram_form(const hfmi_op* A) { return A->kind == OP_SNAPSHOT_GRAM || A->kind == OP_JTJ; }
 
-static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T) {
+// fold_rinv: Q stands for Q R^-1 with R^-1 in SM_RINV (deferred last QR pass): X (Q R^-1) = (X Q) R^-1 is applied to
+// the small m x k intermediate instead of the N x k block.
+static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T, bool fold_rinv = false) {
   hfmi_ctx* ctx = A->ctx;
   const hfmi_block& X = A->X;
   if (X.N != Q->N) HFMI_FAIL(HFMI_ERR_INVALID, "operator acts on vectors of length %lld, got %lld", (long long)X.N, (long long)Q->N);
@@ -1064,6 +1082,7 @@ static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T
   double* Gc2 = gam ? Gc + ldm * k : Gc;
   HFMI_TRY(launch_tsgemm_tn(ctx, X.p, X.ld, m, Q->p, Q->ld, k, X.N, 1.0, 0.0, Gc, 1, ldm, 0));
   HFMI_TRY(launch_zero_pad(ctx, Gc, m, k, ldm));
+  if (fold_rinv) HFMI_TRY(launch_tsgemm_nn(ctx, Gc, ldm, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Gc, ldm, m));
   if (gam) {
     HFMI_TRY(launch_gamma_apply_cm(ctx, Gc, Gc2, ldm, A->ndata, A->q, k, A->gamma_inv, (int)round_up(A->q, 16)));
     HFMI_TRY(launch_zero_pad(ctx, Gc2, m, k, ldm));
@@ -1119,6 +1138,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     return HFMI_OK;
   };
   HFMI_TRY(power_iterations());
+  bool deferred = false;                                   // last Cholesky-QR pass left as R^-1 in SM_RINV
   hfmi_block* Qp = const_cast<hfmi_block*>(cur);           // holds the block to orthogonalise
   hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
   if (flags & 2) {
@@ -1127,8 +1147,10 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     // Cholesky-QR in place WITHOUT the safety copy hfmi_borth_qr(AUTO) keeps (a pass over N x k): if a column turns
     // out to be numerically dependent, the block is recomputed from Omega (deterministic, every rank takes the same
     // branch) and handed to the reference's Gram-Schmidt rule
-    const int qs = hfmi_borth_qr(Qp, B, nullptr, nullptr, HFMI_QR_CHOL, nullptr);
+    const bool gram_path = op_has_gram_form(A) && !(flags & 4);
+    const int qs = qr_chol(Qp, B, nullptr, false, nullptr, gram_path ? &deferred : nullptr);
     if (qs == HFMI_ERR_NUMERIC) {
+      deferred = false;
       HFMI_TRY(power_iterations());
       HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, HFMI_QR_MGS, nullptr));
     } else if (qs != HFMI_OK) {
@@ -1136,7 +1158,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     }
   }
   if (op_has_gram_form(A) && !(flags & 4)) {
-    HFMI_TRY(op_rayleigh_quotient_gram(A, Qp, SM_T));
+    HFMI_TRY(op_rayleigh_quotient_gram(A, Qp, SM_T, deferred));
   } else {
     // T = (AQ)^T Q as the reference forms it
     HFMI_TRY(hfmi_op_apply(A, Qp, AQ, 0));
@@ -1146,7 +1168,12 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
   HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1));
-  HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_V), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
+  if (deferred) {   // U = (Q R^-1) V = Q (R^-1 V)
+    HFMI_TRY(launch_small_matmul(ctx, k, r, SM_RINV, SM_V, SM_TMP2));
+    HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_TMP2), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
+  } else {
+    HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_V), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
+  }
   hfmi_status_words st;
   HFMI_TRY(read_status(ctx, &st));
   if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: Jacobi eigensolve did not converge (off-diagonal %.2e)", st.offdiag);

@@ -193,6 +193,8 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
 // T (k x k) -> eigenvalues (sorted descending) into dvals (device, k), eigenvectors into slot_v (columns).
 int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs);
 int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);
+// slot_c (k x r, zero padded to 16 columns) = slot_a (k x k) * slot_b[:, :r]
+int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int slot_c);
 // R (k x k, slot_r) = U diag(s) V^T: singular values descending in svals (device), U -> slot_u, V -> slot_v (columns)
 int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, double* svals);
 

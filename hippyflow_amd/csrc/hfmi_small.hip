@@ -676,6 +676,24 @@ __global__ void k_small_identity(double* M, int ld, int k) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < k * ld) M[e] = ((e / ld) == (e % ld)) ? 1.0 : 0.0;
 }
+// C (k x r, zero padded to a multiple of 16 columns) = A (k x k) * B[:, :r], all row-major small-arena matrices
+__global__ void k_small_matmul(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ Cm, int ld,
+                               int k, int r, int rpad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= rpad) return;
+  double s = 0.0;
+  if (j < r)
+    for (int l = 0; l < k; ++l) s += A[i * ld + l] * B[l * ld + j];
+  Cm[i * ld + j] = s;
+}
+int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int slot_c) {
+  const int rpad = (r + 15) & ~15;
+  hipLaunchKernelGGL(k_small_matmul, dim3((rpad + 63) / 64, k), dim3(64), 0, ctx->stream, sm_ptr(ctx, slot_a), sm_ptr(ctx, slot_b),
+                     sm_ptr(ctx, slot_c), SM_LD, k, r, rpad);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
 int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot) {
   hipLaunchKernelGGL(k_small_identity, dim3((k * SM_LD + 255) / 256), dim3(256), 0, ctx->stream, sm_ptr(ctx, slot), SM_LD, k);
   HIP_TRY(hipGetLastError());
