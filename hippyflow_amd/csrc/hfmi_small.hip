@@ -87,11 +87,8 @@ __device__ __forceinline__ bool tri_cell(int e, int n, float inv_np1, int& row, 
   return r2 != r;
 }
 
-// EPT > 0: the upper triangle is distributed over the threads (EPT entries each, fixed for the whole kernel) and
-// lives in REGISTERS; a column step of the factorisation / row step of the inverse publishes one row through LDS,
-// takes one barrier and updates the owned entries with two LDS reads and two flops each -- no per-entry index
-// arithmetic.  EPT = 0: generic path for k > 139 (matrix in a global scratch slot).
-template <int EPT>
+// Generic path (any k <= 256; the matrix in LDS when it fits, else in a global scratch slot -- the pointer is then
+// generic and the accesses are FLAT: this kernel is the fallback, k_chol_reg below is the fast path for k <= 139).
 __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __restrict__ G, int ldg, int k,
                                                             double* __restrict__ Rout, double* __restrict__ Rinv,
                                                             double* __restrict__ Rtot, double* __restrict__ Rtmp,
@@ -106,18 +103,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   double* invd = diag0 + 256;                          // 1 / R_jj
   double* ird0 = invd + 256;                           // 1 / (original diagonal + shift): pivot-ratio bookkeeping
   double* lds_m = ird0 + 256;
-  // NOTE: a pointer that may be LDS or global (a runtime select) compiles to FLAT loads/stores, which are several
-  // times slower than ds_read/ds_write and tie vmcnt to lgkmcnt; the register path therefore only exists for the
-  // LDS-resident matrix and names the LDS pointer directly.
-  int ldm;
-  double* M;
-  if constexpr (EPT > 0) {
-    ldm = k | 1;
-    M = lds_m;
-  } else {
-    ldm = use_lds ? (k | 1) : ldo;
-    M = use_lds ? lds_m : gscratch;
-  }
+  const int ldm = use_lds ? (k | 1) : ldo;
+  double* M = use_lds ? lds_m : gscratch;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   __shared__ int s_break;
@@ -143,94 +130,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   tr = block_sum(tr, red);
   tk1 = clock64();
 
-  // owned entries (row oi <= col oc) of the register path.  The upper triangle is enumerated bottom row first
-  // (row k-1: 1 cell, row k-2: 2 cells, ...) and cell e belongs to thread e % nthr, slot q = e / nthr: slot q of
-  // ALL threads is one band of adjacent rows [bmin[q], bmax[q]], so a band that is finished (factorisation: rows
-  // <= j) or not yet started (inverse: rows >= l) is skipped by a wave-uniform branch, and the work of a step is
-  // spread evenly over the waves.
-  constexpr int NE = EPT > 0 ? EPT : 1;
-  int oi[NE], oc[NE], li[NE], bmin[NE], bmax[NE];   // li: row index clamped into the matrix (loads of idle slots)
-  double v[NE];
-  if constexpr (EPT > 0) {
-    const int total = k * (k + 1) / 2;
-    auto cell_row = [&](int e) {  // rows counted from the bottom: m (m + 1) / 2 <= e < (m + 1) (m + 2) / 2
-      int m = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-      while (m * (m + 1) / 2 > e) --m;
-      while ((m + 1) * (m + 2) / 2 <= e) ++m;
-      return m;
-    };
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int e = tid + q * nthr;
-      const bool ok = e < total;
-      const int m = cell_row(ok ? e : 0);
-      oi[q] = ok ? k - 1 - m : (1 << 20);   // idle slot: a row index no step ever matches
-      oc[q] = ok ? (k - 1 - m) + (e - m * (m + 1) / 2) : 0;
-      li[q] = ok ? k - 1 - m : 0;
-      v[q] = 0.0;
-      const int e_first = q * nthr, e_last = (q + 1) * nthr - 1 < total - 1 ? (q + 1) * nthr - 1 : total - 1;
-      bmax[q] = e_first < total ? k - 1 - cell_row(e_first) : -1;
-      bmin[q] = e_first < total ? k - 1 - cell_row(e_last) : 0;
-    }
-  }
-
   int shifted = 0, failed = 0;
   double min_ratio = 1e300;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const double shift = attempt ? shift_rel * tr : 0.0;
-    if constexpr (EPT > 0) {
-      if (tid == 0) s_break = 0;
-      for (int i = tid; i < k; i += nthr) ird0[i] = (diag0[i] + shift > 0.0) ? 1.0 / (diag0[i] + shift) : 0.0;
-#pragma unroll
-      for (int q = 0; q < NE; ++q)
-        if (oi[q] < k) {
-          v[q] = 0.5 * (G[oi[q] * ldg + oc[q]] + G[oc[q] * ldg + oi[q]]);
-          if (oi[q] == oc[q]) v[q] += shift;
-        }
-      double ratio_local = 1e300;
-      // Unscaled (LDL^T-style) right-looking factorisation: U[i][c] = G[i][c] - sum_{j<i} U[j][i] U[j][c] / U[j][j];
-      // R = diag(U)^{-1/2} U is formed by one scaling pass at the end.
-      for (int j = 0; j < k; ++j) {
-#pragma unroll
-        for (int q = 0; q < NE; ++q)
-          if (bmin[q] <= j && j <= bmax[q] && oi[q] == j) M[j * ldm + oc[q]] = v[q];   // row j is final: publish it
-        __syncthreads();
-        const double piv = M[j * ldm + j];
-        const double ref = diag0[j] + shift;
-        if (!(piv > pivot_tol * ref) || !(ref > 0.0)) {  // uniform decision: every thread reads the same words
-          if (tid == 0) s_break = 1;
-          break;
-        }
-        const double inv = fast_rsqrt(piv);
-        const double rp = inv * inv;
-        if (tid == 0) {
-          ratio_local = fmin(ratio_local, piv * ird0[j]);
-          invd[j] = inv;
-        }
-        const double* rj = M + j * ldm;
-        // branch-free per entry (a select on the scale factor) with all LDS reads issued before the first use:
-        // per-entry branches would serialise NE load -> fma chains; the band test is wave-uniform
-        double xa[NE], xb[NE];
-#pragma unroll
-        for (int q = 0; q < NE; ++q)
-          if (bmax[q] > j) {
-            xa[q] = rj[li[q]];
-            xb[q] = rj[oc[q]];
-          }
-#pragma unroll
-        for (int q = 0; q < NE; ++q)
-          if (bmax[q] > j) v[q] -= xa[q] * ((oi[q] > j && oi[q] < k) ? rp : 0.0) * xb[q];
-      }
-      __syncthreads();
-      if (!s_break) {
-        min_ratio = ratio_local;
-        break;
-      }
-      if (attempt == 0) shifted = 1;
-      else failed = 1;
-      __syncthreads();
-      continue;
-    }
     for (int i = wave; i < k; i += nw)
       for (int j = lane; j < k; j += 64) {
         double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
@@ -299,43 +202,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   // R out (upper triangle, zeros below)
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
-  if constexpr (EPT > 0) {
-    // Inverse X = R^-1, right-looking and bottom-up: once row l of X is final it is published (two alternating LDS
-    // rows, aliasing the dead diag0 / ird0 arrays) and every owned entry (i, c), i < l <= c, accumulates
-    // R[i][l] x_lc; x_ic = -acc / R_ii, x_ii = 1 / R_ii.  One barrier per row; the inverse never touches LDS
-    // except for the published row and the R entries it multiplies.
-    double* xrow0 = diag0;
-    double* xrow1 = ird0;
-#pragma unroll
-    for (int q = 0; q < NE; ++q) v[q] = 0.0;
-    for (int l = k - 1; l >= 0; --l) {
-      double* xr = (l & 1) ? xrow1 : xrow0;
-#pragma unroll
-      for (int q = 0; q < NE; ++q)
-        if (bmin[q] <= l && l <= bmax[q] && oi[q] == l) {
-          const double x = (oc[q] == l) ? invd[l] : -invd[l] * v[q];
-          v[q] = x;
-          xr[oc[q]] = x;
-        }
-      __syncthreads();
-      double xa[NE], xb[NE];
-#pragma unroll
-      for (int q = 0; q < NE; ++q)
-        if (bmin[q] < l) {  // wave-uniform: bands made of rows >= l have nothing to accumulate yet
-          xa[q] = M[li[q] * ldm + l];
-          xb[q] = xr[oc[q]];
-        }
-#pragma unroll
-      for (int q = 0; q < NE; ++q)
-        if (bmin[q] < l) v[q] += ((oi[q] < l && oc[q] >= l) ? xa[q] : 0.0) * xb[q];
-    }
-    tk3 = clock64();
-#pragma unroll
-    for (int q = 0; q < NE; ++q)
-      if (oi[q] < k) Rinv[oi[q] * ldo + oc[q]] = v[q];
-    for (int i = wave; i < k; i += nw)
-      for (int j = lane; j < i; j += 64) Rinv[i * ldo + j] = 0.0;
-  } else {
   // Inverse X = R^-1 by back substitution, one ROW per barrier phase (bottom up): x_cc = 1/R_cc and, for i < c,
   // x_ic = -(sum_{l=i+1..c} R[i][l] x_lc) / R_ii.  All columns c > i of row i are independent: one 8-lane group per
   // column, both factors of the dot product contiguous along l (x is kept in the unused strictly lower triangle,
@@ -362,7 +228,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_chol_inv(const double* __rest
   tk3 = clock64();
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < k; j += 64) Rinv[i * ldo + j] = (j > i) ? M[j * ldm + i] : (j == i ? invd[i] : 0.0);
-  }
   // diagonal of the running product R = R_p ... R_1 (its ratio to the original column norms exposes
   // numerically dependent columns); the full product only when the caller wants R
   for (int i = tid; i < k; i += nthr) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * M[i * ldm + i];
@@ -662,8 +527,8 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
     else CHOL_REG(20);
 #undef CHOL_REG
   } else {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k_chol_inv<0>, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
+    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
                        sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,
                        rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_TMP), use_lds, sm_ptr(ctx, SM_AUX),
                        sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);
