@@ -192,7 +192,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 // the slices y, y+RY, y+2RY, ... (four independent running sums, so four loads are in flight), the RY lane totals
 // are combined through LDS in a fixed order -> deterministic, and the sum over hundreds of slices is no longer
 // one serial chain per output element (that chain used to cost more than the contraction itself for k <= 138).
-constexpr int RY = 16;
+// RY = 16 for the many-slice launches of tsgemm_ss, 4 when there are only a few slices (big tn launches: every
+// lane then has work and the kernel is a plain HBM stream).
+template <int RY>
 __global__ __launch_bounds__(64 * RY) void k_reduce_partials(const double* __restrict__ part, int nsplit, int64_t pstride,
                                                              int inner_ld, int tr, int m, int k, double scale, double beta,
                                                              double* __restrict__ C, int64_t rs, int64_t cs) {
@@ -227,12 +229,61 @@ __global__ __launch_bounds__(64 * RY) void k_reduce_partials(const double* __res
   }
 }
 
+// Flat variant for a row-major result whose row stride equals the partial's (C = G of an operator application,
+// m x kpad): the m * kpad entries are one contiguous array per slice, so every lane streams (no 74-of-128 lane waste
+// on a narrow fast axis); pad columns j >= k are written as zeros (tsgemm_nn reads G as a zero-padded small matrix).
+template <int RY>
+__global__ __launch_bounds__(64 * RY) void k_reduce_flat(const double* __restrict__ part, int nsplit, int64_t pstride,
+                                                         int64_t total, int kpad, int k, double scale, double beta,
+                                                         double* __restrict__ C) {
+  __shared__ double sh[RY][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + tx;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (idx < total) {
+    const double* p = part + idx;
+    int sp = ty;
+    for (; sp + 3 * RY < nsplit; sp += 4 * RY) {
+      s0 += p[(int64_t)sp * pstride];
+      s1 += p[(int64_t)(sp + RY) * pstride];
+      s2 += p[(int64_t)(sp + 2 * RY) * pstride];
+      s3 += p[(int64_t)(sp + 3 * RY) * pstride];
+    }
+    for (; sp < nsplit; sp += RY) s0 += p[(int64_t)sp * pstride];
+  }
+  sh[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && idx < total) {
+    double s = 0.0;
+#pragma unroll
+    for (int y = 0; y < RY; ++y) s += sh[y][tx];
+    const bool real = (int)(idx % kpad) < k;
+    C[idx] = real ? ((beta != 0.0) ? scale * s + beta * C[idx] : scale * s) : 0.0;
+  }
+}
+
 int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_t pstride, int inner_ld, bool tr, int m,
                            int k, double scale, double beta, double* C, int64_t rs, int64_t cs) {
   const int fastn = tr ? m : k, slown = tr ? k : m;
-  dim3 block(64, RY), grid((fastn + 63) / 64, slown < 32768 ? slown : 32768);
-  hipLaunchKernelGGL(k_reduce_partials, grid, block, 0, ctx->stream, part, nsplit, pstride, inner_ld, tr ? 1 : 0, m, k,
-                     scale, beta, C, rs, cs);
+  if (!tr && cs == 1 && rs == inner_ld && (int64_t)m * inner_ld >= 65536) {
+    const int64_t total = (int64_t)m * inner_ld;
+    dim3 fgrid((unsigned)((total + 63) / 64));
+    if (nsplit <= 8)
+      hipLaunchKernelGGL(k_reduce_flat<4>, fgrid, dim3(64, 4), 0, ctx->stream, part, nsplit, pstride, total, inner_ld, k, scale,
+                         beta, C);
+    else
+      hipLaunchKernelGGL(k_reduce_flat<16>, fgrid, dim3(64, 16), 0, ctx->stream, part, nsplit, pstride, total, inner_ld, k,
+                         scale, beta, C);
+    HIP_TRY(hipGetLastError());
+    return HFMI_OK;
+  }
+  dim3 grid((fastn + 63) / 64, slown < 32768 ? slown : 32768);
+  if (nsplit <= 8)
+    hipLaunchKernelGGL(k_reduce_partials<4>, grid, dim3(64, 4), 0, ctx->stream, part, nsplit, pstride, inner_ld, tr ? 1 : 0, m,
+                       k, scale, beta, C, rs, cs);
+  else
+    hipLaunchKernelGGL(k_reduce_partials<16>, grid, dim3(64, 16), 0, ctx->stream, part, nsplit, pstride, inner_ld, tr ? 1 : 0, m,
+                       k, scale, beta, C, rs, cs);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
