@@ -295,6 +295,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
 //   ring : stage length of tsgemm_tn (2 = 32 reduction indices per LDS stage, 4 = 64 where the length allows)
 static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
+static int g_nn_hybrid = 1;                          // split only the row tiles beyond the last full round of CUs
 static int g_nn_tt = 0;                              // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
@@ -319,6 +320,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   else if (key && !strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
   else if (key && !strcmp(key, "nn_tt") && value >= 0 && value <= 3) g_nn_tt = value;
+  else if (key && !strcmp(key, "nn_hybrid") && (value == 0 || value == 1)) g_nn_hybrid = value;
   else if (key && !strcmp(key, "ss_percu") && value >= 1 && value <= 4) tsgemm_ss_set_percu(value);
   else HFMI_FAIL(HFMI_ERR_INVALID, "tuning_set: unknown key/value");
   return HFMI_OK;
@@ -473,7 +475,9 @@ template <int TT, int NT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
                                                                     const double* __restrict__ S, int lds_, int r,
                                                                     double* __restrict__ Y, int64_t ldy, int64_t N,
-                                                                    int ntiles, int msplit, int mchunk, int64_t pstride) {
+                                                                    int ntiles, int msplit, int mchunk, int64_t pstride,
+                                                                    int full_tiles, double* __restrict__ Yfull,
+                                                                    int64_t ldfull) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2][NN_KC][SLD]
   constexpr int COLS = NT * 16;
@@ -486,15 +490,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   constexpr int NQ = (CH + NTHR - 1) / NTHR;      // pairs per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, kk = lane >> 4;
-  const int logical = xcd_remap(blockIdx.x, ntiles * msplit);
-  const int split = logical / ntiles, tile = logical % ntiles;
+  // Row tiles [0, full_tiles) are whole rounds of the CUs: one workgroup each over the full reduction range, written
+  // straight to the result.  The remaining (fewer than one round of) tiles are split msplit-ways over the reduction
+  // axis so that they, too, occupy every CU for 1/msplit of a tile's time; only those rows go through partials.
+  const int tail_tiles = ntiles - full_tiles;
+  // whole tiles and tail pieces are remapped over the XCDs separately: one contiguous logical range per XCD would
+  // put all the short tail pieces on the last XCDs and leave the whole tiles to the others (full_tiles % 8 == 0)
+  const bool whole = (int)blockIdx.x < full_tiles;
+  const int logical = whole ? xcd_remap(blockIdx.x, full_tiles)
+                            : full_tiles + xcd_remap((int)blockIdx.x - full_tiles, tail_tiles * msplit);
+  const int split = whole ? 0 : (logical - full_tiles) / tail_tiles;
+  const int tile = whole ? logical : full_tiles + (logical - full_tiles) % tail_tiles;
   const int64_t t0 = (int64_t)tile * (16 * TT * WAVES) + wave * (16 * TT);
-  const int i_begin = split * mchunk;
-  int i_end = i_begin + mchunk;
+  const int i_begin = whole ? 0 : split * mchunk;
+  int i_end = whole ? m : i_begin + mchunk;
   if (i_end > m) i_end = m;
   const int nstages = (i_end - i_begin + NN_KC - 1) / NN_KC;
   const int64_t tmax = round_up_dev(N, 32) - 2;
-  double* Yo = Y + (int64_t)split * pstride;
+  double* Yo = whole ? Yfull : Y + (int64_t)split * pstride;
+  const int64_t ldout = whole ? ldfull : ldy;
 
   // streamed operand: lane (c16, kk) fetches rows t0 + tp*32 + 2*c16 + {0,1} of vector i0 + kk
   int64_t toff[TPA];
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
     for (int rg = 0; rg < 4; ++rg) {
       const int j = nt * 16 + kk + 4 * rg;
       if (j < r) {
-        double* yc = Yo + (int64_t)j * ldy;
+        double* yc = Yo + (int64_t)j * ldout;
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
           const int64_t t = t0 + tp * 32 + 2 * c16;
@@ -637,13 +651,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
     }
 }
 
-// Y[j][t] = sum_s part[s][j][t]  (fixed order), rows t < N
+// Y[j][t] = sum_s part[s][j][t]  (fixed order), rows row0 <= t < N (row0 even)
 __global__ void k_reduce_nn(const double* __restrict__ part, int msplit, int64_t pstride, int64_t ldp, double* __restrict__ Y,
-                            int64_t ldy, int64_t N, int r) {
+                            int64_t ldy, int64_t row0, int64_t N, int r) {
   for (int j = blockIdx.y; j < r; j += gridDim.y) {
     const double* p = part + (int64_t)j * ldp;
     double* y = Y + (int64_t)j * ldy;
-    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+    for (int64_t t = row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
       if (t + 1 < N) {
         d2 acc = *reinterpret_cast<const d2*>(p + t);
         for (int sp = 1; sp < msplit; ++sp) {
@@ -696,13 +710,31 @@ static double nn_plan(hfmi_ctx* ctx, int tile_rows, int m, int r, int64_t N, dou
 
 template <int TT, int NT, int WAVES>
 static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r,
-                          double* Y, int64_t ldy, int64_t N, int msplit) {
+                          double* Y, int64_t ldy, int64_t N, int msplit, bool tail_split = false) {
   constexpr int SLD = NT * 16 + ((NT % 2 == 0) ? 16 : 0);
   const size_t shmem = (size_t)2 * NN_KC * SLD * sizeof(double);
   auto kern = k_tsgemm_nn<TT, NT, WAVES>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const int tile_rows = 16 * TT * WAVES;
   const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  // msplit > 1 means the plan found the row tiles badly quantised over the CUs.  With at least one full round of
+  // tiles, only the tiles beyond the last full round are split (see the kernel); otherwise every tile is.
+  int full_tiles = 0;
+  if ((msplit > 1 || tail_split) && ntiles >= cus && g_nn_hybrid) {
+    full_tiles = ntiles / cus * cus;
+    const int tail = ntiles - full_tiles;
+    if (tail == 0) {
+      msplit = 1;
+    } else {
+      const int stages = (m + NN_KC - 1) / NN_KC;
+      int ms = cus / tail;                                  // one round of CUs for the tail
+      if (ms > stages / 4) ms = stages / 4;                 // at least four LDS stages per workgroup
+      if (ms < 1) ms = 1;
+      msplit = ms;
+      if (msplit == 1) full_tiles = 0;                      // nothing to split: plain launch
+    }
+  }
   int mchunk = (int)round_up((m + msplit - 1) / msplit, NN_KC);
   msplit = (m + mchunk - 1) / mchunk;
   double* out = Y;
@@ -713,15 +745,21 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
     void* pv = nullptr;
     HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)msplit * pstride * sizeof(double), &pv));
     out = (double*)pv;
+  } else {
+    full_tiles = 0;
   }
-  dim3 grid((unsigned)(ntiles * msplit)), block(WAVES * 64);
-  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, ntiles, msplit, mchunk, pstride);
+  const int tail_tiles = ntiles - full_tiles;
+  dim3 grid((unsigned)(full_tiles + tail_tiles * msplit)), block(WAVES * 64);
+  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, ntiles, msplit, mchunk, pstride,
+                     full_tiles, Y, ldy);
   HIP_TRY(hipGetLastError());
   if (msplit > 1) {
-    int64_t gx = ((N + 1) / 2 + 255) / 256;
+    const int64_t row0 = (int64_t)full_tiles * tile_rows;   // multiple of 64
+    int64_t gx = ((N - row0 + 1) / 2 + 255) / 256;
     if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_reduce_nn, dim3((unsigned)gx, (unsigned)r), dim3(256), 0, ctx->stream, (const double*)out, msplit,
-                       pstride, ldo, Y, ldy, N, r);
+                       pstride, ldo, Y, ldy, row0, N, r);
     HIP_TRY(hipGetLastError());
   }
   return HFMI_OK;
@@ -737,6 +775,11 @@ static int nn_launch_w4(hfmi_ctx* ctx, const double* A, int64_t lda, int m, cons
   const double c0 = nn_plan(ctx, 64 * TMAX, m, r, N, 1.0, &ms0);
   const double c1 = (T1 != TMAX) ? nn_plan(ctx, 64 * T1, m, r, N, 0.98, &ms1) : 1e300;
   const double c2 = (T2 != T1) ? nn_plan(ctx, 64 * T2, m, r, N, 0.96, &ms2) : 1e300;
+  // With at least one full round of the tallest tiles the quantisation is handled by splitting only the tail tiles
+  // (nn_launch_inst), so the tallest tile -- the best MFMA-to-LDS ratio -- is taken (A/B r01e: config 4 nn 56.5 -> 59.7 TF)
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  if (g_nn_hybrid && g_nn_tt == 0 && (N + 64 * TMAX - 1) / (64 * TMAX) >= cus && m >= 16 * NN_KC)
+    return nn_launch_inst<TMAX, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, 1, true);
   if (g_nn_tt == 1) return nn_launch_inst<TMAX, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms0);
   if (g_nn_tt == 2) return nn_launch_inst<T1, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms1);
   if (g_nn_tt == 3) return nn_launch_inst<T2, NT, 4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms2);

@@ -11,12 +11,14 @@ for name, m, r, N in (("pod nn", 2048, 138, 500000), ("pod QR nn", 138, 138, 500
     S = np.random.default_rng(0).standard_normal((m, r))
     res = {}
     for rep in range(3):
-        for tt in (0, 1, 2, 3):
-            L.call("hfmi_tuning_set", b"nn_tt", tt)
-            ms = C.c_double(0)
-            L.call("hfmi_bench_tsgemm_nn", A.handle, L.ptr(S), Y.handle, 3, C.byref(ms))
-            res.setdefault(tt, []).append(ms.value)
-    L.call("hfmi_tuning_set", b"nn_tt", 0)
+        for hyb in (1, 0):
+            L.call("hfmi_tuning_set", b"nn_hybrid", hyb)
+            for tt in (0, 1, 2):
+                L.call("hfmi_tuning_set", b"nn_tt", tt)
+                ms = C.c_double(0)
+                L.call("hfmi_bench_tsgemm_nn", A.handle, L.ptr(S), Y.handle, 3, C.byref(ms))
+                res.setdefault((hyb, tt), []).append(ms.value)
+    L.call("hfmi_tuning_set", b"nn_tt", 0); L.call("hfmi_tuning_set", b"nn_hybrid", 1)
     fl = 2.0 * N * m * r
-    print(name, (m, r, N), "  ".join("tt%d: %.3f ms %.1f TF" % (tt, np.median(v), fl / np.median(v) / 1e9) for tt, v in res.items()), flush=True)
+    print(name, (m, r, N), "  ".join("h%d/tt%d: %.3f ms %.1f TF" % (h, tt, np.median(v), fl / np.median(v) / 1e9) for (h, tt), v in res.items()), flush=True)
     del A, Y
