@@ -268,7 +268,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
   if (!tr && cs == 1 && rs == inner_ld && (int64_t)m * inner_ld >= 65536) {
     const int64_t total = (int64_t)m * inner_ld;
     dim3 fgrid((unsigned)((total + 63) / 64));
-    if (nsplit <= 8)
+    if (nsplit <= 32)
       hipLaunchKernelGGL(k_reduce_flat<4>, fgrid, dim3(64, 4), 0, ctx->stream, part, nsplit, pstride, total, inner_ld, k, scale,
                          beta, C);
     else
@@ -278,7 +278,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
     return HFMI_OK;
   }
   dim3 grid((fastn + 63) / 64, slown < 32768 ? slown : 32768);
-  if (nsplit <= 8)
+  if (nsplit <= 32)
     hipLaunchKernelGGL(k_reduce_partials<4>, grid, dim3(64, 4), 0, ctx->stream, part, nsplit, pstride, inner_ld, tr ? 1 : 0, m,
                        k, scale, beta, C, rs, cs);
   else
