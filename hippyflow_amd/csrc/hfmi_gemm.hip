@@ -54,12 +54,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ part, int mpad, int kpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // RING selects the stage length: 2 -> 32 reduction indices per LDS stage, 4 -> 64 (half as many barriers; only
-  // launched when the padded length is a multiple of 64).  The streamed operand always runs one 8-index
-  // iteration ahead in a two-deep register ring.
-  constexpr int BK = (RING == 4) ? 64 : TN_BK;
+  // RING selects how the streamed operand is fetched.  2: one 16-byte load per lane and row tile per 8-index
+  // iteration, one iteration ahead (each instruction touches 64 bytes of 16 different vectors, so every 128-byte
+  // line is requested from L2 twice, an iteration apart).  4: the loads of TWO consecutive iterations are issued
+  // together, two iterations ahead (four register sets): the second request finds the line already in flight.
+  constexpr int BK = TN_BK;
   constexpr int LDB = BK + 2;
-  constexpr int CSH = (RING == 4) ? 5 : 4;        // log2(16-byte chunks per column per stage)
+  constexpr int CSH = 4;                          // log2(16-byte chunks per column per stage)
   double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][LDB]
   constexpr int COLS = NT * 16;
   constexpr int NTHR = WAVES * 64;
@@ -145,27 +146,51 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     stage_store(lds);
     __syncthreads();
   }
-  // streamed operand: two-deep register ring over iterations of 8 reduction indices (prefetch distance 1); the LDS
-  // fragments of iteration it+1 are read before the MFMAs of iteration it
+  // streamed operand: register ring over iterations of 8 reduction indices; the LDS fragments of iteration it+1 are
+  // read before the MFMAs of iteration it
   {
     constexpr int NIT = BK / 8;
     d2 bf[2][NT];
-    d2 a[2][MT];
-    load_a(a[0], t_begin);
-    for (int s = 0; s < nstages; ++s) {
-      const int64_t ts = t_begin + (int64_t)s * BK;
-      const bool has_next = s + 1 < nstages;
-      if (has_next) stage_load(ts + BK);
-      const double* L = lds + (s & 1) * COLS * LDB;
-      ldsb(bf[0], L, 0);
+    if constexpr (RING == 2) {
+      d2 a[2][MT];
+      load_a(a[0], t_begin);
+      for (int s = 0; s < nstages; ++s) {
+        const int64_t ts = t_begin + (int64_t)s * BK;
+        const bool has_next = s + 1 < nstages;
+        if (has_next) stage_load(ts + BK);
+        const double* L = lds + (s & 1) * COLS * LDB;
+        ldsb(bf[0], L, 0);
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        load_a(a[(it + 1) & 1], ts + 8 * (it + 1));
-        if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
-        mma(a[it & 1], bf[it & 1]);
+        for (int it = 0; it < NIT; ++it) {
+          load_a(a[(it + 1) & 1], ts + 8 * (it + 1));
+          if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
+          mma(a[it & 1], bf[it & 1]);
+        }
+        if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * LDB);
+        __syncthreads();
       }
-      if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * LDB);
-      __syncthreads();
+    } else {
+      d2 a[4][MT];
+      load_a(a[0], t_begin);
+      load_a(a[1], t_begin + 8);
+      for (int s = 0; s < nstages; ++s) {
+        const int64_t ts = t_begin + (int64_t)s * BK;
+        const bool has_next = s + 1 < nstages;
+        if (has_next) stage_load(ts + BK);
+        const double* L = lds + (s & 1) * COLS * LDB;
+        ldsb(bf[0], L, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          if ((it & 1) == 0) {   // both halves of the next 128-byte line of every row, back to back
+            load_a(a[(it + 2) & 3], ts + 8 * (it + 2));
+            load_a(a[(it + 3) & 3], ts + 8 * (it + 3));
+          }
+          if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
+          mma(a[it & 3], bf[it & 1]);
+        }
+        if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * LDB);
+        __syncthreads();
+      }
     }
   }
 
@@ -293,7 +318,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 // Tuning knobs of the MFMA kernels (A/B measurements: environment HFMI_GEMM_WAVES / HFMI_GEMM_RING, or
 // hfmi_tuning_set at run time).
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
-//   ring : stage length of tsgemm_tn (2 = 32 reduction indices per LDS stage, 4 = 64 where the length allows)
+//   ring : streamed-operand fetch of tsgemm_tn (2 = one iteration ahead, 4 = two iterations fetched together, two ahead)
 static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
 static int g_nn_hybrid = 1;                          // split only the row tiles beyond the last full round of CUs
 static int g_nn_tt = 0;                              // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
@@ -335,7 +360,7 @@ static inline int tn_mt_max(int nt, int waves) {
 template <int MT, int NT, int WAVES, bool TR, int RING>
 static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t N,
                          int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  const size_t shmem = (size_t)2 * NT * 16 * ((RING == 4 ? 64 : TN_BK) + 2) * sizeof(double);
+  const size_t shmem = (size_t)2 * NT * 16 * (TN_BK + 2) * sizeof(double);
   auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, RING>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,
@@ -347,8 +372,7 @@ static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
 template <int MT, int NT, int WAVES>
 static int tn_launch_inst(hfmi_ctx* ctx, bool tr, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
                           int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  // long (64-index) stages: only when every slice is a whole number of them and the two buffers fit in LDS
-  const bool ring4 = gemm_ring() == 4 && N % 64 == 0 && chunk % 64 == 0 && NT <= 9;
+  const bool ring4 = gemm_ring() == 4;
   if (tr) {
     if (ring4) return tn_launch_one<MT, NT, WAVES, true, 4>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
     return tn_launch_one<MT, NT, WAVES, true, 2>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
@@ -420,7 +444,7 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
     }
     nsplit = best;
   }
-  const int64_t stage_len = (gemm_ring() == 4 && Npad % 64 == 0 && nt <= 9) ? 64 : TN_BK;
+  const int64_t stage_len = TN_BK;
   int64_t chunk = round_up((Npad + nsplit - 1) / nsplit, stage_len);
   if (chunk < stage_len) chunk = stage_len;
   nsplit = (int)((Npad + chunk - 1) / chunk);

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import hippyflow_amd as hf
 from hippyflow_amd import _lib as L
 ctx = hf.Context.default()
-shapes = [("as  tn", 12800, 74, 200000), ("as  tn", 25600, 74, 200000), ("kle tn", 25000, 84, 102400), ("pod tn", 2048, 138, 499968), ("as shard tn", 6400, 74, 200000)]
+shapes = [("as  tn", 12800, 74, 200000), ("as  tn", 25600, 74, 200000), ("kle tn", 25000, 84, 100000), ("pod tn", 2048, 138, 500000), ("as shard tn", 6400, 74, 200000)]
 variants = [(8, 2), (8, 4)]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for name, m, k, N in shapes:
