@@ -54,15 +54,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ part, int mpad, int kpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // RING selects how the streamed operand is fetched.  2: one 16-byte load per lane and row tile per 8-index
-  // iteration, one iteration ahead (each instruction touches 64 bytes of 16 different vectors, so every 128-byte
-  // line is requested from L2 twice, an iteration apart).  4: the loads of TWO consecutive iterations are issued
-  // together, two iterations ahead (four register sets): the second request finds the line already in flight.
+  // RING selects the LDS image of the staged operand (A/B knob "ring").  2: [column][34 doubles], padded rows;
+  // PMC shows 44 % of its LDS cycles are bank conflicts (one 2-way conflict per 16-lane group of every
+  // ds_read_b128).  4: [16 chunks][columns] of 16-byte elements, unpadded, column XOR (chunk & 7) -- the layout of
+  // k_tsgemm_ss, conflict free for the fragment reads and the staging writes.
   constexpr int BK = TN_BK;
-  constexpr int LDB = BK + 2;
-  constexpr int CSH = 4;                          // log2(16-byte chunks per column per stage)
-  double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][LDB]
   constexpr int COLS = NT * 16;
+  constexpr bool SWZ = (RING == 4);
+  constexpr int LDB = BK + 2;
+  constexpr int BUFD = SWZ ? (BK / 2) * COLS * 2 : COLS * LDB;   // doubles per stage buffer
+  constexpr int CSH = 4;                          // log2(16-byte chunks per column per stage)
+  double* lds = reinterpret_cast<double*>(smem);  // [2][BUFD]
   constexpr int NTHR = WAVES * 64;
   constexpr int CH = COLS * (BK / 2);             // 16-byte chunks per stage
   constexpr int NQ = (CH + NTHR - 1) / NTHR;      // chunks per thread
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
       const int c = tid + NTHR * qd;
-      if (CH % NTHR == 0 || c < CH) *reinterpret_cast<d2*>(L + (c >> CSH) * LDB + (c & ((1 << CSH) - 1)) * 2) = breg[qd];
+      const int col = c >> CSH, q = c & ((1 << CSH) - 1);
+      const int off = SWZ ? (q * COLS + (col ^ (q & 7))) * 2 : col * LDB + q * 2;
+      if (CH % NTHR == 0 || c < CH) *reinterpret_cast<d2*>(L + off) = breg[qd];
     }
   };
   auto load_a = [&](d2(&dst)[MT], int64_t t) {
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
   auto ldsb = [&](d2(&bf)[NT], const double* L, int it) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      bf[nt] = *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * LDB + it * 8 + kk * 2);
+      bf[nt] = SWZ ? *reinterpret_cast<const d2*>(L + ((it * 4 + kk) * COLS + nt * 16 + (r16 ^ ((it * 4 + kk) & 7))) * 2)
+                   : *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * LDB + it * 8 + kk * 2);
   };
   auto mma = [&](const d2(&a)[MT], const d2(&bf)[NT]) {
 #pragma unroll
@@ -151,46 +156,22 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
   {
     constexpr int NIT = BK / 8;
     d2 bf[2][NT];
-    if constexpr (RING == 2) {
-      d2 a[2][MT];
-      load_a(a[0], t_begin);
-      for (int s = 0; s < nstages; ++s) {
-        const int64_t ts = t_begin + (int64_t)s * BK;
-        const bool has_next = s + 1 < nstages;
-        if (has_next) stage_load(ts + BK);
-        const double* L = lds + (s & 1) * COLS * LDB;
-        ldsb(bf[0], L, 0);
+    d2 a[2][MT];
+    load_a(a[0], t_begin);
+    for (int s = 0; s < nstages; ++s) {
+      const int64_t ts = t_begin + (int64_t)s * BK;
+      const bool has_next = s + 1 < nstages;
+      if (has_next) stage_load(ts + BK);
+      const double* L = lds + (s & 1) * BUFD;
+      ldsb(bf[0], L, 0);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          load_a(a[(it + 1) & 1], ts + 8 * (it + 1));
-          if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
-          mma(a[it & 1], bf[it & 1]);
-        }
-        if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * LDB);
-        __syncthreads();
+      for (int it = 0; it < NIT; ++it) {
+        load_a(a[(it + 1) & 1], ts + 8 * (it + 1));
+        if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
+        mma(a[it & 1], bf[it & 1]);
       }
-    } else {
-      d2 a[4][MT];
-      load_a(a[0], t_begin);
-      load_a(a[1], t_begin + 8);
-      for (int s = 0; s < nstages; ++s) {
-        const int64_t ts = t_begin + (int64_t)s * BK;
-        const bool has_next = s + 1 < nstages;
-        if (has_next) stage_load(ts + BK);
-        const double* L = lds + (s & 1) * COLS * LDB;
-        ldsb(bf[0], L, 0);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          if ((it & 1) == 0) {   // both halves of the next 128-byte line of every row, back to back
-            load_a(a[(it + 2) & 3], ts + 8 * (it + 2));
-            load_a(a[(it + 3) & 3], ts + 8 * (it + 3));
-          }
-          if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
-          mma(a[it & 3], bf[it & 1]);
-        }
-        if (has_next) stage_store(lds + ((s + 1) & 1) * COLS * LDB);
-        __syncthreads();
-      }
+      if (has_next) stage_store(lds + ((s + 1) & 1) * BUFD);
+      __syncthreads();
     }
   }
 
@@ -318,7 +299,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 // Tuning knobs of the MFMA kernels (A/B measurements: environment HFMI_GEMM_WAVES / HFMI_GEMM_RING, or
 // hfmi_tuning_set at run time).
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
-//   ring : streamed-operand fetch of tsgemm_tn (2 = one iteration ahead, 4 = two iterations fetched together, two ahead)
+//   ring : LDS image of the staged operand in tsgemm_tn (2 = padded rows, 4 = unpadded XOR-swizzled chunks)
 static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
 static int g_nn_hybrid = 1;                          // split only the row tiles beyond the last full round of CUs
 static int g_nn_tt = 0;                              // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
@@ -360,7 +341,7 @@ static inline int tn_mt_max(int nt, int waves) {
 template <int MT, int NT, int WAVES, bool TR, int RING>
 static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t N,
                          int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  const size_t shmem = (size_t)2 * NT * 16 * (TN_BK + 2) * sizeof(double);
+  const size_t shmem = (size_t)2 * NT * 16 * (RING == 4 ? TN_BK : TN_BK + 2) * sizeof(double);
   auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, RING>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,

@@ -199,7 +199,7 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * total milliseconds, launches, and the ALGORITHMIC flops / bytes of one launch. */
 /* kernel tuning knobs for in-process A/B measurements (defaults are the measured winners; scripts/gemm_ab.py,
  * scripts/ss_ab.py, scripts/nn_tt_probe.py): ("waves", 8|4|44) tsgemm_tn workgroup shape (44 = two 4-wave workgroups
- * per CU); ("ring", 2|4) tsgemm_tn streamed-operand fetch (one iteration ahead | two iterations fetched together); ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
+ * per CU); ("ring", 2|4) tsgemm_tn LDS image of the staged operand (padded rows | XOR-swizzled chunks); ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
  * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("ss", 0|1) route skinny x skinny contractions to
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized. */
 int hfmi_tuning_set(const char* key, int value);
