@@ -13,7 +13,8 @@ from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobi
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, PriorPreconditionedProjector,
                         SnapshotGramOperator, Solver2Operator, SummedListOperator, as_device_operator, npToDeviceOperator)
-from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, KLEParameterList, KLEProjector,
+from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, BoundaryRestrictedKLEProjector,
+                         KLEParameterList, KLEProjector,
                          ParameterList, PODParameterList, PODProjector, PODProjectorFromData, weighted_l2_norm_vector)
 from .randomized import accuracyEnhancedSVD, doublePass, doublePassG, parRandom, svd_small, sym_eig_small
 from .errors import projection_error_test

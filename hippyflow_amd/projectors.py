@@ -357,6 +357,63 @@ class KLEProjector:
         return avg, std
 
 
+class BoundaryRestrictedKLEProjector:
+    """Prior-based KLE subspace for boundary data (KLEProjector.py:336-435): the generalized eigenproblem
+    ``M_b C M_b u = lambda B u`` with the boundary-restricted mass matrix ``M_b`` (singular: zero rows for interior
+    nodes) and its invertible completion ``B = M_b + I_interior``; decoder B-orthonormal, encoder ``M_b * decoder``.
+
+    The reference assembles ``M_b`` with FEniCS from the boundary measure ``ds`` (:364-396); here the assembled matrix
+    is handed over (``boundary_mass``, a scipy sparse matrix, or ``prior.M_boundary``) and ``ds`` is accepted only for
+    signature parity.  ``B`` follows the reference's rule (:382-394): a one on every diagonal entry of ``M_b`` that is
+    numerically zero.  ``B^-1`` is the reference's MUMPS LU (:360-361); on the device it is a Jacobi-PCG solve (B is
+    a boundary mass matrix plus an identity block: well conditioned)."""
+
+    def __init__(self, prior, ds=None, parameters=KLEParameterList(), boundary_mass=None, ctx=None):
+        import scipy.sparse as sp
+        self.prior = prior
+        self.ds = ds
+        self.parameters = parameters
+        self.ctx = ctx or L.Context.default()
+        if boundary_mass is None:
+            boundary_mass = getattr(prior, "M_boundary", None)
+        if boundary_mass is None:
+            raise ValueError("BoundaryRestrictedKLEProjector: pass the assembled boundary mass matrix "
+                             "(boundary_mass=... or prior.M_boundary); FEniCS assembly is a host-side black box")
+        self._Mb_csr = sp.csr_matrix(boundary_mass)
+        self.N = self._Mb_csr.shape[0]
+        self.M = CsrOperator(self.make_boundary_restricted_mass_matrix(fill_nullspace=False), ctx=self.ctx)
+        self._B_csr = self.make_boundary_restricted_mass_matrix(fill_nullspace=True)
+        self.B = CsrOperator(self._B_csr, ctx=self.ctx)
+        if hasattr(prior, "C") and prior.C is not None:
+            self.C = as_device_operator(prior.C, self.N, self.ctx)
+        else:
+            self.C = as_device_operator(Solver2Operator(prior.Rsolver), self.N, self.ctx)    # :356
+        self.KLE_Operator = MassPreconditionedCovarianceOperator(self.C, self.M)              # :357
+        self.Bsolver = CsrPCGSolver(self._B_csr, rel_tol=1e-13, ctx=self.ctx)                 # :360-361
+        self.d_KLE = None
+        self.V_KLE = None
+
+    def make_boundary_restricted_mass_matrix(self, fill_nullspace=False):
+        """The boundary mass matrix, optionally with the reference's nullspace fill (:364-396)."""
+        import scipy.sparse as sp
+        Mb = self._Mb_csr
+        if not fill_nullspace:
+            return Mb
+        new_diag = np.isclose(Mb.diagonal(), 0.0).astype(np.float64)
+        return (Mb + sp.diags(new_diag)).tocsr()
+
+    def construct_input_subspace(self):
+        """(d, decoder, encoder) of the boundary-restricted KLE (:399-435)."""
+        rank = self.parameters['rank']
+        oversampling = self.parameters['oversampling']
+        Omega = MultiVector(self.N, rank + oversampling, ctx=self.ctx)
+        parRandom.normal(1.0, Omega)                                                          # :423-425
+        self.d_KLE, self.V_KLE = doublePassG(self.KLE_Operator, self.B, self.Bsolver, Omega, rank, s=1)   # :428
+        KLE_encoder = MultiVector(self.N, rank, ctx=self.ctx)
+        MatMvMult(self.M, self.V_KLE, KLE_encoder)                                            # :431-432
+        return self.d_KLE, self.V_KLE, KLE_encoder
+
+
 # =====================================================================================
 # POD
 # =====================================================================================

@@ -253,6 +253,64 @@ def test_double_pass_g_kle_mass(ctx, binv):
     _check_eigs(d2, V2.to_dense(), d_ref, V_ref, 1e-7, 1e-5, 10, lambda W: M @ W)
 
 
+def test_boundary_restricted_kle_projector(ctx):
+    """BoundaryRestrictedKLEProjector (KLEProjector.py:336-435): doublePassG with the boundary mass matrix M_b
+    inside the operator (M_b C M_b) and its invertible completion B = M_b + I_interior as the inner product.
+    Checked against the dense generalized eigenproblem and the oracle's doublePassG on the same Omega."""
+    import scipy.linalg as sla
+    nx = 24
+    N = nx * nx
+    idx = np.arange(N).reshape(nx, nx)
+    ring = np.concatenate([idx[0, :-1], idx[:-1, -1], idx[-1, :0:-1], idx[:0:-1, 0]])   # boundary nodes, in order
+    h = 1.0 / (nx - 1)
+    Mb = sp.lil_matrix((N, N))
+    for a, b in zip(ring, np.roll(ring, -1)):                                            # 1-D P1 mass per boundary edge
+        Mb[a, a] += h / 3
+        Mb[b, b] += h / 3
+        Mb[a, b] += h / 6
+        Mb[b, a] += h / 6
+    Mb = Mb.tocsr()
+    M, K = _fem(N)
+    Rm = ((M + 0.05 * K) @ sp.diags(1.0 / np.asarray(M.sum(axis=1)).ravel()) @ (M + 0.05 * K)).toarray()
+    Rm = 0.5 * (Rm + Rm.T)
+
+    class Prior:
+        pass
+
+    prior = Prior()
+    prior.Rsolver = hp_o.SparseLUSolver(sp.csr_matrix(Rm))
+    prior.Rsolver.N = N
+    params = hf.KLEParameterList()
+    params["rank"], params["oversampling"] = 12, 8
+    with pytest.raises(ValueError):
+        hf.BoundaryRestrictedKLEProjector(prior, None, parameters=params)
+    proj = hf.BoundaryRestrictedKLEProjector(prior, None, parameters=params, boundary_mass=Mb)
+    B = proj.make_boundary_restricted_mass_matrix(fill_nullspace=True)
+    interior = np.setdiff1d(np.arange(N), ring)
+    assert np.allclose(B.diagonal()[interior], 1.0) and np.allclose((B - Mb).diagonal()[ring], 0.0)   # :382-394
+    hf.parRandom.reseed(7)
+    d, dec, enc = proj.construct_input_subspace()
+    V, E = dec.to_dense(), enc.to_dense()
+    r = 12
+    Bd = B.toarray()
+    assert np.linalg.norm(V.T @ Bd @ V - np.eye(r)) / np.sqrt(r) < 1e-10
+    assert rel(E, Mb @ V) < 1e-12
+    Cm = np.linalg.inv(Rm)
+    A_dense = Mb @ Cm @ Mb.toarray()
+    A_dense = 0.5 * (A_dense + A_dense.T)
+    w = sla.eigh(A_dense, Bd, eigvals_only=True)[::-1][:r]
+    np.testing.assert_allclose(d[:4], w[:4], rtol=1e-6)                                 # randomization error only
+    np.testing.assert_allclose(d[:8], w[:8], rtol=1e-3)
+    assert np.all(d[:r] <= w[:r] * (1 + 1e-10))                                         # Ritz values from below
+    # same Omega through the oracle's doublePassG
+    hf.parRandom.reseed(7)
+    Omega = hf.MultiVector(N, 20)
+    hf.parRandom.normal(1.0, Omega)
+    d_ref, U_ref = hp_o.double_pass_g(hp_o.DenseOperator(A_dense), hp_o.SparseOperator(B), hp_o.SparseLUSolver(B),
+                                      np.asfortranarray(Omega.to_dense()), r, s=1)
+    np.testing.assert_allclose(d, d_ref, rtol=1e-8)
+
+
 # ------------------------------------------------------------------ projectors
 @pytest.mark.parametrize("method", ["hep", "ghep", "inverse_ghep"])
 @pytest.mark.parametrize("shifted", [True, False])
