@@ -11,7 +11,8 @@ from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, Mult
 from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector
 from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobianOperator, DeviceOperator, HostCallbackOperator,
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
-                        MeanJJTfromDataOperator, MeanJTJfromDataOperator, PriorPreconditionedProjector,
+                        JJT, JTJ, MeanJJTfromDataOperator, MeanJTJfromDataOperator, PriorPreconditionedProjector,
+                        SeriallySampledJacobianOperator, StateSpaceIdentityOperator, npToDolfinOperator,
                         SnapshotGramOperator, Solver2Operator, SummedListOperator, as_device_operator, npToDeviceOperator)
 from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, BoundaryRestrictedKLEProjector,
                          KLEParameterList, KLEProjector,

@@ -422,6 +422,160 @@ class SummedListOperator:
         Y.axpy(1.0 / float(len(self.operators)) if self.average else 1.0, temp)
 
 
+class StateSpaceIdentityOperator:
+    """Identity observable on the state space (fullStateObservable.py:18-52): ``mult`` copies; ``transpmult`` applies
+    the mass matrix (the adjoint in the M-inner product) unless ``use_mass_matrix`` is False."""
+
+    def __init__(self, M, use_mass_matrix=True):
+        self.M = M
+        self.use_mass_matrix = use_mass_matrix
+
+    def mpi_comm(self):
+        return self.M.mpi_comm()
+
+    def init_vector(self, v, dim):
+        return self.M.init_vector(v, dim)
+
+    def mult(self, u, y):
+        y.zero()
+        y.axpy(1.0, u)
+
+    def transpmult(self, x, p):
+        if self.use_mass_matrix:
+            self.M.transpmult(x, p) if hasattr(self.M, "transpmult") else self.M.mult(x, p)   # M is symmetric
+        else:
+            p.zero()
+            p.axpy(1.0, x)
+
+
+class JTJ:
+    """J^T J of a Jacobian-protocol object (``mult`` domain -> range, ``transpmult`` range -> domain,
+    ``init_vector(x, dim)``; jacobian.py:142-166).  With a block-capable Jacobian (``DenseJacobianOperator``) the
+    block form ``matMvMult`` runs as two tall-skinny contractions."""
+
+    def __init__(self, J):
+        self.J = J
+        self.vector_help = Vector(ctx=getattr(J, "ctx", None))
+        self.J.init_vector(self.vector_help, 0)
+
+    def mult(self, x, y):
+        self.J.mult(x, self.vector_help)
+        self.J.transpmult(self.vector_help, y)
+
+    def init_vector(self, x, dim=None):
+        self.J.init_vector(x, 1)
+
+    def matMvMult(self, X, Y):
+        """Y = J^T (J X) (overwrites Y, the semantics of hp.MatMvMult on an operator without a block form)."""
+        if hasattr(self.J, "matMvMult") and hasattr(self.J, "matMvTranspmult"):
+            tmp = MultiVector(self.vector_help, X.nvec())
+            self.J.matMvMult(X, tmp)
+            self.J.matMvTranspmult(tmp, Y)
+        else:
+            for j in range(X.nvec()):
+                self.mult(X[j], Y[j])
+
+
+class JJT:
+    """J J^T (jacobian.py:169-193)."""
+
+    def __init__(self, J):
+        self.J = J
+        self.vector_help = Vector(ctx=getattr(J, "ctx", None))
+        self.J.init_vector(self.vector_help, 1)
+
+    def mult(self, x, y):
+        self.J.transpmult(x, self.vector_help)
+        self.J.mult(self.vector_help, y)
+
+    def init_vector(self, x, dim=None):
+        self.J.init_vector(x, 0)
+
+    def matMvMult(self, X, Y):
+        if hasattr(self.J, "matMvMult") and hasattr(self.J, "matMvTranspmult"):
+            tmp = MultiVector(self.vector_help, X.nvec())
+            self.J.matMvTranspmult(X, tmp)
+            self.J.matMvMult(tmp, Y)
+        else:
+            for j in range(X.nvec()):
+                self.mult(X[j], Y[j])
+
+
+class SeriallySampledJacobianOperator:
+    """Sample-by-sample accumulation of J^T J (or J J^T) over prior draws (activeSubspaceProjector.py:98-257).
+
+    Protocol-level mirror: the PDE work stays behind the duck-typed ``observable`` exactly as in the reference
+    (``solveFwd(u, x)``, ``setLinearizationPoint(x)``, ``generate_vector``), and the linearised map is whatever
+    ``jacobian_factory(observable)`` returns -- the reference hard-wires ``ObservableJacobian(observable)``
+    (:178-181); a stored / dense Jacobian enters through ``DenseJacobianOperator``.  ``matMvMult`` ACCUMULATES into y
+    (:214-221, :242-248): callers pass a zeroed block, as ``MatrixMultCollectiveOperator`` does.  Per sample the whole
+    probe block goes through ``JTJ.matMvMult`` (two contractions) instead of the reference's column loop."""
+
+    def __init__(self, observable, noise, prior, control_distribution=None, operation='JTJ', nsamples=None, ms=None, zs=None,
+                 communicator=None, average=True, jacobian_factory=None):
+        assert operation in ['JTJ', 'JJT']
+        assert (nsamples is not None) or (ms is not None)
+        self.observable = observable
+        self.noise = noise
+        self.prior = prior
+        self.control_distribution = control_distribution
+        self.operation = operation
+        self.nsamples = nsamples
+        self.average = average
+        self.ms = ms
+        if zs is not None:
+            self.zs = zs
+        else:
+            self.zs = len(self.ms) * [None] if type(self.ms) is list else zs
+        self.jacobian_factory = jacobian_factory or (lambda obs: obs.jacobian())
+        self.u = observable.generate_vector(0) if hasattr(observable, "generate_vector") else None
+        self.m = observable.generate_vector(1) if hasattr(observable, "generate_vector") else None
+        self.z = None if control_distribution is None else observable.generate_vector(3)
+
+    def init_vector(self, x, dim=None):
+        if self.operation == 'JJT':
+            self.observable.init_vector(x, 0)
+        elif hasattr(getattr(self.observable, "problem", None), 'parameter_projection'):
+            self.prior.init_vector(x, 0)
+        else:
+            self.observable.init_vector(x, 1)
+
+    def _operator(self):
+        J = self.jacobian_factory(self.observable)
+        return JTJ(J) if self.operation == 'JTJ' else JJT(J)
+
+    def _accumulate(self, x, y, weight):
+        op = self._operator()
+        tmp = MultiVector(y)
+        op.matMvMult(x, tmp)
+        y.axpy(weight, tmp)
+
+    def matMvMult(self, x, y):
+        assert x.nvec() == y.nvec(), "x and y have non-matching number of vectors"
+        from .randomized import parRandom
+        if self.ms is None:
+            for _ in range(self.nsamples):
+                self.m.zero()
+                self.noise.zero()
+                parRandom.normal(1, self.noise)
+                self.prior.sample(self.noise, self.m)
+                linearization_x = [self.u, self.m, None]
+                if self.control_distribution is not None:
+                    self.z.zero()
+                    self.control_distribution.sample(self.z)
+                    linearization_x.append(self.z)
+                self.observable.solveFwd(self.u, linearization_x)
+                self.observable.setLinearizationPoint(linearization_x)
+                self._accumulate(x, y, 1.0 / self.nsamples if self.average else 1.0)
+        else:
+            nsamples = len(self.ms)
+            for m, z in zip(self.ms, self.zs):
+                linearization_x = [self.u, m, None] if z is None else [self.u, m, None, z]
+                self.observable.solveFwd(self.u, linearization_x)
+                self.observable.setLinearizationPoint(linearization_x)
+                self._accumulate(x, y, 1.0 / nsamples if self.average else 1.0)
+
+
 class PriorPreconditionedProjector:
     """y = U U^T C^{-1} x (priorPreconditionedProjector.py:19-55)."""
 
@@ -468,3 +622,7 @@ class LowRankRectangularOperator:
         Utx = self.U.dot_v(x)
         y.zero()
         self.V.reduce(y, self.s * Utx)
+
+
+# the reference's name for the dense-array operator wrapper (operatorWrappers.py:19-52)
+npToDolfinOperator = npToDeviceOperator

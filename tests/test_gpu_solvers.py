@@ -733,3 +733,109 @@ def test_derivative_datasets_from_stored_jacobians(ctx, tmp_path):
     f = np.load(d + "Jsvd_data.npz")
     assert sorted(f.files) == ["U_data", "V_data", "sigma_data"]
     np.testing.assert_allclose(f["sigma_data"], sig, rtol=1e-12)         # same seed -> same Omega -> same factors
+
+
+def test_jtj_jjt_and_serially_sampled_operator(ctx, golden_dir):
+    """JTJ / JJT over a Jacobian-protocol object against the reference's own outputs (jacobian.py:142-193; goldens
+    made by running hf.JTJ / hf.JJT / SummedListOperator of the reference), and the serially sampled accumulation
+    (activeSubspaceProjector.py:98-257) against the sample mean it defines."""
+    g = np.load(os.path.join(golden_dir, "operators.npz"))
+    Js, x13, x9 = g["Js"], g["x13"], g["x9"]
+    Jops = [hf.DenseJacobianOperator(Ji) for Ji in Js]
+    x, y = hf.Vector(), hf.Vector()
+    x.init(13)
+    x.set_local(x13)
+    jtj = hf.JTJ(Jops[0])
+    jtj.init_vector(y, 0)
+    jtj.mult(x, y)
+    np.testing.assert_allclose(y.get_local(), g["jtj"], rtol=1e-12)
+    xq, yq = hf.Vector(), hf.Vector()
+    xq.init(9)
+    xq.set_local(x9)
+    jjt = hf.JJT(Jops[0])
+    jjt.init_vector(yq, 0)
+    jjt.mult(xq, yq)
+    np.testing.assert_allclose(yq.get_local(), g["jjt"], rtol=1e-12)
+    hf.SummedListOperator([hf.JTJ(J) for J in Jops], average=True).mult(x, y)
+    np.testing.assert_allclose(y.get_local(), g["summed_avg"], rtol=1e-12)
+    # block form == column form
+    W = np.random.default_rng(0).standard_normal((13, 5))
+    Y = hf.MultiVector(13, 5)
+    hf.MatMvMult(jtj, hf.MultiVector.from_dense(W), Y)
+    assert rel(Y.to_dense(), Js[0].T @ (Js[0] @ W)) < 1e-13
+
+    class Observable:
+        """Linear toy observable: the 'forward solve' just selects which stored Jacobian is the linearisation."""
+        def __init__(self):
+            self.i = -1
+            self.solves = 0
+
+        def generate_vector(self, kind):
+            v = hf.Vector()
+            v.init(13 if kind == 1 else 9)
+            return v
+
+        def init_vector(self, v, dim):
+            v.init(9 if dim == 0 else 13)
+
+        def solveFwd(self, u, lin):
+            self.solves += 1
+            self.i = (self.i + 1) % len(Jops)
+
+        def setLinearizationPoint(self, lin):
+            self.lin = lin
+
+        def jacobian(self):
+            return Jops[self.i]
+
+    class Prior:
+        def sample(self, noise, m):
+            m.zero()
+            m.axpy(1.0, noise)
+
+    obs, noise = Observable(), hf.Vector()
+    noise.init(13)
+    for operation, Wd, ref in (("JTJ", W, np.mean([J.T @ (J @ W) for J in Js], axis=0)),
+                               ("JJT", np.random.default_rng(1).standard_normal((9, 4)), None)):
+        op = hf.SeriallySampledJacobianOperator(obs, noise, Prior(), operation=operation, nsamples=len(Js))
+        if ref is None:
+            ref = np.mean([J @ (J.T @ Wd) for J in Js], axis=0)
+        Yd = hf.MultiVector(ref.shape[0], Wd.shape[1])
+        op.matMvMult(hf.MultiVector.from_dense(Wd), Yd)            # accumulates into a zeroed block
+        assert rel(Yd.to_dense(), ref) < 1e-13
+        op.matMvMult(hf.MultiVector.from_dense(Wd), Yd)            # ... and again: twice the mean (:214-221)
+        assert rel(Yd.to_dense(), 2 * ref) < 1e-13
+        v = hf.Vector()
+        op.init_vector(v)
+        assert v.size() == ref.shape[0]
+    assert obs.solves == 4 * len(Js)
+    ms = [hf.Vector() for _ in Js]
+    for m in ms:
+        m.init(13)
+    obs.i = -1
+    op = hf.SeriallySampledJacobianOperator(obs, noise, Prior(), operation="JTJ", ms=ms, average=False)
+    Yd = hf.MultiVector(13, 5)
+    op.matMvMult(hf.MultiVector.from_dense(W), Yd)
+    assert rel(Yd.to_dense(), np.sum([J.T @ (J @ W) for J in Js], axis=0)) < 1e-13
+    with pytest.raises(AssertionError):
+        op.matMvMult(hf.MultiVector.from_dense(W), hf.MultiVector(13, 4))
+
+
+def test_state_space_identity_operator_and_reference_names(ctx):
+    """StateSpaceIdentityOperator (fullStateObservable.py:18-52) and the reference's spelling of the dense wrapper."""
+    M, _ = _fem(300)
+    Mop = hf.CsrOperator(M)
+    x, y, p = hf.Vector(), hf.Vector(), hf.Vector()
+    ident = hf.StateSpaceIdentityOperator(Mop)
+    ident.init_vector(x, 0)
+    ident.init_vector(y, 0)
+    ident.init_vector(p, 1)
+    v = np.random.default_rng(2).standard_normal(300)
+    x.set_local(v)
+    ident.mult(x, y)
+    np.testing.assert_array_equal(y.get_local(), v)
+    ident.transpmult(x, p)
+    np.testing.assert_allclose(p.get_local(), M @ v, rtol=1e-13)
+    hf.StateSpaceIdentityOperator(Mop, use_mass_matrix=False).transpmult(x, p)
+    np.testing.assert_array_equal(p.get_local(), v)
+    assert hf.npToDolfinOperator is hf.npToDeviceOperator
