@@ -273,6 +273,70 @@ class ActiveSubspaceProjector:
                 _save(out, name + '_d_NG', self.d_NG)
         return result
 
+    # ---- consumers of the subspaces --------------------------------------------------
+    def construct_low_rank_Jacobians(self, check_for_data=True, compress_files=True):
+        """Randomized SVDs of this rank's Jacobians for derivative-informed training
+        (activeSubspaceProjector.py:690-900: ``hp.accuracyEnhancedSVD(J, Omega_m, parameter_rank, s=1)`` per sample,
+        rank ``min(jacobian_rank, q, N)``, dumped as ``J_on_proc{rank}.npz`` with keys U_data / sigma_data / V_data and
+        the matching ``mq_on_proc{rank}.npz``).  The Jacobians come from ``observable.jacobian_data(n)`` with
+        ``n = jacobian_data_per_process``; the samples themselves from ``observable.mq_data(n)`` when it exists.
+        Returns (U_data, sigma_data, V_data)."""
+        from .datasets import jacobian_svds
+        n = self.parameters['jacobian_data_per_process']
+        data = self.observable.jacobian_data(n)
+        if isinstance(data, tuple):
+            block, ndata, q = data
+        else:
+            data = np.asarray(data, dtype=np.float64)
+            ndata, q, dM = data.shape
+            block = MultiVector.from_vectors(data.reshape(ndata * q, dM), ctx=self.ctx)
+        parameter_rank = min(self.parameters['jacobian_rank'], q, block.size())                 # :724
+        U_data, sigma_data, V_data = jacobian_svds((block, ndata, q), parameter_rank)
+        out = self.parameters['output_directory']
+        if compress_files and out is not None:
+            os.makedirs(out, exist_ok=True)
+            proc_id = int(self.collective.rank())
+            np.savez_compressed(out + 'J_on_proc' + str(proc_id) + '.npz', U_data=U_data, sigma_data=sigma_data,
+                                V_data=V_data)                                                   # :877-878
+            if hasattr(self.observable, 'mq_data'):
+                m_data, q_data = self.observable.mq_data(ndata)
+                np.savez_compressed(out + 'mq_on_proc' + str(proc_id) + '.npz', m_data=m_data, q_data=q_data)   # :860
+        return U_data, sigma_data, V_data
+
+    def test_errors(self, test_input=True, test_output=False, ranks=[None], cut_off=1e-12, samples=None,
+                    output_samples=None):
+        """Projection-error tests of the active subspaces (activeSubspaceProjector.py:1037-1230): relative error of
+        ``x - V_r V_r^T R x`` (prior-preconditioned input basis; ``V_r V_r^T x`` otherwise, :1093-1096) over parameter
+        samples, and of ``q - U_r U_r^T q`` over observable samples.  ``samples`` / ``output_samples`` are blocks or
+        (n, dim) arrays; if omitted they come from ``prior.sample_block(n)`` / ``observable.sample_observables(n, ...)``
+        with ``n = error_test_samples`` (host PDE-side draws in the reference).  Returns the reference's tuple
+        ``(avg_input, std_input)`` / ``(avg_output, std_output)`` / all four, depending on the flags."""
+        from .errors import projection_error_test
+        want = max((r for r in ranks if r is not None), default=0)
+        results = []
+        if test_input:
+            if self.d_GN is None or len(self.d_GN) < want:
+                if want:
+                    self.parameters['rank'] = max(self.parameters['rank'], want)
+                self.construct_input_subspace()
+            if samples is None:
+                samples = self.prior.sample_block(self.parameters['error_test_samples'])
+            B = self.prior.R if self.prior_preconditioned else None
+            _, avg, std = projection_error_test(self.V_GN, samples, ranks, B=B, d=self.d_GN, cut_off=cut_off,
+                                                collective=self.collective)
+            results += [avg, std]
+        if test_output:
+            if self.d_NG is None or len(self.d_NG) < want:
+                if want:
+                    self.parameters['rank'] = max(self.parameters['rank'], want)
+                self.construct_output_subspace()
+            if output_samples is None:
+                output_samples = self.observable.sample_observables(self.parameters['error_test_samples'], self.prior, None)
+            _, avg, std = projection_error_test(self.U_NG, output_samples, ranks, d=self.d_NG, cut_off=cut_off,
+                                                collective=self.collective)
+            results += [avg, std]
+        return tuple(results)
+
 
 # =====================================================================================
 # KLE

@@ -839,3 +839,61 @@ def test_state_space_identity_operator_and_reference_names(ctx):
     hf.StateSpaceIdentityOperator(Mop, use_mass_matrix=False).transpmult(x, p)
     np.testing.assert_array_equal(p.get_local(), v)
     assert hf.npToDolfinOperator is hf.npToDeviceOperator
+
+
+def test_active_subspace_error_tests_and_low_rank_jacobians(ctx, tmp_path):
+    """ActiveSubspaceProjector.test_errors (activeSubspaceProjector.py:1037-1230) and construct_low_rank_Jacobians
+    (:690-900): projection errors decrease with rank and match a numpy evaluation of the same projector; the Jacobian
+    SVD dump has the reference's file names, keys and ranks."""
+    rng = np.random.default_rng(11)
+    ns, q, N = 12, 20, 900
+    P, _ = np.linalg.qr(rng.standard_normal((N, q)))
+    J = np.einsum("ioc,tc->iot", rng.standard_normal((ns, q, q)) * np.exp(-0.3 * np.arange(q))[None, None, :], P)
+    M, K = _fem(N)
+    A = (M + 1e-6 * K)
+    Rm = (A @ sp.diags(1.0 / np.asarray(M.sum(axis=1)).ravel()) @ A).tocsr()
+
+    class Prior:
+        pass
+
+    prior = Prior()
+    prior.R = Rm
+    prior.Rsolver = hp_o.SparseLUSolver(Rm)
+    m_data, q_data = rng.standard_normal((ns, N)), rng.standard_normal((ns, q))
+
+    class Obs:
+        def jacobian_data(self, n):
+            return J[:n]
+
+        def mq_data(self, n):
+            return m_data[:n], q_data[:n]
+
+    params = hf.ActiveSubspaceParameterList()
+    params["rank"], params["oversampling"], params["samples_per_process"] = 12, 6, ns
+    params["serialized_sampling"], params["verbose"], params["save_and_plot"] = False, False, False
+    params["jacobian_data_per_process"], params["jacobian_rank"] = ns, 6
+    params["output_directory"] = str(tmp_path) + "/"
+    asp = hf.ActiveSubspaceProjector(Obs(), prior, parameters=params)
+    Xs = rng.standard_normal((9, N)) @ (0.05 * np.eye(N) + P @ P.T)          # mostly inside the Jacobians' row space
+    Qs = rng.standard_normal((9, q))
+    avg_in, std_in, avg_out, std_out = asp.test_errors(test_input=True, test_output=True, ranks=[2, 6, 12], samples=Xs,
+                                                       output_samples=Qs)
+    assert avg_in.shape == (3,) and avg_in[0] > avg_in[1] > avg_in[2] > 0 and np.all(std_in >= 0)
+    assert avg_out[0] > avg_out[1] > avg_out[2] >= 0
+    V = asp.V_GN.to_dense()
+    for i, r in enumerate((2, 6, 12)):                                         # x - V_r V_r^T R x  (:1093-1111)
+        E = Xs.T - V[:, :r] @ (V[:, :r].T @ (Rm @ Xs.T))
+        ref = np.mean(np.linalg.norm(E, axis=0) / np.linalg.norm(Xs.T, axis=0))
+        assert abs(avg_in[i] - ref) < 1e-10 * max(ref, 1.0)
+    only_in = asp.test_errors(ranks=[6], samples=Xs)
+    assert len(only_in) == 2
+    U_data, sigma, V_data = asp.construct_low_rank_Jacobians()
+    assert U_data.shape == (ns, q, 6) and sigma.shape == (ns, 6) and V_data.shape == (ns, N, 6)
+    f = np.load(str(tmp_path) + "/J_on_proc0.npz")
+    assert sorted(f.files) == ["U_data", "V_data", "sigma_data"]
+    mq = np.load(str(tmp_path) + "/mq_on_proc0.npz")
+    assert sorted(mq.files) == ["m_data", "q_data"] and mq["m_data"].shape == (ns, N)
+    for i in range(ns):                                                        # rank-6 SVD of a rapidly decaying J
+        s_ref = np.linalg.svd(J[i], compute_uv=False)[:6]
+        np.testing.assert_allclose(sigma[i][:3], s_ref[:3], rtol=2e-2)
+        assert np.linalg.norm(U_data[i].T @ U_data[i] - np.eye(6)) < 1e-10
