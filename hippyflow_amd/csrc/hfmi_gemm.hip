@@ -24,6 +24,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define MFMA_F64_4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 // XCD-aware block id remap (8 XCDs, block b runs on XCD b % 8): consecutive logical ids land on the
 // same XCD so that workgroups sharing the LDS-staged operand also share an L2.  Bijective for any total.
@@ -48,23 +49,27 @@ constexpr int TN_LDB = 34;  // LDS leading dimension (doubles): 16-byte aligned 
 // WAVES = 4: one wave per SIMD with up to 32 accumulator tiles (256 AGPRs).  WAVES = 8: two waves per SIMD with
 // up to 16 tiles each -- same workgroup tile, but while one wave of a SIMD sits in a barrier / LDS / HBM wait the
 // other keeps the matrix pipe busy.
-template <int MT, int NT, bool TR, int WAVES, int RING>
+// R4 > 0: the LAST of the NT column tiles holds at most 4 R4 real columns and is computed with R4
+// v_mfma_f64_4x4x4_4b instructions (16 cycles each, four 4x4x4 blocks = the four 4-row groups of a 16-row tile)
+// instead of one 16x16x4 (64 cycles): k = 84 costs 5 x 64 + 16 cycles per k-step instead of 6 x 64, k = 74
+// 4 x 64 + 48 instead of 5 x 64.  Lane layout of the 4x4x4 instruction (scripts/mfma4x4_probe.hip): A lane
+// 16 k + 4 g + i = A_g[i][k], B lane 16 k + 4 g + j = B_g[k][j], D lane 16 i + 4 g + j = D_g[i][j] -- so the 16x16x4
+// A fragment (lane (row & 15, k)) already IS the 4x4x4 A operand with block g = rows 4g..4g+3, and B only has to be
+// read from LDS with the 4 columns of a group repeated for every block.
+template <int MT, int NT, bool TR, int WAVES, int R4>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
                                                                     const double* __restrict__ B, int64_t ldb, int k,
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ part, int mpad, int kpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // RING selects the LDS image of the staged operand (A/B knob "ring").  2: [column][34 doubles], padded rows;
-  // PMC shows 44 % of its LDS cycles are bank conflicts (one 2-way conflict per 16-lane group of every
-  // ds_read_b128).  4: [16 chunks][columns] of 16-byte elements, unpadded, column XOR (chunk & 7) -- the layout of
-  // k_tsgemm_ss, conflict free for the fragment reads and the staging writes.
   constexpr int BK = TN_BK;
   constexpr int COLS = NT * 16;
-  constexpr bool SWZ = (RING == 4);
   constexpr int LDB = BK + 2;
-  constexpr int BUFD = SWZ ? (BK / 2) * COLS * 2 : COLS * LDB;   // doubles per stage buffer
+  constexpr int BUFD = COLS * LDB;                // doubles per stage buffer
   constexpr int CSH = 4;                          // log2(16-byte chunks per column per stage)
-  double* lds = reinterpret_cast<double*>(smem);  // [2][BUFD]
+  constexpr int NTF = R4 > 0 ? NT - 1 : NT;       // full 16-column tiles
+  constexpr int NR4 = R4 > 0 ? R4 : 1;
+  double* lds = reinterpret_cast<double*>(smem);  // [2][NT*16][LDB]
   constexpr int NTHR = WAVES * 64;
   constexpr int CH = COLS * (BK / 2);             // 16-byte chunks per stage
   constexpr int NQ = (CH + NTHR - 1) / NTHR;      // chunks per thread
@@ -97,11 +102,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     b_ptr[qd] = B + (int64_t)col * ldb + (c & ((1 << CSH) - 1)) * 2;
   }
 
-  d4 acc[MT][NT];
+  constexpr int NTA = NTF > 0 ? NTF : 1;
+  d4 acc[MT][NTA];
+  double acc4[MT][NR4];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int nt = 0; nt < NTA; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NR4; ++q) acc4[mt][q] = 0.0;
+  }
 
   d2 breg[NQ];
   auto stage_load = [&](int64_t ts) {
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     for (int qd = 0; qd < NQ; ++qd) {
       const int c = tid + NTHR * qd;
       const int col = c >> CSH, q = c & ((1 << CSH) - 1);
-      const int off = SWZ ? (q * COLS + (col ^ (q & 7))) * 2 : col * LDB + q * 2;
+      const int off = col * LDB + q * 2;
       if (CH % NTHR == 0 || c < CH) *reinterpret_cast<d2*>(L + off) = breg[qd];
     }
   };
@@ -122,25 +132,44 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const d2*>(a_ptr[mt] + t);
   };
-  auto ldsb = [&](d2(&bf)[NT], const double* L, int it) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      bf[nt] = SWZ ? *reinterpret_cast<const d2*>(L + ((it * 4 + kk) * COLS + nt * 16 + (r16 ^ ((it * 4 + kk) & 7))) * 2)
-                   : *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * LDB + it * 8 + kk * 2);
+  // Full tiles: lane (r16, kk) reads column nt*16 + r16.  The fragments are SINGLE-buffered: the moment the MFMAs
+  // of column tile nt have been issued, its registers are refilled with the next iteration's fragment, and the MFMAs of
+  // the other column tiles cover the LDS latency (the sched_barriers pin that order; left alone the scheduler hoists
+  // all reads to the top, which is the double-buffered register budget again -- 4 NT VGPRs more).  The 4-column groups
+  // of the last tile (lane -> column NTF*16 + 4 q + (lane & 3), the same for every row group) are read at the top of
+  // their own iteration; the full-tile MFMAs in front of them cover the latency.
+  d2 bf[NTA];
+  auto ldsb1 = [&](const double* L, int it, int nt) {
+    bf[nt] = *reinterpret_cast<const d2*>(L + (nt * 16 + r16) * LDB + it * 8 + kk * 2);
   };
-  auto mma = [&](const d2(&a)[MT], const d2(&bf)[NT]) {
+  auto mma = [&](const d2(&a)[MT], const double* L, int it, bool refill) {
+    d2 bg[NR4];
+    if constexpr (R4 > 0) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int q = 0; q < R4; ++q)
+        bg[q] = *reinterpret_cast<const d2*>(L + (NTF * 16 + 4 * q + (lane & 3)) * LDB + it * 8 + kk * 2);
+    }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (TR) {
-          acc[mt][nt] = MFMA_F64(bf[nt].x, a[mt].x, acc[mt][nt]);
-          acc[mt][nt] = MFMA_F64(bf[nt].y, a[mt].y, acc[mt][nt]);
-        } else {
-          acc[mt][nt] = MFMA_F64(a[mt].x, bf[nt].x, acc[mt][nt]);
-          acc[mt][nt] = MFMA_F64(a[mt].y, bf[nt].y, acc[mt][nt]);
-        }
-      }
+    for (int nt = 0; nt < NTF; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = TR ? MFMA_F64(bf[nt].x, a[mt].x, acc[mt][nt]) : MFMA_F64(a[mt].x, bf[nt].x, acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = TR ? MFMA_F64(bf[nt].y, a[mt].y, acc[mt][nt]) : MFMA_F64(a[mt].y, bf[nt].y, acc[mt][nt]);
+      if (refill) ldsb1(L, it + 1, nt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (R4 > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < R4; ++q) acc4[mt][q] = MFMA_F64_4(a[mt].x, bg[q].x, acc4[mt][q]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < R4; ++q) acc4[mt][q] = MFMA_F64_4(a[mt].y, bg[q].y, acc4[mt][q]);
+    }
     // keep the scheduler from hoisting later iterations' loads above these MFMAs
     // (it would otherwise blow the register budget and spill the accumulators)
     __builtin_amdgcn_sched_barrier(0);
@@ -151,11 +180,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     stage_store(lds);
     __syncthreads();
   }
-  // streamed operand: register ring over iterations of 8 reduction indices; the LDS fragments of iteration it+1 are
-  // read before the MFMAs of iteration it
+  // streamed operand: register ring over iterations of 8 reduction indices
   {
     constexpr int NIT = BK / 8;
-    d2 bf[2][NT];
     d2 a[2][MT];
     load_a(a[0], t_begin);
     for (int s = 0; s < nstages; ++s) {
@@ -163,12 +190,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
       const bool has_next = s + 1 < nstages;
       if (has_next) stage_load(ts + BK);
       const double* L = lds + (s & 1) * BUFD;
-      ldsb(bf[0], L, 0);
+#pragma unroll
+      for (int nt = 0; nt < NTF; ++nt) ldsb1(L, 0, nt);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         load_a(a[(it + 1) & 1], ts + 8 * (it + 1));
-        if (it + 1 < NIT) ldsb(bf[(it + 1) & 1], L, it + 1);
-        mma(a[it & 1], bf[it & 1]);
+        mma(a[it & 1], L, it, it + 1 < NIT);
       }
       if (has_next) stage_store(lds + ((s + 1) & 1) * BUFD);
       __syncthreads();
@@ -179,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NTF; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (TR) {
@@ -192,6 +219,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
           P[(int64_t)i * kpad + j] = acc[mt][nt][r];
         }
       }
+  if constexpr (R4 > 0) {
+    // 4x4x4 results: lane 16 i + 4 g + j holds (row 4 g + i of the tile, column 4 q + j of the last tile)
+    const int i4 = lane >> 4, g4 = (lane >> 2) & 3, j4 = lane & 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        const int i = rowbase + mt * 16 + 4 * g4 + i4;
+        const int j = NTF * 16 + 4 * q + j4;
+        if (TR) P[(int64_t)j * mpad + i] = acc4[mt][q];
+        else P[(int64_t)i * kpad + j] = acc4[mt][q];
+      }
+  }
 }
 
 // C[i*rs + j*cs] = scale * sum_sp part[sp][...] + beta * C.  A workgroup is 64 outputs x RY split lanes: lane y sums
@@ -296,33 +336,27 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 
 #include <stdlib.h>
 #include <string.h>
-// Tuning knobs of the MFMA kernels (A/B measurements: environment HFMI_GEMM_WAVES / HFMI_GEMM_RING, or
+// Tuning knobs of the MFMA kernels (A/B measurements: environment HFMI_GEMM_WAVES, or
 // hfmi_tuning_set at run time).
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
-//   ring : LDS image of the staged operand in tsgemm_tn (2 = padded rows, 4 = unpadded XOR-swizzled chunks)
-static int g_waves = 0, g_ring = 0, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
+//   rem4 : compute a last column tile of <= 12 columns with 4x4x4 MFMAs (1, default) or as a full 16-column tile (0)
+static int g_waves = 0, g_rem4 = 1, g_nn_waves = 0;  // g_nn_waves: 0 = auto (4 for <= 9 column tiles, else 8)
 static int g_nn_hybrid = 1;                          // split only the row tiles beyond the last full round of CUs
 static int g_nn_tt = 0;                              // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
   if (g_waves) return;
   const char* e = getenv("HFMI_GEMM_WAVES");
-  g_waves = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 44) ? 44 : 8;   // measured: 8 waves + ring 2 is best or equal on every shape (scripts/gemm_ab.py)
-  e = getenv("HFMI_GEMM_RING");
-  g_ring = (e && atoi(e) == 4) ? 4 : 2;
+  g_waves = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 44) ? 44 : 8;   // measured: 8 waves is best or equal on every shape (scripts/gemm_ab.py)
 }
 static int gemm_waves() {
   tuning_init();
   return g_waves;
 }
-static int gemm_ring() {
-  tuning_init();
-  return g_ring;
-}
 extern "C" int hfmi_tuning_set(const char* key, int value) {
   tuning_init();
   if (key && !strcmp(key, "waves") && (value == 4 || value == 8 || value == 44)) g_waves = value;
-  else if (key && !strcmp(key, "ring") && (value == 2 || value == 4)) g_ring = value;
+  else if (key && !strcmp(key, "rem4") && (value == 0 || value == 1)) g_rem4 = value;
   else if (key && !strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
   else if (key && !strcmp(key, "nn_tt") && value >= 0 && value <= 3) g_nn_tt = value;
@@ -338,11 +372,11 @@ static inline int tn_mt_max(int nt, int waves) {
   return waves == 4 ? t4[nt] : t8[nt];
 }
 
-template <int MT, int NT, int WAVES, bool TR, int RING>
+template <int MT, int NT, int WAVES, bool TR, int R4>
 static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t N,
                          int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  const size_t shmem = (size_t)2 * NT * 16 * (RING == 4 ? TN_BK : TN_BK + 2) * sizeof(double);
-  auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, RING>;
+  const size_t shmem = (size_t)2 * NT * 16 * (TN_BK + 2) * sizeof(double);
+  auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, R4>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,
                      nsplit, part, mpad, kpad);
@@ -350,27 +384,31 @@ static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
   return HFMI_OK;
 }
 
+// r4: number of 4-column groups the last column tile is computed in (0 = as a full 16-column tile)
 template <int MT, int NT, int WAVES>
-static int tn_launch_inst(hfmi_ctx* ctx, bool tr, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
+static int tn_launch_inst(hfmi_ctx* ctx, bool tr, int r4, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
                           int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
-  const bool ring4 = gemm_ring() == 4;
-  if (tr) {
-    if (ring4) return tn_launch_one<MT, NT, WAVES, true, 4>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
-    return tn_launch_one<MT, NT, WAVES, true, 2>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+#define TN_R4(R)                                                                                                          \
+  case R:                                                                                                                 \
+    if (tr) return tn_launch_one<MT, NT, WAVES, true, R>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad); \
+    return tn_launch_one<MT, NT, WAVES, false, R>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+  if constexpr (WAVES == 8) {
+    switch (r4) { TN_R4(1) TN_R4(2) TN_R4(3) }
   }
-  if (ring4) return tn_launch_one<MT, NT, WAVES, false, 4>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
-  return tn_launch_one<MT, NT, WAVES, false, 2>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+  switch (0) { TN_R4(0) }
+#undef TN_R4
+  return HFMI_OK;
 }
 
 template <int NT, int WAVES>
-static int tn_dispatch_mt(hfmi_ctx* ctx, int mt, bool tr, const double* A, int64_t lda, int m, const double* B,
+static int tn_dispatch_mt(hfmi_ctx* ctx, int mt, bool tr, int r4, const double* A, int64_t lda, int m, const double* B,
                           int64_t ldb, int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad,
                           int kpad) {
   constexpr int LIM = (WAVES == 8) ? 20 : 32;
 #define TN_CASE(M)                                                                                                 \
   case M:                                                                                                          \
     if constexpr (M * NT <= LIM)                                                                                   \
-      return tn_launch_inst<M, NT, WAVES>(ctx, tr, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad); \
+      return tn_launch_inst<M, NT, WAVES>(ctx, tr, r4, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad); \
     break;
   switch (mt) {
     TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(8)
@@ -434,13 +472,16 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   HFMI_TRY(ctx_ws(ctx, WS_PART, (size_t)nsplit * mpad * kpad * sizeof(double), &partv));
   double* part = (double*)partv;
   // algorithmic work of this launch: flops 2 N m k, bytes 8 (N m + N k + m k)
+  // columns of the last tile: up to 12 are done as 1..3 groups of 4 with the 4x4x4 MFMA (16 instead of 64 cycles each)
+  const int rem = k - (nt - 1) * 16;
+  const int r4 = (g_rem4 && waves == 8 && rem <= 12) ? (rem + 3) / 4 : 0;
   const int pidx = prof_start(ctx, 0, m, k, N);
 #define TN_NT(NTV)                                                                                                       \
   case NTV:                                                                                                              \
     if (waves == 8)                                                                                                      \
-      HFMI_TRY((tn_dispatch_mt<NTV, 8>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
+      HFMI_TRY((tn_dispatch_mt<NTV, 8>(ctx, mt, tr, r4, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
     else                                                                                                                 \
-      HFMI_TRY((tn_dispatch_mt<NTV, 4>(ctx, mt, tr, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
+      HFMI_TRY((tn_dispatch_mt<NTV, 4>(ctx, mt, tr, 0, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
     break;
   switch (nt) {
     TN_NT(1) TN_NT(2) TN_NT(3) TN_NT(4) TN_NT(5) TN_NT(6) TN_NT(7) TN_NT(8) TN_NT(9) TN_NT(10) TN_NT(11) TN_NT(12)
@@ -476,7 +517,11 @@ constexpr int NN_KC = 32;  // reduction indices per LDS stage (8 MFMA k-steps)
 // The reduction axis m may be split over gridDim-many workgroups (msplit > 1): each split writes a raw partial
 // block and k_reduce_nn adds them in a fixed order -- this is what balances the grid over the 256 CUs when
 // there are only a few row tiles (quantisation), at the price of msplit * N * r * 16 bytes of extra traffic.
-template <int TT, int NT, int WAVES>
+// R4 > 0: the last column tile has at most 4 R4 real columns and is computed in R4 groups of 4 columns with the
+// 4x4x4 MFMA (see k_tsgemm_tn): the streamed fragment (lane (c16, kk) = long-axis row c16, reduction index kk) is its B
+// operand with block g = rows 4g..4g+3, the small-matrix fragment (column 4 q + (lane & 3), the same for every block)
+// its A operand, and lane 16 i + 4 g + j receives Y[row 4 g + j = c16][column 4 q + i = 4 q + kk].
+template <int TT, int NT, int WAVES, int R4>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
                                                                     const double* __restrict__ S, int lds_, int r,
                                                                     double* __restrict__ Y, int64_t ldy, int64_t N,
@@ -493,6 +538,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   constexpr int NTHR = WAVES * 64;
   constexpr int CH = NN_KC * COLS / 2;            // 16-byte pairs per stage
   constexpr int NQ = (CH + NTHR - 1) / NTHR;      // pairs per thread
+  constexpr int NTF = R4 > 0 ? NT - 1 : NT;       // full 16-column tiles
+  constexpr int NTA = NTF > 0 ? NTF : 1;
+  constexpr int NR4 = R4 > 0 ? R4 : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, kk = lane >> 4;
   // Row tiles [0, full_tiles) are whole rounds of the CUs: one workgroup each over the full reduction range, written
@@ -534,11 +582,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
     s_cp[qd] = c % (COLS / 2);
   }
 
-  d4 acc[TT][NT];
+  d4 acc[TT][NTA];
+  double acc4[TT][NR4];
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt)
+  for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[tt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int nt = 0; nt < NTA; ++nt) acc[tt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NR4; ++q) acc4[tt][q] = 0.0;
+  }
 
   struct AFrag {
     d2 p[TPA];
@@ -569,21 +621,41 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
     for (int tp = 0; tp < TP; ++tp) dst.p[tp] = *reinterpret_cast<const d2*>(p + toff[tp]);
     if (ODD) dst.s = p[toff1];
   };
-  auto ldss = [&](double(&sf)[NT], const double* L, int ks) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) sf[nt] = L[(ks * 4 + kk) * SLD + nt * 16 + c16];
+  struct SFrag {
+    double f[NTA];   // full tiles: column nt*16 + c16
+    double g[NR4];   // 4-column groups of the last tile: column NTF*16 + 4 q + (lane & 3)
   };
-  auto mma = [&](const AFrag& a, const double(&sf)[NT]) {
+  auto ldss = [&](SFrag& sf, const double* L, int ks) {
 #pragma unroll
-    for (int tp = 0; tp < TP; ++tp)
+    for (int nt = 0; nt < NTF; ++nt) sf.f[nt] = L[(ks * 4 + kk) * SLD + nt * 16 + c16];
+    if constexpr (R4 > 0) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        acc[2 * tp][nt] = MFMA_F64(sf[nt], a.p[tp].x, acc[2 * tp][nt]);
-        acc[2 * tp + 1][nt] = MFMA_F64(sf[nt], a.p[tp].y, acc[2 * tp + 1][nt]);
+      for (int q = 0; q < R4; ++q) sf.g[q] = L[(ks * 4 + kk) * SLD + NTF * 16 + 4 * q + (lane & 3)];
+    }
+  };
+  auto mma = [&](const AFrag& a, const SFrag& sf) {
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+#pragma unroll
+      for (int nt = 0; nt < NTF; ++nt) {
+        acc[2 * tp][nt] = MFMA_F64(sf.f[nt], a.p[tp].x, acc[2 * tp][nt]);
+        acc[2 * tp + 1][nt] = MFMA_F64(sf.f[nt], a.p[tp].y, acc[2 * tp + 1][nt]);
       }
+      if constexpr (R4 > 0) {
+#pragma unroll
+        for (int q = 0; q < R4; ++q) {
+          acc4[2 * tp][q] = MFMA_F64_4(sf.g[q], a.p[tp].x, acc4[2 * tp][q]);
+          acc4[2 * tp + 1][q] = MFMA_F64_4(sf.g[q], a.p[tp].y, acc4[2 * tp + 1][q]);
+        }
+      }
+    }
     if (ODD) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[TT - 1][nt] = MFMA_F64(sf[nt], a.s, acc[TT - 1][nt]);
+      for (int nt = 0; nt < NTF; ++nt) acc[TT - 1][nt] = MFMA_F64(sf.f[nt], a.s, acc[TT - 1][nt]);
+      if constexpr (R4 > 0) {
+#pragma unroll
+        for (int q = 0; q < R4; ++q) acc4[TT - 1][q] = MFMA_F64_4(sf.g[q], a.s, acc4[TT - 1][q]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -593,7 +665,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   __syncthreads();
   // register ring of 4 k-steps for the streamed operand (prefetch distance 3), ping-pong LDS fragments
   AFrag a0, a1, a2, a3;
-  double sf0[NT], sf1[NT];
+  SFrag sf0, sf1;
   load_a(a0, i_begin);
   load_a(a1, i_begin + 4);
   load_a(a2, i_begin + 8);
@@ -633,7 +705,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   // Raw accumulator stores only: any VALU arithmetic on the accumulators here makes hipcc keep them in
   // VGPRs across the loop back-edge (256 v_accvgpr copies per stage); scaling/accumulation is done by the caller.
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < NTF; ++nt)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int j = nt * 16 + kk + 4 * rg;
@@ -654,6 +726,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
         }
       }
     }
+  if constexpr (R4 > 0) {
+#pragma unroll
+    for (int q = 0; q < R4; ++q) {
+      const int j = NTF * 16 + 4 * q + kk;
+      if (j < r) {
+        double* yc = Yo + (int64_t)j * ldout;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          const int64_t t = t0 + tp * 32 + 2 * c16;
+          if (t + 1 < N) {
+            *reinterpret_cast<d2*>(yc + t) = d2{acc4[2 * tp][q], acc4[2 * tp + 1][q]};
+          } else if (t < N) {
+            yc[t] = acc4[2 * tp][q];
+          }
+        }
+        if (ODD) {
+          const int64_t t = t0 + TP * 32 + c16;
+          if (t < N) yc[t] = acc4[TT - 1][q];
+        }
+      }
+    }
+  }
 }
 
 // Y[j][t] = sum_s part[s][j][t]  (fixed order), rows row0 <= t < N (row0 even)
@@ -718,7 +812,11 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
                           double* Y, int64_t ldy, int64_t N, int msplit, bool tail_split = false) {
   constexpr int SLD = NT * 16 + ((NT % 2 == 0) ? 16 : 0);
   const size_t shmem = (size_t)2 * NN_KC * SLD * sizeof(double);
-  auto kern = k_tsgemm_nn<TT, NT, WAVES>;
+  // columns of the last tile: up to 12 are done as 1..3 groups of 4 with the 4x4x4 MFMA
+  const int rem = r - (NT - 1) * 16;
+  const int r4 = (g_rem4 && rem <= 12) ? (rem + 3) / 4 : 0;
+  auto kern = r4 == 1 ? k_tsgemm_nn<TT, NT, WAVES, 1> : r4 == 2 ? k_tsgemm_nn<TT, NT, WAVES, 2>
+            : r4 == 3 ? k_tsgemm_nn<TT, NT, WAVES, 3> : k_tsgemm_nn<TT, NT, WAVES, 0>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const int tile_rows = 16 * TT * WAVES;
   const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
