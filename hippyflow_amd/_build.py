@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhfmi.so")
-SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip"]
+SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -36,7 +36,7 @@ def build(force=False, verbose=True):
     """Compile every translation unit for gfx950 and link hippyflow_amd/libhfmi.so."""
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "hfmi_internal.h"), os.path.join(INCLUDE, "hfmi.h")]
+    headers = [os.path.join(CSRC, "hfmi_internal.h"), os.path.join(CSRC, "hfmi_gemm_common.h"), os.path.join(INCLUDE, "hfmi.h")]
     jobs = []
     objs = []
     for src in SOURCES:
@@ -55,7 +55,7 @@ def build(force=False, verbose=True):
         return r.stdout
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(5, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or not _newer(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
