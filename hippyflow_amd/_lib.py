@@ -166,6 +166,12 @@ class Context:
     def set_stream(self, stream_ptr):
         call("hfmi_ctx_set_stream", self.handle, C.c_void_p(stream_ptr))
 
+    def get_stream(self):
+        """The HIP stream every kernel of this context is launched on (hipStream_t as an integer)."""
+        s = C.c_void_p()
+        call("hfmi_ctx_get_stream", self.handle, C.byref(s))
+        return s.value or 0
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus = C.c_int(0)

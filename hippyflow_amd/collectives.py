@@ -109,30 +109,53 @@ class TorchCollective:
         mv.ctx.synchronize()
         return t, stage
 
+    def _on_block_stream(self, mv):
+        """Context manager that makes libhfmi's stream torch's current stream: the collective is then ordered after the
+        kernels that produced the block and before the ones that consume it by stream semantics alone (ProcessGroupNCCL
+        makes its communication stream wait on the current stream and, for a blocking call, the current stream wait on
+        the collective) -- no host synchronisation on the solve's critical path."""
+        import torch
+        sp = mv.ctx.get_stream()
+        if not sp or self.dist.get_backend(self.group) != "nccl":
+            return None
+        return torch.cuda.stream(torch.cuda.ExternalStream(sp, device=torch.device("cuda", mv.ctx.device)))
+
     def _reduce_block(self, mv, op):
         import torch
         if op not in ("sum", "avg"):
             raise NotImplementedError("Unknown operation *{0}* in TorchCollective.allReduce".format(op))
-        mv.ctx.synchronize()                       # libhfmi's stream -> host: the block is complete
         t, stage = self._tensor_of(mv)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        if op == "avg":
-            t.mul_(1.0 / float(self.size()))
-        torch.cuda.current_stream(mv.ctx.device).synchronize()   # RCCL + scale done before libhfmi reads
-        if stage is not None:
-            mv.copy_from(stage)
-            mv.ctx.synchronize()
+        cm = self._on_block_stream(mv) if stage is None else None
+        if cm is None:
+            mv.ctx.synchronize()                   # libhfmi's stream -> host: the block is complete
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if op == "avg":
+                t.mul_(1.0 / float(self.size()))
+            torch.cuda.current_stream(mv.ctx.device).synchronize()   # RCCL + scale done before libhfmi reads
+            if stage is not None:
+                mv.copy_from(stage)
+                mv.ctx.synchronize()
+            return mv
+        with cm:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if op == "avg":
+                t.mul_(1.0 / float(self.size()))
         return mv
 
     def _bcast_block(self, mv, root):
         import torch
-        mv.ctx.synchronize()
         t, stage = self._tensor_of(mv)
-        self.dist.broadcast(t, src=root, group=self.group)
-        torch.cuda.current_stream(mv.ctx.device).synchronize()
-        if stage is not None:
-            mv.copy_from(stage)
+        cm = self._on_block_stream(mv) if stage is None else None
+        if cm is None:
             mv.ctx.synchronize()
+            self.dist.broadcast(t, src=root, group=self.group)
+            torch.cuda.current_stream(mv.ctx.device).synchronize()
+            if stage is not None:
+                mv.copy_from(stage)
+                mv.ctx.synchronize()
+            return mv
+        with cm:
+            self.dist.broadcast(t, src=root, group=self.group)
         return mv
 
     def allReduce(self, v, op):

@@ -4,7 +4,7 @@
 #include "hfmi_gemm_common.h"
 #include <string.h>
 
-static int g_nn_waves = 0;    // 0 = auto (4 for <= 9 column tiles, else 8)
+static int g_nn_waves = 0;    // 0 = auto (4 for <= 6 column tiles, else 8)
 static int g_nn_hybrid = 1;   // split only the row tiles beyond the last full round of CUs
 static int g_nn_tt = 0;       // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_rem4 = 1;        // last column tile of <= 12 columns in 4-column groups (4x4x4 MFMA)
@@ -411,14 +411,14 @@ static int nn_launch_w8(hfmi_ctx* ctx, const double* A, int64_t lda, int m, cons
 static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
                     int64_t ldy, int64_t N) {
   const int nt = (r + 15) / 16;
-  const int waves = g_nn_waves ? g_nn_waves : (nt >= 10 ? 8 : 4);   // A/B (scripts/gemm_ab.py, r01e): 4 waves win up to 9 column tiles
+  const int waves = g_nn_waves ? g_nn_waves : (nt >= 7 ? 8 : 4);   // A/B (scripts/nn_waves_ab.py, r01g): one wave per SIMD wins up to 6 column tiles
 #define NN_CASE(NTV, TT4, TT8)                                                             \
   case NTV:                                                                                \
     if (waves == 8) return nn_launch_w8<NTV, TT8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);  \
     return nn_launch_w4<NTV, TT4>(ctx, A, lda, m, S, lds_, r, Y, ldy, N);
   switch (nt) {
     NN_CASE(1, 8, 8) NN_CASE(2, 8, 8) NN_CASE(3, 8, 5) NN_CASE(4, 8, 4) NN_CASE(5, 6, 3) NN_CASE(6, 5, 2)
-    NN_CASE(7, 4, 2) NN_CASE(8, 4, 2) NN_CASE(9, 3, 1) NN_CASE(10, 3, 1) NN_CASE(11, 2, 1) NN_CASE(12, 2, 1)
+    NN_CASE(7, 4, 2) NN_CASE(8, 4, 2) NN_CASE(9, 3, 2) NN_CASE(10, 3, 1) NN_CASE(11, 2, 1) NN_CASE(12, 2, 1)
     NN_CASE(13, 2, 1) NN_CASE(14, 2, 1) NN_CASE(15, 2, 1) NN_CASE(16, 2, 1)
   }
 #undef NN_CASE

@@ -198,8 +198,10 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * kind[g] 0 = k_tsgemm_tn (or k_tsgemm_ss for skinny x skinny shapes), 1 = k_tsgemm_nn; shape[3*g..] = (short-side rows m, columns k, long axis N);
  * total milliseconds, launches, and the ALGORITHMIC flops / bytes of one launch. */
 /* kernel tuning knobs for in-process A/B measurements (defaults are the measured winners; scripts/gemm_ab.py,
- * scripts/ss_ab.py, scripts/nn_tt_probe.py): ("waves", 8|4|44) tsgemm_tn workgroup shape (44 = two 4-wave workgroups
- * per CU); ("ring", 2|4) tsgemm_tn LDS image of the staged operand (padded rows | XOR-swizzled chunks); ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
+ * scripts/ss_ab.py, scripts/nn_tt_probe.py, scripts/nn_waves_ab.py): ("waves", 8|4|44) tsgemm_tn workgroup shape (44 = two 4-wave workgroups
+ * per CU); ("rem4", 1|0) last column tile of <= 12 columns as 4-column groups on the 4x4x4 MFMA | as a full 16-column tile;
+ * ("probe", 0..3) timing-only diagnostic of tsgemm_tn (bit 0: the streamed operand re-reads one address, bit 1: no staging /
+ * barriers; results are garbage -- scripts/tn_probe.py); ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
  * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("ss", 0|1) route skinny x skinny contractions to
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized. */
 int hfmi_tuning_set(const char* key, int value);
