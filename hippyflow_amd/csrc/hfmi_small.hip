@@ -759,6 +759,214 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig(const double* __re
   }
 }
 
+// The 2x2 block update shared by the update phase and the look-ahead pivots of k_jacobi_eig_db (which must
+// reproduce the stored values bit for bit): z = J_P^T [x1; x2] J_Q, rp / rq = (c, s) of pairs P / Q.
+__device__ __forceinline__ void jac_block(double2 x1, double2 x2, const double2 rp, const double2 rq, const bool diag,
+                                          double& z11, double& z12, double& z21, double& z22) {
+  if (diag) x2.x = x1.y;  // below the diagonal of a diagonal block: not stored
+  const double y11 = rq.x * x1.x - rq.y * x1.y, y12 = rq.y * x1.x + rq.x * x1.y;
+  const double y21 = rq.x * x2.x - rq.y * x2.y, y22 = rq.y * x2.x + rq.x * x2.y;
+  z11 = rp.x * y11 - rp.y * y21;
+  z21 = rp.y * y11 + rp.x * y21;
+  z12 = rp.x * y12 - rp.y * y22;
+  z22 = rp.y * y12 + rp.x * y22;
+  if (diag && rp.y != 0.0) z12 = 0.0;  // the annihilated pivot (an identity rotation keeps it)
+}
+
+// k_jacobi_eig_db: the same tournament with ONE barrier per round instead of three (n <= 138).
+//  * The block-upper triangle is PACKED, block (P, Q), P <= Q, at index P np - P (P - 1) / 2 + Q - P, in two planes
+//    of 16-byte elements (top row / bottom row of the 2x2 block), and there are TWO such images: a round reads one and
+//    writes the players' next seats into the other, so no barrier separates its reads from its writes
+//    (2 x 2 x 2415 x 16 B = 154.6 KB at n = 138 -- the full square would not fit twice).
+//  * The rotations of round g + 1 are computed DURING round g by the last two waves, which own no blocks: pair P' of the
+//    next round is made of two players that sit in different pairs now, its three entries are three values the update
+//    phase is about to store, and the look-ahead threads recompute exactly those (jac_block on the three source blocks,
+//    same operation order) from the old image and the current rotations.  The dependent chain LDS read -> rotation ->
+//    barrier -> LDS read -> update -> LDS write -> barrier of the three-barrier kernel becomes max(update, look-ahead).
+template <int NB>
+__global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* __restrict__ T, int ldt, int k,
+                                                                 double2* __restrict__ rotlog, double* __restrict__ dvals,
+                                                                 int* __restrict__ perm, int sort_by_abs,
+                                                                 hfmi_status_words* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);                // 32
+  double2* rot = reinterpret_cast<double2*>(red + 32);          // 2 x 128 (c, s) per pair: this round / next round
+  double* Ad = reinterpret_cast<double*>(rot + 256);            // 256 diagonal copy / keys
+  double2* img = reinterpret_cast<double2*>(Ad + 256);          // [2 images][2 planes][nblk]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int n = (k + 1) & ~1;  // players (one dummy if k is odd: a zero row/column that is never rotated)
+  const int np = n / 2;
+  const int nblk = np * (np + 1) / 2;
+  const int nupd = nthr - 128;                                   // update threads; the last two waves look ahead
+  const float inv_np1 = __frcp_rn((float)(np + 1));
+  const int cells = ((np + 1) >> 1) * (np + 1);
+  auto bidx = [&](int P, int Q) { return P * np - P * (P - 1) / 2 + (Q - P); };
+  // double index (within one image) of entry (r, c) of the seat-ordered matrix; lower entries map to their mirror
+  auto seat = [&](int r, int c) {
+    const bool upper = (r >> 1) != (c >> 1) ? (r >> 1) < (c >> 1) : r <= c;
+    const int rr = upper ? r : c, cc = upper ? c : r;
+    return 2 * ((rr & 1) * nblk + bidx(rr >> 1, cc >> 1)) + (cc & 1);
+  };
+
+  // this thread's blocks: element index in a plane, and the next-round seats of its four entries
+  int bx[NB], d11[NB], d12[NB], d21[NB], d22[NB], P_[NB], Q_[NB];
+  bool live[NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) {
+    const int e = tid + bi * nupd;
+    int P = 0, Q = 0;
+    live[bi] = tid < nupd && e < cells && tri_cell(e, np, inv_np1, P, Q);
+    P_[bi] = P;
+    Q_[bi] = Q;
+    bx[bi] = bidx(P, Q);
+    const int r1 = jac_next_slot(2 * P, n), r2 = jac_next_slot(2 * P + 1, n);
+    const int c1 = jac_next_slot(2 * Q, n), c2 = jac_next_slot(2 * Q + 1, n);
+    d11[bi] = seat(r1, c1);
+    d12[bi] = seat(r1, c2);
+    d21[bi] = seat(r2, c1);
+    d22[bi] = seat(r2, c2);
+  }
+  // look-ahead thread pi: the pair that will sit in seats (2 pi, 2 pi + 1) comes from the seats a, b of this round
+  const int pi = tid - nupd;
+  const bool ahead = pi >= 0 && pi < np;
+  int pa = 0, pb = 0, ia = 0, ib = 0, bab = 0;
+  bool ab_swapped = false;
+  if (ahead) {
+    int a = 0, b = 0;
+    for (int sl = 0; sl < n; ++sl) {
+      const int nx = jac_next_slot(sl, n);
+      if (nx == 2 * pi) a = sl;
+      if (nx == 2 * pi + 1) b = sl;
+    }
+    pa = a >> 1; ia = a & 1; pb = b >> 1; ib = b & 1;
+    ab_swapped = pb < pa;
+    bab = ab_swapped ? bidx(pb, pa) : bidx(pa, pb);
+  }
+
+  // load (symmetrised) into image 0, seat order == index order
+  double fro = 0.0;
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) {
+    if (!live[bi]) continue;
+    double v[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = 2 * P_[bi] + i, c = 2 * Q_[bi] + j;
+        v[i][j] = (r < k && c < k) ? 0.5 * (T[r * ldt + c] + T[c * ldt + r]) : 0.0;
+      }
+    img[bx[bi]] = make_double2(v[0][0], v[0][1]);
+    img[nblk + bx[bi]] = make_double2(v[1][0], v[1][1]);
+    if (P_[bi] == Q_[bi]) fro += v[0][0] * v[0][0] + v[1][1] * v[1][1] + 2.0 * v[0][1] * v[0][1];
+    else fro += 2.0 * (v[0][0] * v[0][0] + v[0][1] * v[0][1] + v[1][0] * v[1][0] + v[1][1] * v[1][1]);
+  }
+  fro = block_sum(fro, red);
+  __syncthreads();
+  const double tol2 = EPS_D * EPS_D * fro;
+  const long long max_rounds = (long long)JAC_MAX_SWEEPS * (n - 1);
+
+  // rotations of the very first round, straight from the diagonal blocks
+  if (tid < np) {
+    const double2 top = img[bidx(tid, tid)], bot = img[nblk + bidx(tid, tid)];
+    double c, sn;
+    jac_rotation(top.x, top.y, bot.y, c, sn);
+    rot[tid] = make_double2(c, sn);
+    rotlog[tid] = make_double2(c, sn);
+  }
+  __syncthreads();
+
+  const long long tj0 = clock64();
+  int sweeps = 0, cur = 0;
+  long long g = 0;  // global round counter
+  double off2 = 0.0;
+  for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
+    const double2* A = img + (size_t)cur * 2 * nblk;
+    off2 = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (!live[bi]) continue;
+      const double2 x1 = A[bx[bi]], x2 = A[nblk + bx[bi]];
+      if (P_[bi] == Q_[bi]) off2 += 2.0 * x1.y * x1.y;
+      else off2 += 2.0 * (x1.x * x1.x + x1.y * x1.y + x2.x * x2.x + x2.y * x2.y);
+    }
+    off2 = block_sum(off2, red);
+    __syncthreads();
+    if (off2 <= tol2) break;
+    for (int r = 0; r < n - 1; ++r, ++g) {
+      const double2* Ar = img + (size_t)cur * 2 * nblk;
+      double* Aw = reinterpret_cast<double*>(img + (size_t)(cur ^ 1) * 2 * nblk);
+      const double2* rt = rot + (g & 1) * 128;
+      if (tid < nupd) {
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+          if (!live[bi]) continue;
+          const double2 x1 = Ar[bx[bi]], x2 = Ar[nblk + bx[bi]];
+          double z11, z12, z21, z22;
+          jac_block(x1, x2, rt[P_[bi]], rt[Q_[bi]], P_[bi] == Q_[bi], z11, z12, z21, z22);
+          Aw[d11[bi]] = z11;
+          Aw[d22[bi]] = z22;
+          Aw[d12[bi]] = z12;                          // d12 == d21 for a diagonal block
+          if (P_[bi] != Q_[bi]) Aw[d21[bi]] = z21;
+        }
+      } else if (ahead) {
+        double z11, z12, z21, z22;
+        const double2 ra = rt[pa], rb = rt[pb];
+        jac_block(Ar[bidx(pa, pa)], Ar[nblk + bidx(pa, pa)], ra, ra, true, z11, z12, z21, z22);
+        const double naa = ia ? z22 : z11;
+        jac_block(Ar[bidx(pb, pb)], Ar[nblk + bidx(pb, pb)], rb, rb, true, z11, z12, z21, z22);
+        const double nbb = ib ? z22 : z11;
+        double nab;
+        if (pa == pb) {
+          jac_block(Ar[bab], Ar[nblk + bab], ra, ra, true, z11, z12, z21, z22);
+          nab = z12;
+        } else if (!ab_swapped) {
+          jac_block(Ar[bab], Ar[nblk + bab], ra, rb, false, z11, z12, z21, z22);
+          nab = ia ? (ib ? z22 : z21) : (ib ? z12 : z11);
+        } else {  // stored block is (pb, pa): rows belong to b's pair
+          jac_block(Ar[bab], Ar[nblk + bab], rb, ra, false, z11, z12, z21, z22);
+          nab = ib ? (ia ? z22 : z21) : (ia ? z12 : z11);
+        }
+        double c, sn;
+        jac_rotation(naa, nab, nbb, c, sn);
+        rot[((g + 1) & 1) * 128 + pi] = make_double2(c, sn);
+        if (g + 1 < max_rounds) rotlog[(size_t)(g + 1) * np + pi] = make_double2(c, sn);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // whole sweeps bring every player back to its own slot: slot order == index order here.
+  {
+    const double2* A = img + (size_t)cur * 2 * nblk;
+    for (int i = tid; i < k; i += nthr) {
+      const int P = i >> 1;
+      Ad[i] = (i & 1) ? A[nblk + bidx(P, P)].y : A[bidx(P, P)].x;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < k; i += nthr) {
+    const double ki = sort_by_abs ? fabs(Ad[i]) : Ad[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const double kj = sort_by_abs ? fabs(Ad[j]) : Ad[j];
+      if (kj > ki || (kj == ki && j < i)) ++rank;
+    }
+    perm[rank] = i;
+    dvals[rank] = Ad[i];
+  }
+  if (tid == 0) {
+    status->offdiag = fro > 0.0 ? sqrt(off2 / fro) : 0.0;
+    status->sweeps = sweeps;
+    status->failed = (sweeps >= JAC_MAX_SWEEPS && off2 > tol2) ? 1 : 0;
+    status->tick[0] = clock64() - tj0;
+    status->tick[1] = 0;
+    status->tick[2] = 0;
+    status->tick[3] = sweeps;
+    status->tick[4] = 2;
+  }
+}
+
 // Row i of V = e_i^T * (product of all logged rotations); one workgroup per row.  The row is kept in slot order
 // in two LDS buffers: lane P rotates the adjacent pair (2P, 2P+1) of the current buffer and writes it to the
 // players' next seats in the other one -- one barrier per round, no index arithmetic.
@@ -977,7 +1185,31 @@ int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dval
     if (use_lds) JAC_LAUNCH2(NBV, true); \
     else JAC_LAUNCH2(NBV, false);        \
   } while (0)
-  if (nb <= 1) JAC_LAUNCH(1);
+  static int use_db = -1;   // HFMI_JACOBI_DB: A/B measurements
+  if (use_db < 0) {
+    const char* e = getenv("HFMI_JACOBI_DB");
+    use_db = e ? atoi(e) : 1;   // 0: never, 1: where it wins (>= 3 blocks per thread), 2: whenever it fits
+  }
+  const int nblk = np * (np + 1) / 2;
+  const size_t shmem_db = (32 + 512 + 256) * sizeof(double) + (size_t)4 * nblk * sizeof(double2);
+  const int nb_db = threads > 128 ? (cells + (threads - 128) - 1) / (threads - 128) : 99;
+  // measured (scripts/jacobi_ab.py, kernel traces): k = 138 1.21 vs 1.38 ms, but k = 74 0.41 vs 0.35 and k = 84 0.46 vs
+  // 0.44 ms -- with one block per thread the look-ahead chain is longer than the three short phases it replaces
+  const int db_min_blocks = (use_db == 2) ? 1 : 3;
+  if (use_db && nb >= db_min_blocks && n <= 138 && np <= 128 && threads >= 256 && nb_db <= 4 && shmem_db <= 160 * 1024) {
+#define JAC_DB(NBV)                                                                                                  \
+  do {                                                                                                               \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_eig_db<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                (int)shmem_db));                                                                     \
+    hipLaunchKernelGGL((k_jacobi_eig_db<NBV>), dim3(1), dim3(threads), shmem_db, ctx->stream, sm_ptr(ctx, slot_t),   \
+                       SM_LD, k, rotlog, dvals, perm, sort_by_abs, ctx->status_dev);                                 \
+  } while (0)
+    if (nb_db <= 1) JAC_DB(1);
+    else if (nb_db <= 2) JAC_DB(2);
+    else if (nb_db <= 3) JAC_DB(3);
+    else JAC_DB(4);
+#undef JAC_DB
+  } else if (nb <= 1) JAC_LAUNCH(1);
   else if (nb <= 2) JAC_LAUNCH(2);
   else if (nb <= 3) JAC_LAUNCH(3);
   else if (nb <= 9) JAC_LAUNCH(9);
