@@ -792,7 +792,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
   double* red = reinterpret_cast<double*>(smem);                // 32
   double2* rot = reinterpret_cast<double2*>(red + 32);          // 2 x 128 (c, s) per pair: this round / next round
   double* Ad = reinterpret_cast<double*>(rot + 256);            // 256 diagonal copy / keys
-  double2* img = reinterpret_cast<double2*>(Ad + 256);          // [2 images][2 planes][nblk]
+  double* img = Ad + 256;                                       // [2 images][4 planes][nblk]
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int n = (k + 1) & ~1;  // players (one dummy if k is odd: a zero row/column that is never rotated)
   const int np = n / 2;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
   auto seat = [&](int r, int c) {
     const bool upper = (r >> 1) != (c >> 1) ? (r >> 1) < (c >> 1) : r <= c;
     const int rr = upper ? r : c, cc = upper ? c : r;
-    return 2 * ((rr & 1) * nblk + bidx(rr >> 1, cc >> 1)) + (cc & 1);
+    return ((rr & 1) * 2 + (cc & 1)) * nblk + bidx(rr >> 1, cc >> 1);
   };
 
   // this thread's blocks: element index in a plane, and the next-round seats of its four entries
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
   // look-ahead thread pi: the pair that will sit in seats (2 pi, 2 pi + 1) comes from the seats a, b of this round
   const int pi = tid - nupd;
   const bool ahead = pi >= 0 && pi < np;
-  int pa = 0, pb = 0, ia = 0, ib = 0, bab = 0;
+  int pa = 0, pb = 0, ia = 0, ib = 0, bab = 0, baa = 0, bbb = 0;
   bool ab_swapped = false;
   if (ahead) {
     int a = 0, b = 0;
@@ -841,6 +841,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
     pa = a >> 1; ia = a & 1; pb = b >> 1; ib = b & 1;
     ab_swapped = pb < pa;
     bab = ab_swapped ? bidx(pb, pa) : bidx(pa, pb);
+    baa = bidx(pa, pa);
+    bbb = bidx(pb, pb);
   }
 
   // load (symmetrised) into image 0, seat order == index order
@@ -856,8 +858,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
         const int r = 2 * P_[bi] + i, c = 2 * Q_[bi] + j;
         v[i][j] = (r < k && c < k) ? 0.5 * (T[r * ldt + c] + T[c * ldt + r]) : 0.0;
       }
-    img[bx[bi]] = make_double2(v[0][0], v[0][1]);
-    img[nblk + bx[bi]] = make_double2(v[1][0], v[1][1]);
+    img[bx[bi]] = v[0][0];
+    img[nblk + bx[bi]] = v[0][1];
+    img[2 * nblk + bx[bi]] = v[1][0];
+    img[3 * nblk + bx[bi]] = v[1][1];
     if (P_[bi] == Q_[bi]) fro += v[0][0] * v[0][0] + v[1][1] * v[1][1] + 2.0 * v[0][1] * v[0][1];
     else fro += 2.0 * (v[0][0] * v[0][0] + v[0][1] * v[0][1] + v[1][0] * v[1][0] + v[1][1] * v[1][1]);
   }
@@ -868,9 +872,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
 
   // rotations of the very first round, straight from the diagonal blocks
   if (tid < np) {
-    const double2 top = img[bidx(tid, tid)], bot = img[nblk + bidx(tid, tid)];
+    const int bd = bidx(tid, tid);
     double c, sn;
-    jac_rotation(top.x, top.y, bot.y, c, sn);
+    jac_rotation(img[bd], img[nblk + bd], img[3 * nblk + bd], c, sn);
     rot[tid] = make_double2(c, sn);
     rotlog[tid] = make_double2(c, sn);
   }
@@ -881,12 +885,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
   long long g = 0;  // global round counter
   double off2 = 0.0;
   for (; sweeps < JAC_MAX_SWEEPS; ++sweeps) {
-    const double2* A = img + (size_t)cur * 2 * nblk;
+    const double* A = img + (size_t)cur * 4 * nblk;
     off2 = 0.0;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) {
       if (!live[bi]) continue;
-      const double2 x1 = A[bx[bi]], x2 = A[nblk + bx[bi]];
+      const double2 x1 = make_double2(A[bx[bi]], A[nblk + bx[bi]]), x2 = make_double2(A[2 * nblk + bx[bi]], A[3 * nblk + bx[bi]]);
       if (P_[bi] == Q_[bi]) off2 += 2.0 * x1.y * x1.y;
       else off2 += 2.0 * (x1.x * x1.x + x1.y * x1.y + x2.x * x2.x + x2.y * x2.y);
     }
@@ -894,14 +898,19 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
     __syncthreads();
     if (off2 <= tol2) break;
     for (int r = 0; r < n - 1; ++r, ++g) {
-      const double2* Ar = img + (size_t)cur * 2 * nblk;
-      double* Aw = reinterpret_cast<double*>(img + (size_t)(cur ^ 1) * 2 * nblk);
+      const double* Ar = img + (size_t)cur * 4 * nblk;
+      double* Aw = img + (size_t)(cur ^ 1) * 4 * nblk;
+      auto blk = [&](int b, double2& x1, double2& x2) {
+        x1 = make_double2(Ar[b], Ar[nblk + b]);
+        x2 = make_double2(Ar[2 * nblk + b], Ar[3 * nblk + b]);
+      };
       const double2* rt = rot + (g & 1) * 128;
       if (tid < nupd) {
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
           if (!live[bi]) continue;
-          const double2 x1 = Ar[bx[bi]], x2 = Ar[nblk + bx[bi]];
+          double2 x1, x2;
+          blk(bx[bi], x1, x2);
           double z11, z12, z21, z22;
           jac_block(x1, x2, rt[P_[bi]], rt[Q_[bi]], P_[bi] == Q_[bi], z11, z12, z21, z22);
           Aw[d11[bi]] = z11;
@@ -911,20 +920,24 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
         }
       } else if (ahead) {
         double z11, z12, z21, z22;
+        double2 x1, x2;
         const double2 ra = rt[pa], rb = rt[pb];
-        jac_block(Ar[bidx(pa, pa)], Ar[nblk + bidx(pa, pa)], ra, ra, true, z11, z12, z21, z22);
+        blk(baa, x1, x2);
+        jac_block(x1, x2, ra, ra, true, z11, z12, z21, z22);
         const double naa = ia ? z22 : z11;
-        jac_block(Ar[bidx(pb, pb)], Ar[nblk + bidx(pb, pb)], rb, rb, true, z11, z12, z21, z22);
+        blk(bbb, x1, x2);
+        jac_block(x1, x2, rb, rb, true, z11, z12, z21, z22);
         const double nbb = ib ? z22 : z11;
         double nab;
+        blk(bab, x1, x2);
         if (pa == pb) {
-          jac_block(Ar[bab], Ar[nblk + bab], ra, ra, true, z11, z12, z21, z22);
+          jac_block(x1, x2, ra, ra, true, z11, z12, z21, z22);
           nab = z12;
         } else if (!ab_swapped) {
-          jac_block(Ar[bab], Ar[nblk + bab], ra, rb, false, z11, z12, z21, z22);
+          jac_block(x1, x2, ra, rb, false, z11, z12, z21, z22);
           nab = ia ? (ib ? z22 : z21) : (ib ? z12 : z11);
         } else {  // stored block is (pb, pa): rows belong to b's pair
-          jac_block(Ar[bab], Ar[nblk + bab], rb, ra, false, z11, z12, z21, z22);
+          jac_block(x1, x2, rb, ra, false, z11, z12, z21, z22);
           nab = ib ? (ia ? z22 : z21) : (ia ? z12 : z11);
         }
         double c, sn;
@@ -938,10 +951,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_jacobi_eig_db(const double* _
   }
   // whole sweeps bring every player back to its own slot: slot order == index order here.
   {
-    const double2* A = img + (size_t)cur * 2 * nblk;
+    const double* A = img + (size_t)cur * 4 * nblk;
     for (int i = tid; i < k; i += nthr) {
       const int P = i >> 1;
-      Ad[i] = (i & 1) ? A[nblk + bidx(P, P)].y : A[bidx(P, P)].x;
+      Ad[i] = (i & 1) ? A[3 * nblk + bidx(P, P)] : A[bidx(P, P)];
     }
   }
   __syncthreads();
@@ -1191,12 +1204,12 @@ int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dval
     use_db = e ? atoi(e) : 1;   // 0: never, 1: where it wins (>= 3 blocks per thread), 2: whenever it fits
   }
   const int nblk = np * (np + 1) / 2;
-  const size_t shmem_db = (32 + 512 + 256) * sizeof(double) + (size_t)4 * nblk * sizeof(double2);
+  const size_t shmem_db = (32 + 512 + 256) * sizeof(double) + (size_t)8 * nblk * sizeof(double);
   const int nb_db = threads > 128 ? (cells + (threads - 128) - 1) / (threads - 128) : 99;
   // measured (scripts/jacobi_ab.py, kernel traces): k = 138 1.21 vs 1.38 ms, but k = 74 0.41 vs 0.35 and k = 84 0.46 vs
   // 0.44 ms -- with one block per thread the look-ahead chain is longer than the three short phases it replaces
   const int db_min_blocks = (use_db == 2) ? 1 : 3;
-  if (use_db && nb >= db_min_blocks && n <= 138 && np <= 128 && threads >= 256 && nb_db <= 4 && shmem_db <= 160 * 1024) {
+  if (use_db && nb >= db_min_blocks && n <= 138 && np <= 128 && threads >= 256 && nb_db <= 3 && shmem_db <= 160 * 1024) {
 #define JAC_DB(NBV)                                                                                                  \
   do {                                                                                                               \
     HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_eig_db<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
@@ -1206,8 +1219,7 @@ int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dval
   } while (0)
     if (nb_db <= 1) JAC_DB(1);
     else if (nb_db <= 2) JAC_DB(2);
-    else if (nb_db <= 3) JAC_DB(3);
-    else JAC_DB(4);
+    else JAC_DB(3);
 #undef JAC_DB
   } else if (nb <= 1) JAC_LAUNCH(1);
   else if (nb <= 2) JAC_LAUNCH(2);

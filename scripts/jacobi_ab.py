@@ -1,6 +1,6 @@
 """Accuracy and time of the small symmetric eigensolver (run twice: HFMI_JACOBI_DB=0 / 1)."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hippyflow_amd as hf
 ctx = hf.Context.default()
 rng = np.random.default_rng(0)
