@@ -93,7 +93,10 @@ TN_SHAPES = [(1, 1, 1), (3, 2, 7), (9, 13, 100), (16, 16, 32), (17, 33, 1000), (
              (256, 30, 4225), (64, 74, 20011), (300, 260, 1000), (500, 84, 3000), (2048, 138, 20000), (700, 5, 50000),
              # both operands skinny (tsgemm_ss): every tiles-per-wave class, ragged tiles, more slices than stages
              (8, 138, 70001), (138, 8, 70001), (160, 128, 5000), (144, 144, 33), (150, 130, 9999), (97, 160, 64),
-             (33, 17, 300000), (160, 1, 2049), (112, 110, 12345)]
+             (33, 17, 300000), (160, 1, 2049), (112, 110, 12345),
+             # column remainders of the last tile handled as 1 / 2 / 3 groups on the 4x4x4 MFMA (and 13: a full tile again)
+             (500, 74, 3000), (400, 36, 5000), (300, 100, 4000), (1000, 9, 4000), (1000, 12, 3000), (333, 45, 2000),
+             (3000, 4, 2000), (700, 170, 3000)]
 
 
 @pytest.mark.parametrize("m,k,N", TN_SHAPES)
@@ -131,7 +134,10 @@ def test_block_dot_is_deterministic(ctx):
 
 
 NN_SHAPES = [(1, 1, 1), (7, 3, 2), (100, 9, 13), (4225, 30, 20), (4225, 256, 30), (20011, 74, 64), (1000, 300, 260),
-             (50000, 138, 128), (3000, 2048, 138), (999, 5, 1)]
+             (50000, 138, 128), (3000, 2048, 138), (999, 5, 1),
+             # column remainders on the 4x4x4 MFMA: r = 74 (3 groups), 84 (1), 36 (1), 100 (1), 9 (3), 12 (3), 45 (full tile)
+             (20011, 200, 74), (5000, 300, 84), (7000, 100, 36), (3000, 64, 100), (4000, 50, 9), (4000, 50, 12), (2000, 40, 45),
+             (30000, 700, 138), (2500, 64, 170)]
 
 
 @pytest.mark.parametrize("N,m,r", NN_SHAPES)
