@@ -390,9 +390,10 @@ static int read_status(hfmi_ctx* ctx, hfmi_status_words* out) {
 static void print_status_dbg(const hfmi_status_words* out) {
   static const bool dbg = getenv("HFMI_DEBUG_TIMING") != nullptr;
   if (dbg)
-    fprintf(stderr, "[hfmi timing] %s cycles: %lld %lld %lld %lld\n", out->tick[4] ? "jacobi(total,phase1,phase2,sweeps)" : "chol(load,chol,inv,out)",
+    fprintf(stderr, "[hfmi timing] %s cycles: %lld %lld %lld %lld\n",
+            out->tick[4] == 3 ? "chol-polish(load,-,-,out)" : out->tick[4] ? "jacobi(total,phase1,phase2,sweeps)" : "chol(load,chol,inv,out)",
             out->tick[0], out->tick[1], out->tick[2], out->tick[3]);
-  if (dbg && !out->tick[4])
+  if (dbg && (!out->tick[4] || out->tick[4] == 3))
     fprintf(stderr, "[hfmi timing]   chol status: min pivot ratio %.3e, input defect %.3e, shifted %d\n", out->min_pivot_ratio,
             out->gram_dev, out->shifted);
 }

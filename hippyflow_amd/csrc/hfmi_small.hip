@@ -319,6 +319,42 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_reg(const double* 
   tr = block_sum(tr, red);
   tk1 = clock64();
 
+  // Near-orthonormal input (the polishing pass of Cholesky-QR2: G = D^1/2 (I + E) D^1/2 with |E| ~ eps cond^2): the
+  // sequential factorisation is replaced by the first-order inverse square root X = D^-1/2 (I - E/2), for which
+  // X^T G X = I - 3/4 E^2 + O(E^3) -- below 1e-14 for |E|_F < 1e-7.  X is not triangular, so this is only taken when
+  // the caller does not ask for the triangular factor (the fused solves: only the span and the B-orthonormality of Q
+  // matter there).  k = 138: 0.27 ms -> 0.02 ms for the second pass of every solve.
+  if (!full_r && dev < 1e-14) {
+    bool pos = true;
+    for (int i = tid; i < k; i += NT) pos = pos && diag0[i] > 0.0;
+    if (__syncthreads_and(pos ? 1 : 0)) {
+      for (int i = wave; i < k; i += nw) {
+        const double di = invd[i];
+        for (int j = lane; j < k; j += 64) {
+          const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+          const double dj = invd[j];
+          const double e = g * di * dj - (i == j ? 1.0 : 0.0);
+          const double id = (i == j) ? 1.0 : 0.0;
+          Rinv[i * ldo + j] = di * (id - 0.5 * e);
+          Rout[i * ldo + j] = (id + 0.5 * e) * diag0[j] * dj;          // (I + E/2) D^1/2, d^1/2 = d * d^-1/2
+          if (i == j) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * (1.0 + 0.5 * e) * diag0[i] * di;
+        }
+      }
+      if (tid == 0) {
+        status->min_pivot_ratio = 1.0;
+        status->gram_dev = sqrt(dev);
+        status->shifted = 0;
+        status->failed = 0;
+        status->tick[0] = tk1 - tk0;
+        status->tick[1] = 0;
+        status->tick[2] = 0;
+        status->tick[3] = clock64() - tk1;
+        status->tick[4] = 3;
+      }
+      return;
+    }
+  }
+
   // owned entries: slot q holds cell e = tid + q * NT; rows counted from the bottom, m (m+1)/2 <= e < (m+1)(m+2)/2
   const int total = k * (k + 1) / 2;
   int oi[EPT], oc[EPT];   // row (clamped into the matrix for idle slots: they compute garbage nobody reads), column
