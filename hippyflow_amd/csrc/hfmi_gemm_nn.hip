@@ -8,11 +8,13 @@ static int g_nn_waves = 0;    // 0 = auto (4 for <= 6 column tiles, else 8)
 static int g_nn_hybrid = 1;   // split only the row tiles beyond the last full round of CUs
 static int g_nn_tt = 0;       // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_rem4 = 1;        // last column tile of <= 12 columns in 4-column groups (4x4x4 MFMA)
+static int g_nn_res = 1;      // small matrix resident in LDS + persistent workgroups when it fits
 int nn_tuning_set(const char* key, int value) {
   if (!strcmp(key, "rem4") && (value == 0 || value == 1)) g_rem4 = value;
   else if (!strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
   else if (!strcmp(key, "nn_tt") && value >= 0 && value <= 3) g_nn_tt = value;
   else if (!strcmp(key, "nn_hybrid") && (value == 0 || value == 1)) g_nn_hybrid = value;
+  else if (!strcmp(key, "nn_res") && (value == 0 || value == 1)) g_nn_res = value;
   else return 0;
   return 1;
 }
@@ -259,6 +261,196 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   }
 }
 
+// k_tsgemm_nn_res: the same product when the small matrix S (m x r) fits LDS whole (m <= ~160: Q R^-1 of the QR
+// passes, U = Q V, MvDSmatMult).  The streamed kernel above re-stages S for every row tile and pays its prologue (first
+// stage, first fragments) and epilogue (the stores) once per tile with nothing to overlap them -- with m = 138 a tile is
+// only five stages long, and config 3's Q R^-1 ran at 0.45 ms where the flops need 0.32.  Here S is staged ONCE per
+// workgroup, the workgroups are persistent (grid = number of CUs, row tiles dealt cyclically), there is no barrier
+// after the staging, and the streamed operand is prefetched three k-steps ahead ACROSS tile boundaries, so the next
+// tile's first fragments are in flight while the current tile's results are being stored.
+template <int TT, int NT, int R4>
+__global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restrict__ A, int64_t lda, int m,
+                                                          const double* __restrict__ S, int lds_, int r,
+                                                          double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* L = reinterpret_cast<double*>(smem);  // [round_up(m, 4)][SLD]
+  constexpr int WAVES = 8;
+  constexpr int COLS = NT * 16;
+  constexpr int SLD = COLS + ((NT % 2 == 0) ? 16 : 0);  // SLD % 32 == 16: conflict-free ds_read_b64
+  constexpr int TP = TT / 2;
+  constexpr bool ODD = (TT & 1) != 0;
+  constexpr int TPA = TP > 0 ? TP : 1;
+  constexpr int NTF = R4 > 0 ? NT - 1 : NT;
+  constexpr int NTA = NTF > 0 ? NTF : 1;
+  constexpr int NR4 = R4 > 0 ? R4 : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, kk = lane >> 4;
+  const int mpad = (m + 3) & ~3;
+  const int nk = mpad >> 2;  // MFMA k-steps per tile
+  // stage S once: rows >= m are zero (the streamed operand is clamped to vector m - 1 there)
+  for (int c = tid; c < mpad * (COLS / 2); c += WAVES * 64) {
+    const int row = c / (COLS / 2), cp = c - row * (COLS / 2);
+    d2 v = d2{0.0, 0.0};
+    if (row < m) v = *reinterpret_cast<const d2*>(S + (int64_t)row * lds_ + cp * 2);
+    *reinterpret_cast<d2*>(L + row * SLD + cp * 2) = v;
+  }
+  __syncthreads();
+
+  const int64_t tmax = round_up_dev(N, 32) - 2;
+  const int G = gridDim.x;
+  int ntl = 0;  // tiles of this workgroup: blockIdx.x, blockIdx.x + G, ...
+  if ((int)blockIdx.x < ntiles) ntl = (ntiles - 1 - (int)blockIdx.x) / G + 1;
+  const int64_t total = (int64_t)ntl * nk;
+
+  struct AFrag {
+    d2 p[TPA];
+    double s;
+  };
+  struct SFrag {
+    double f[NTA];
+    double g[NR4];
+  };
+  // prefetch cursor (three k-steps ahead of the MFMAs): tile, k-step, row offsets of that tile
+  int ptile = blockIdx.x, pks = 0;
+  int64_t ptoff[TPA], ptoff1;
+  auto set_ptoff = [&]() {
+    const int tl = ptile < ntiles ? ptile : ntiles - 1;   // past the end: re-read the last tile (results unused)
+    const int64_t t0 = (int64_t)tl * (16 * TT * WAVES) + wave * (16 * TT);
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+      const int64_t t = t0 + tp * 32 + 2 * c16;
+      ptoff[tp] = t > tmax ? tmax : t;
+    }
+    ptoff1 = t0 + TP * 32 + c16;
+    if (ptoff1 > tmax + 1) ptoff1 = tmax + 1;
+  };
+  set_ptoff();
+  auto load_next = [&](AFrag& dst) {
+    int col = pks * 4 + kk;
+    if (col > m - 1) col = m - 1;
+    const double* p = A + (int64_t)col * lda;
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) dst.p[tp] = *reinterpret_cast<const d2*>(p + ptoff[tp]);
+    if (ODD) dst.s = p[ptoff1];
+    if (++pks == nk) {
+      pks = 0;
+      ptile += G;
+      set_ptoff();
+    }
+  };
+  auto ldss = [&](SFrag& sf, int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NTF; ++nt) sf.f[nt] = L[(ks * 4 + kk) * SLD + nt * 16 + c16];
+    if constexpr (R4 > 0) {
+#pragma unroll
+      for (int q = 0; q < R4; ++q) sf.g[q] = L[(ks * 4 + kk) * SLD + NTF * 16 + 4 * q + (lane & 3)];
+    }
+  };
+
+  d4 acc[TT][NTA];
+  double acc4[TT][NR4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+      for (int nt = 0; nt < NTA; ++nt) acc[tt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < NR4; ++q) acc4[tt][q] = 0.0;
+    }
+  };
+  // one k-step; the small-matrix fragments are single-buffered: as soon as the MFMAs of column tile nt have issued,
+  // its register is refilled with the fragment of k-step ksn and the other tiles' MFMAs cover the LDS latency
+  SFrag sf;
+  auto mma = [&](const AFrag& a, int ksn) {
+    const double* Ln = L + (ksn * 4 + kk) * SLD;
+#pragma unroll
+    for (int nt = 0; nt < NTF; ++nt) {
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        acc[2 * tp][nt] = MFMA_F64(sf.f[nt], a.p[tp].x, acc[2 * tp][nt]);
+        acc[2 * tp + 1][nt] = MFMA_F64(sf.f[nt], a.p[tp].y, acc[2 * tp + 1][nt]);
+      }
+      if (ODD) acc[TT - 1][nt] = MFMA_F64(sf.f[nt], a.s, acc[TT - 1][nt]);
+      sf.f[nt] = Ln[nt * 16 + c16];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (R4 > 0) {
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          acc4[2 * tp][q] = MFMA_F64_4(sf.g[q], a.p[tp].x, acc4[2 * tp][q]);
+          acc4[2 * tp + 1][q] = MFMA_F64_4(sf.g[q], a.p[tp].y, acc4[2 * tp + 1][q]);
+        }
+        if (ODD) acc4[TT - 1][q] = MFMA_F64_4(sf.g[q], a.s, acc4[TT - 1][q]);
+        sf.g[q] = Ln[NTF * 16 + 4 * q + (lane & 3)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_tile = [&](int tile) {
+    const int64_t t0 = (int64_t)tile * (16 * TT * WAVES) + wave * (16 * TT);
+    auto put = [&](int j, int tt0, double v0, double v1, bool pair, int64_t t) {
+      double* yc = Y + (int64_t)j * ldy;
+      if (pair) {
+        if (t + 1 < N) *reinterpret_cast<d2*>(yc + t) = d2{v0, v1};
+        else if (t < N) yc[t] = v0;
+      } else if (t < N) {
+        yc[t] = v0;
+      }
+      (void)tt0;
+    };
+#pragma unroll
+    for (int nt = 0; nt < NTF; ++nt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int j = nt * 16 + kk + 4 * rg;
+        if (j < r) {
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp) put(j, tp, acc[2 * tp][nt][rg], acc[2 * tp + 1][nt][rg], true, t0 + tp * 32 + 2 * c16);
+          if (ODD) put(j, TT - 1, acc[TT - 1][nt][rg], 0.0, false, t0 + TP * 32 + c16);
+        }
+      }
+    if constexpr (R4 > 0) {
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        const int j = NTF * 16 + 4 * q + kk;
+        if (j < r) {
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp) put(j, tp, acc4[2 * tp][q], acc4[2 * tp + 1][q], true, t0 + tp * 32 + 2 * c16);
+          if (ODD) put(j, TT - 1, acc4[TT - 1][q], 0.0, false, t0 + TP * 32 + c16);
+        }
+      }
+    }
+  };
+
+  // prefetch ring of the streamed operand: three k-steps ahead, one for the widest panels (registers)
+  constexpr int RD = (TT * NT >= 18) ? 2 : 4;
+  AFrag ring[RD];
+  zero_acc();
+  if (total > 0) {
+#pragma unroll
+    for (int u = 0; u < RD - 1; ++u) load_next(ring[u]);
+    ldss(sf, 0);
+  }
+  int ctile = blockIdx.x, cks = 0;
+  for (int64_t q0 = 0; q0 < total; q0 += RD) {
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      if (q0 + u < total) {   // wave-uniform
+        load_next(ring[(u + RD - 1) % RD]);
+        mma(ring[u], (cks + 1 == nk) ? 0 : cks + 1);
+        if (++cks == nk) {
+          store_tile(ctile);
+          zero_acc();
+          cks = 0;
+          ctile += G;
+        }
+      }
+    }
+  }
+}
+
 // Y[j][t] = sum_s part[s][j][t]  (fixed order), rows row0 <= t < N (row0 even)
 __global__ void k_reduce_nn(const double* __restrict__ part, int msplit, int64_t pstride, int64_t ldp, double* __restrict__ Y,
                             int64_t ldy, int64_t row0, int64_t N, int r) {
@@ -408,9 +600,42 @@ static int nn_launch_w8(hfmi_ctx* ctx, const double* A, int64_t lda, int m, cons
   return nn_launch_inst<TT, NT, 8>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, ms);
 }
 
+template <int TT, int NT>
+static int nn_launch_res(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
+                         int64_t ldy, int64_t N, size_t shmem) {
+  const int rem = r - (NT - 1) * 16;
+  const int r4 = (g_rem4 && rem <= 12) ? (rem + 3) / 4 : 0;
+  auto kern = r4 == 1 ? k_tsgemm_nn_res<TT, NT, 1> : r4 == 2 ? k_tsgemm_nn_res<TT, NT, 2>
+            : r4 == 3 ? k_tsgemm_nn_res<TT, NT, 3> : k_tsgemm_nn_res<TT, NT, 0>;
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  const int tile_rows = 16 * TT * 8;
+  const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int grid = ntiles < cus ? ntiles : cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, ntiles);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
 static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int lds_, int r, double* Y,
                     int64_t ldy, int64_t N) {
   const int nt = (r + 15) / 16;
+  // S whole in LDS (one workgroup per CU): [round_up(m, 4)][SLD] doubles.  In-place products (Y == A: Q <- Q R^-1) are
+  // fine: a workgroup reads the rows of a tile completely before it stores them, and tiles do not overlap.
+  if (g_nn_res && nt <= 10 && N >= 4096) {
+    const int sld = nt * 16 + ((nt % 2 == 0) ? 16 : 0);
+    const size_t shmem = (size_t)((m + 3) & ~3) * sld * sizeof(double);
+    if (shmem <= 160 * 1024) {
+#define NN_RES(NTV, TTV) \
+  case NTV:              \
+    return nn_launch_res<TTV, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, shmem);
+      switch (nt) {
+        NN_RES(1, 4) NN_RES(2, 4) NN_RES(3, 4) NN_RES(4, 4) NN_RES(5, 3) NN_RES(6, 2) NN_RES(7, 2) NN_RES(8, 2) NN_RES(9, 2)
+        NN_RES(10, 1)
+      }
+#undef NN_RES
+    }
+  }
   const int waves = g_nn_waves ? g_nn_waves : (nt >= 7 ? 8 : 4);   // A/B (scripts/nn_waves_ab.py, r01g): one wave per SIMD wins up to 6 column tiles
 #define NN_CASE(NTV, TT4, TT8)                                                             \
   case NTV:                                                                                \

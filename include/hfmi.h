@@ -202,7 +202,8 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * per CU); ("rem4", 1|0) last column tile of <= 12 columns as 4-column groups on the 4x4x4 MFMA | as a full 16-column tile;
  * ("probe", 0..3) timing-only diagnostic of tsgemm_tn (bit 0: the streamed operand re-reads one address, bit 1: no staging /
  * barriers; results are garbage -- scripts/tn_probe.py); ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
- * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("ss", 0|1) route skinny x skinny contractions to
+ * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("nn_res", 1|0) small matrix resident in LDS with persistent
+ * workgroups when it fits (short reductions: Q R^-1, U = Q V); ("ss", 0|1) route skinny x skinny contractions to
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized. */
 int hfmi_tuning_set(const char* key, int value);
 int hfmi_profile_begin(hfmi_ctx* ctx);

@@ -1,0 +1,25 @@
+"""In-process A/B of tsgemm_nn with a short reduction (m <= 160): streamed small matrix (nn_res=0) against the
+LDS-resident small matrix with persistent workgroups (nn_res=1).  Includes the in-place product Q <- Q S."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hippyflow_amd as hf
+from hippyflow_amd import _lib as L
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for name, m, r, N in [("pod Q R^-1", 138, 138, 500000), ("pod U=QV", 138, 128, 500000), ("as Q R^-1", 74, 74, 200000),
+                      ("as U=QV", 74, 64, 200000), ("kle", 84, 84, 100000), ("small", 30, 20, 4225 * 4), ("k=160", 150, 160, 100000)]:
+    A = hf.MultiVector(N, m); Y = hf.MultiVector(N, r)
+    hf.parRandom.normal(1.0, A)
+    S = np.random.default_rng(0).standard_normal((m, r))
+    res = {0: [], 1: []}
+    for it in range(rounds):
+        for v in (0, 1):
+            L.call("hfmi_tuning_set", b"nn_res", v)
+            ms = C.c_double(0)
+            L.call("hfmi_bench_tsgemm_nn", A.handle, L.ptr(S), Y.handle, 5, C.byref(ms))
+            res[v].append(ms.value)
+    L.call("hfmi_tuning_set", b"nn_res", 1)
+    fl = 2.0 * N * m * r
+    by = 8.0 * N * (m + r)
+    print("%-12s %s " % (name, (m, r, N)) + "  ".join("res=%d: %.4f ms %.1f TF %.2f TB/s" % (v, np.median(t), fl / np.median(t) / 1e9, by / np.median(t) / 1e9) for v, t in res.items()))
+    del A, Y
