@@ -536,6 +536,277 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_reg(const double* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_chol_tile: k_chol_reg with a two-dimensional ownership map.  With the entries dealt cyclically every entry of a
+// thread needs its own two LDS words per step (the pivot row at its row and at its column): 2 EPT reads per step,
+// 164 KB per step at k = 138 -- the factorisation was LDS-bandwidth bound (1.3 k of its 2 k cycles per step).  Here a
+// thread owns a TR x TC rectangle of the upper triangle and reads TR + TC words for TR TC entries (10 instead of 50
+// at k = 138); everything else is the same algorithm: unscaled right-looking factorisation with the pivot row
+// published through alternating LDS row buffers, one barrier per column, dead entries instead of masks, and the
+// inverse accumulated the same way bottom-up.
+// ------------------------------------------------------------------------------------------------
+template <int TR, int TC>
+__global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double* __restrict__ G, int ldg, int k,
+                                                                double* __restrict__ Rout, double* __restrict__ Rinv,
+                                                                double* __restrict__ Rtot, double* __restrict__ Rtmp,
+                                                                int ldo, int rtot_mode, int full_r, double shift_rel,
+                                                                double pivot_tol, double* __restrict__ colnorm0,
+                                                                double* __restrict__ rdiag,
+                                                                hfmi_status_words* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
+  double* diag0 = red + 32;                            // k original diagonal entries
+  double* invd = diag0 + 256;                          // 1 / R_jj
+  double* rb0 = invd + 256;                            // published row, two alternating buffers
+  double* rb1 = rb0 + 256;
+  double* M = rb1 + 256;                               // U, then R (upper triangle), row-major
+  const int ldm = k | 1;
+  constexpr int NT = CHOL_REG_THREADS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+  __shared__ int s_break;
+
+  long long tk0 = clock64(), tk1, tk2, tk3, tk4;
+  for (int i = tid; i < k; i += NT) {
+    diag0[i] = G[i * ldg + i];
+    if (rtot_mode == 1) colnorm0[i] = sqrt(fmax(diag0[i], 0.0));  // norms of the ORIGINAL columns (first pass)
+  }
+  for (int i = tid; i < 512; i += NT) rb0[i] = 0.0;               // both row buffers
+  __syncthreads();
+  for (int i = tid; i < k; i += NT) invd[i] = diag0[i] > 0.0 ? fast_rsqrt(diag0[i]) : 0.0;
+  __syncthreads();
+  double dev = 0.0, tr = 0.0;
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) {
+      const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+      const double x = g * invd[i] * invd[j] - (i == j ? 1.0 : 0.0);
+      dev += x * x;
+      if (i == j) tr += g;
+    }
+  dev = block_sum(dev, red);
+  tr = block_sum(tr, red);
+  tk1 = clock64();
+
+  // near-orthonormal input and no triangular factor wanted: first-order inverse square root (see k_chol_reg)
+  if (!full_r && dev < 1e-14) {
+    bool pos = true;
+    for (int i = tid; i < k; i += NT) pos = pos && diag0[i] > 0.0;
+    if (__syncthreads_and(pos ? 1 : 0)) {
+      for (int i = wave; i < k; i += nw) {
+        const double di = invd[i];
+        for (int j = lane; j < k; j += 64) {
+          const double g = 0.5 * (G[i * ldg + j] + G[j * ldg + i]);
+          const double dj = invd[j];
+          const double e = g * di * dj - (i == j ? 1.0 : 0.0);
+          const double id = (i == j) ? 1.0 : 0.0;
+          Rinv[i * ldo + j] = di * (id - 0.5 * e);
+          Rout[i * ldo + j] = (id + 0.5 * e) * diag0[j] * dj;
+          if (i == j) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * (1.0 + 0.5 * e) * diag0[i] * di;
+        }
+      }
+      if (tid == 0) {
+        status->min_pivot_ratio = 1.0;
+        status->gram_dev = sqrt(dev);
+        status->shifted = 0;
+        status->failed = 0;
+        status->tick[0] = tk1 - tk0;
+        status->tick[1] = 0;
+        status->tick[2] = 0;
+        status->tick[3] = clock64() - tk1;
+        status->tick[4] = 3;
+      }
+      return;
+    }
+  }
+
+  // this thread's tile: the tid-th rectangle (tile row I ascending, then tile column J) that touches the upper triangle
+  const int ntr = (k + TR - 1) / TR, ntc = (k + TC - 1) / TC;
+  bool own = false;
+  int r0 = 0, c0 = 0;
+  {
+    int left = tid;
+    for (int I = 0; I < ntr; ++I) {
+      int jmin = (I * TR - TC + 1 + TC - 1) / TC;          // smallest J with J TC + TC - 1 >= I TR
+      if (I * TR - TC + 1 <= 0) jmin = 0;
+      const int cnt = ntc - jmin;
+      if (cnt <= 0) continue;
+      if (left < cnt) {
+        own = true;
+        r0 = I * TR;
+        c0 = (jmin + left) * TC;
+        break;
+      }
+      left -= cnt;
+    }
+  }
+  double v[TR][TC];
+
+  int shifted = 0, failed = 0;
+  double shift = 0.0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    shift = attempt ? shift_rel * tr : 0.0;
+    if (tid == 0) s_break = 0;
+#pragma unroll
+    for (int a = 0; a < TR; ++a)
+#pragma unroll
+      for (int b = 0; b < TC; ++b) {
+        const int r = r0 + a, c = c0 + b;
+        double g = 0.0;
+        if (own && r < k && c < k && c >= r) g = 0.5 * (G[r * ldg + c] + G[c * ldg + r]) + (r == c ? shift : 0.0);
+        v[a][b] = g;
+      }
+    for (int j = 0; j < k; ++j) {
+      double* rb = (j & 1) ? rb1 : rb0;
+      if (own && j >= r0 && j < r0 + TR) {                 // row j is final: publish it
+#pragma unroll
+        for (int a = 0; a < TR; ++a)
+          if (r0 + a == j) {
+#pragma unroll
+            for (int b = 0; b < TC; ++b) {
+              const int c = c0 + b;
+              if (c >= j && c < k) {
+                rb[c] = v[a][b];
+                M[j * ldm + c] = v[a][b];
+              }
+            }
+          }
+      }
+      __syncthreads();
+      const double piv = rb[j];
+      const double ref = diag0[j] + shift;
+      if (!(piv > pivot_tol * ref) || !(ref > 0.0)) {     // uniform decision: every thread reads the same words
+        if (tid == 0) s_break = 1;
+        break;
+      }
+      const double inv = fast_rsqrt(piv);
+      const double nrp = -(inv * inv);
+      if (tid == 0) invd[j] = inv;
+      if (own && r0 + TR - 1 > j) {                        // the tile still holds rows below row j
+        double xa[TR], xb[TC];
+#pragma unroll
+        for (int a = 0; a < TR; ++a) xa[a] = rb[r0 + a];
+#pragma unroll
+        for (int b = 0; b < TC; ++b) xb[b] = rb[c0 + b];
+#pragma unroll
+        for (int a = 0; a < TR; ++a) {
+          const double f = xa[a] * nrp;
+#pragma unroll
+          for (int b = 0; b < TC; ++b) v[a][b] = fma(f, xb[b], v[a][b]);
+        }
+      }
+    }
+    __syncthreads();
+    if (!s_break) break;
+    if (attempt == 0) shifted = 1;
+    else failed = 1;
+    __syncthreads();
+  }
+  if (failed) {
+    if (tid == 0) {
+      status->min_pivot_ratio = 0.0;
+      status->gram_dev = sqrt(dev);
+      status->shifted = shifted;
+      status->failed = 1;
+    }
+    return;
+  }
+  double ratio = 1e300;
+  for (int j = tid; j < k; j += NT) ratio = fmin(ratio, 1.0 / (invd[j] * invd[j] * (diag0[j] + shift)));
+  const double min_ratio = block_min(ratio, red);
+  // R = diag(U)^{-1/2} U
+  for (int i = wave; i < k; i += nw) {
+    const double sc = invd[i];
+    for (int j = i + lane; j < k; j += 64) M[i * ldm + j] *= sc;
+  }
+  for (int i = tid; i < 512; i += NT) rb0[i] = 0.0;  // the inverse relies on zeros left of the published row
+  __syncthreads();
+  tk2 = clock64();
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+  // Inverse X = R^-1, right-looking and bottom-up (see k_chol_reg)
+#pragma unroll
+  for (int a = 0; a < TR; ++a)
+#pragma unroll
+    for (int b = 0; b < TC; ++b) v[a][b] = 0.0;
+  for (int l = k - 1; l >= 0; --l) {
+    double* xr = (l & 1) ? rb1 : rb0;
+    const double il = invd[l];
+    if (own && l >= r0 && l < r0 + TR) {
+#pragma unroll
+      for (int a = 0; a < TR; ++a)
+        if (r0 + a == l) {
+#pragma unroll
+          for (int b = 0; b < TC; ++b) {
+            const int c = c0 + b;
+            if (c >= l && c < k) {
+              const double x = (c == l) ? il : -il * v[a][b];
+              xr[c] = x;
+              Rinv[l * ldo + c] = x;
+            }
+          }
+        }
+    }
+    __syncthreads();
+    if (own && r0 < l) {                                   // the tile still holds rows above row l
+      double xa[TR], xb[TC];
+#pragma unroll
+      for (int a = 0; a < TR; ++a) {
+        const int r = r0 + a < k ? r0 + a : k - 1;
+        xa[a] = M[r * ldm + l];
+      }
+#pragma unroll
+      for (int b = 0; b < TC; ++b) xb[b] = xr[c0 + b];
+#pragma unroll
+      for (int a = 0; a < TR; ++a)
+#pragma unroll
+        for (int b = 0; b < TC; ++b) v[a][b] = fma(xa[a], xb[b], v[a][b]);
+    }
+  }
+  __syncthreads();
+  tk3 = clock64();
+  for (int i = wave; i < k; i += nw)
+    for (int j = lane; j < i; j += 64) Rinv[i * ldo + j] = 0.0;
+  for (int i = tid; i < k; i += NT) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * M[i * ldm + i];
+  if (full_r) {
+    if (rtot_mode == 1) {
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+    } else {
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) {
+          double acc = 0.0;
+          if (j >= i)
+            for (int l = i; l <= j; ++l) acc += M[i * ldm + l] * Rtot[l * ldo + j];
+          Rtmp[i * ldo + j] = acc;
+        }
+      __syncthreads();
+      for (int i = wave; i < k; i += nw)
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = Rtmp[i * ldo + j];
+    }
+  }
+  tk4 = clock64();
+  if (tid == 0) {
+    status->min_pivot_ratio = min_ratio;
+    status->gram_dev = sqrt(dev);
+    status->shifted = shifted;
+    status->failed = 0;
+    status->tick[0] = tk1 - tk0;
+    status->tick[1] = tk2 - tk1;
+    status->tick[2] = tk3 - tk2;
+    status->tick[3] = tk4 - tk3;
+    status->tick[4] = 0;
+  }
+}
+
+static int chol_tiles(int k, int trr, int tcc) {
+  const int ntr = (k + trr - 1) / trr, ntc = (k + tcc - 1) / tcc;
+  int n = 0;
+  for (int I = 0; I < ntr; ++I)
+    for (int J = 0; J < ntc; ++J)
+      if (J * tcc + tcc - 1 >= I * trr) ++n;
+  return n;
+}
+
 int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
                     int full_r, double shift_rel, double pivot_tol) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "chol_inv: k=%d out of range", k);
@@ -553,7 +824,30 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
                        sm_ptr(ctx, SM_TMP2), SM_LD, rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_AUX),     \
                        sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);                                                 \
   } while (0)
-    if (ept <= 1) CHOL_REG(1);
+    static int use_tile = -1;   // HFMI_CHOL_TILE=0: the cyclic ownership map (A/B measurements)
+    if (use_tile < 0) {
+      const char* e = getenv("HFMI_CHOL_TILE");
+      use_tile = (e && atoi(e) == 0) ? 0 : 1;
+    }
+#define CHOL_TILE(A, B)                                                                                                 \
+  do {                                                                                                                  \
+    HIP_TRY(hipFuncSetAttribute((const void*)k_chol_tile<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+    hipLaunchKernelGGL((k_chol_tile<A, B>), dim3(1), dim3(CHOL_REG_THREADS), shm, ctx->stream, sm_ptr(ctx, slot_gram),  \
+                       SM_LD, k, sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot),                   \
+                       sm_ptr(ctx, SM_TMP2), SM_LD, rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_AUX),       \
+                       sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);                                                   \
+  } while (0)
+    // smallest rectangle whose tiles fit the 512 threads
+    if (use_tile && k >= 8) {
+      if (chol_tiles(k, 1, 2) <= CHOL_REG_THREADS) CHOL_TILE(1, 2);
+      else if (chol_tiles(k, 2, 2) <= CHOL_REG_THREADS) CHOL_TILE(2, 2);
+      else if (chol_tiles(k, 2, 3) <= CHOL_REG_THREADS) CHOL_TILE(2, 3);
+      else if (chol_tiles(k, 3, 3) <= CHOL_REG_THREADS) CHOL_TILE(3, 3);
+      else if (chol_tiles(k, 3, 4) <= CHOL_REG_THREADS) CHOL_TILE(3, 4);
+      else if (chol_tiles(k, 4, 4) <= CHOL_REG_THREADS) CHOL_TILE(4, 4);
+      else if (chol_tiles(k, 4, 5) <= CHOL_REG_THREADS) CHOL_TILE(4, 5);
+      else CHOL_TILE(5, 5);
+    } else if (ept <= 1) CHOL_REG(1);
     else if (ept <= 2) CHOL_REG(2);
     else if (ept <= 4) CHOL_REG(4);
     else if (ept <= 6) CHOL_REG(6);
@@ -562,6 +856,7 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
     else if (ept <= 16) CHOL_REG(16);
     else CHOL_REG(20);
 #undef CHOL_REG
+#undef CHOL_TILE
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
