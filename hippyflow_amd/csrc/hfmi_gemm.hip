@@ -44,7 +44,8 @@ template <int MT, int NT, bool TR, int WAVES, int R4>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
                                                                     const double* __restrict__ B, int64_t ldb, int k,
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
-                                                                    double* __restrict__ part, int mpad, int kpad, int probe) {
+                                                                    double* __restrict__ out, int64_t si, int64_t sj,
+                                                                    int64_t sps, int direct, int probe) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = TN_BK;
   constexpr int COLS = NT * 16;
@@ -204,22 +205,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     }
   }
 
-  double* P = part + (int64_t)sp * mpad * kpad;
+  // Results: element (i, j) goes to P[i si + j sj].  Split launches write raw partial tiles (padded image of split
+  // sp, summed by k_reduce_partials); a launch with ONE split and nothing to scale or accumulate writes the result
+  // block itself (direct: bounds-checked) -- config 2's m = 1e5 launches used to spend 0.28 ms copying one partial.
+  double* P = out + (int64_t)sp * sps;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NTF; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (TR) {
-          const int j = nt * 16 + kk + 4 * r;
-          const int i = rowbase + mt * 16 + r16;
-          P[(int64_t)j * mpad + i] = acc[mt][nt][r];
-        } else {
-          const int i = rowbase + mt * 16 + kk + 4 * r;
-          const int j = nt * 16 + r16;
-          P[(int64_t)i * kpad + j] = acc[mt][nt][r];
-        }
+        const int i = TR ? rowbase + mt * 16 + r16 : rowbase + mt * 16 + kk + 4 * r;
+        const int j = TR ? nt * 16 + kk + 4 * r : nt * 16 + r16;
+        if (!direct || (i < m && j < k)) P[(int64_t)i * si + (int64_t)j * sj] = acc[mt][nt][r];
       }
   if constexpr (R4 > 0) {
     // 4x4x4 results: lane 16 i + 4 g + j holds (row 4 g + i of the tile, column 4 q + j of the last tile)
@@ -230,8 +228,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
       for (int q = 0; q < R4; ++q) {
         const int i = rowbase + mt * 16 + 4 * g4 + i4;
         const int j = NTF * 16 + 4 * q + j4;
-        if (TR) P[(int64_t)j * mpad + i] = acc4[mt][q];
-        else P[(int64_t)i * kpad + j] = acc4[mt][q];
+        if (!direct || (i < m && j < k)) P[(int64_t)i * si + (int64_t)j * sj] = acc4[mt][q];
       }
   }
 }
@@ -343,6 +340,12 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
 //   rem4 : compute a last column tile of <= 12 columns with 4x4x4 MFMAs (1, default) or as a full 16-column tile (0)
 static int g_waves = 0, g_rem4 = 1, g_probe = 0;
+// where a launch writes: split partials (the reduce kernel sums them) or, for one split with nothing to scale, C itself
+struct TnOut {
+  bool direct;
+  double* C;
+  int64_t rs, cs;
+};
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
 static void tuning_init() {
   if (g_waves) return;
@@ -373,12 +376,14 @@ static inline int tn_mt_max(int nt, int waves) {
 
 template <int MT, int NT, int WAVES, bool TR, int R4>
 static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t N,
-                         int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
+                         int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad, const TnOut& o) {
   const size_t shmem = (size_t)2 * NT * 16 * (TN_BK + 2) * sizeof(double);
   auto kern = k_tsgemm_tn<MT, NT, TR, WAVES, R4>;
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  double* out = o.direct ? o.C : part;
+  const int64_t si = o.direct ? o.rs : (TR ? 1 : kpad), sj = o.direct ? o.cs : (TR ? mpad : 1);
   hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,
-                     nsplit, part, mpad, kpad, g_probe);
+                     nsplit, out, si, sj, (int64_t)mpad * kpad, o.direct ? 1 : 0, g_probe);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
@@ -386,11 +391,12 @@ static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
 // r4: number of 4-column groups the last column tile is computed in (0 = as a full 16-column tile)
 template <int MT, int NT, int WAVES>
 static int tn_launch_inst(hfmi_ctx* ctx, bool tr, int r4, const double* A, int64_t lda, int m, const double* B, int64_t ldb,
-                          int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad) {
+                          int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad, int kpad,
+                          const TnOut& o) {
 #define TN_R4(R)                                                                                                          \
   case R:                                                                                                                 \
-    if (tr) return tn_launch_one<MT, NT, WAVES, true, R>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad); \
-    return tn_launch_one<MT, NT, WAVES, false, R>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad);
+    if (tr) return tn_launch_one<MT, NT, WAVES, true, R>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad, o); \
+    return tn_launch_one<MT, NT, WAVES, false, R>(ctx, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad, o);
   if constexpr (WAVES == 8) {
     switch (r4) { TN_R4(1) TN_R4(2) TN_R4(3) }
   }
@@ -402,12 +408,12 @@ static int tn_launch_inst(hfmi_ctx* ctx, bool tr, int r4, const double* A, int64
 template <int NT, int WAVES>
 static int tn_dispatch_mt(hfmi_ctx* ctx, int mt, bool tr, int r4, const double* A, int64_t lda, int m, const double* B,
                           int64_t ldb, int k, int64_t N, int64_t chunk, int nrb, int nsplit, double* part, int mpad,
-                          int kpad) {
+                          int kpad, const TnOut& o) {
   constexpr int LIM = (WAVES == 8) ? 20 : 32;
 #define TN_CASE(M)                                                                                                 \
   case M:                                                                                                          \
     if constexpr (M * NT <= LIM)                                                                                   \
-      return tn_launch_inst<M, NT, WAVES>(ctx, tr, r4, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad); \
+      return tn_launch_inst<M, NT, WAVES>(ctx, tr, r4, A, lda, m, B, ldb, k, N, chunk, nrb, nsplit, part, mpad, kpad, o); \
     break;
   switch (mt) {
     TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(8)
@@ -474,13 +480,15 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   // columns of the last tile: up to 12 are done as 1..3 groups of 4 with the 4x4x4 MFMA (16 instead of 64 cycles each)
   const int rem = k - (nt - 1) * 16;
   const int r4 = (g_rem4 && waves == 8 && rem <= 12) ? (rem + 3) / 4 : 0;
+  const bool direct = (nsplit == 1 && scale == 1.0 && beta == 0.0 && C != A && C != B);   // blocks never overlap partially
+  const TnOut o = {direct, C, rs, cs};
   const int pidx = prof_start(ctx, 0, m, k, N);
 #define TN_NT(NTV)                                                                                                       \
   case NTV:                                                                                                              \
     if (waves == 8)                                                                                                      \
-      HFMI_TRY((tn_dispatch_mt<NTV, 8>(ctx, mt, tr, r4, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
+      HFMI_TRY((tn_dispatch_mt<NTV, 8>(ctx, mt, tr, r4, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad, o))); \
     else                                                                                                                 \
-      HFMI_TRY((tn_dispatch_mt<NTV, 4>(ctx, mt, tr, 0, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad))); \
+      HFMI_TRY((tn_dispatch_mt<NTV, 4>(ctx, mt, tr, 0, A, lda, m, B, ldb, k, Npad, chunk, nrb, nsplit, part, mpad, kpad, o))); \
     break;
   switch (nt) {
     TN_NT(1) TN_NT(2) TN_NT(3) TN_NT(4) TN_NT(5) TN_NT(6) TN_NT(7) TN_NT(8) TN_NT(9) TN_NT(10) TN_NT(11) TN_NT(12)
@@ -490,6 +498,7 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   }
 #undef TN_NT
   prof_stop(ctx, pidx);
+  if (direct) return HFMI_OK;
   return launch_reduce_partials(ctx, part, nsplit, (int64_t)mpad * kpad, tr ? mpad : kpad, tr, m, k, scale, beta, C, rs,
                                 cs);
 }

@@ -111,6 +111,26 @@ def test_block_dot_matches_numpy(ctx, m, k, N):
     assert np.max(np.abs(got - ref) / scale) < 1e-13
 
 
+@pytest.mark.parametrize("m,k,N", [(300, 74, 5000), (1000, 84, 3000), (500, 138, 4000), (383, 30, 2000), (700, 5, 9000)])
+def test_tsgemm_tn_single_split_writes_the_result_directly(ctx, m, k, N):
+    """One split, nothing to scale: tsgemm_tn stores the result block itself (bounds-checked, no partial + reduce)."""
+    import ctypes as C
+    from hippyflow_amd import _lib as L
+    rng = np.random.default_rng(m + k)
+    A = rng.standard_normal((N, m))
+    B = rng.standard_normal((N, k))
+    Am, Bm = hf.MultiVector.from_dense(A), hf.MultiVector.from_dense(B)
+    got = np.full((m, k), np.nan)
+    L.call("hfmi_tuning_set", b"ss", 0)          # keep skinny shapes on the tn kernel
+    try:
+        L.call("hfmi_bench_tsgemm_tn", Am.handle, Bm.handle, 1, 0, L.ptr(got), None)
+    finally:
+        L.call("hfmi_tuning_set", b"ss", 1)
+    ref = A.T @ B
+    scale = np.linalg.norm(A, axis=0)[:, None] * np.linalg.norm(B, axis=0)[None, :]
+    assert np.max(np.abs(got - ref) / scale) < 1e-13
+
+
 @pytest.mark.parametrize("k,N", [(5, 1000), (74, 30011), (138, 50000), (160, 4225)])
 def test_block_gram_same_operand(ctx, k, N):
     """Q^T Q with both arguments the SAME block (staged once through LDS) equals the two-operand product."""
