@@ -577,6 +577,43 @@ def test_full_size_config3_pod_properties(ctx):
     assert np.linalg.norm(Y3.norm()) < 1e-12 * np.linalg.norm(Y1.norm())
 
 
+def test_full_size_config2_kle_properties(ctx):
+    """Config 2 at full size (explicit dense covariance on N = 1e5 points, 80 GB in HBM; r = 64, p = 20): the invariants
+    of the reference's own KLE test (test_KLEProjector.py:91-129: M-orthonormality 1e-10, encoder = M decoder,
+    eigen-residual) and the factored oracle on the same Omega."""
+    from hippyflow_amd import workloads
+    import scipy.sparse.linalg as spla
+    wl = workloads.kle_workload(400, 250, latent=256, rate=0.08, seed=2)
+    N, r, k = wl.N, 64, 84
+    A = hf.MassPreconditionedCovarianceOperator(wl.C_operator, wl.M_operator)
+    B, Binv = wl.M_operator, hf.CsrPCGSolver(wl.M_operator.csr)
+    hf.parRandom.reseed(1)
+    Omega = hf.MultiVector(N, k)
+    hf.parRandom.normal(1.0, Omega)
+    d, U = hf.doublePassG(A, B, Binv, Omega, r, s=1)
+    assert np.all(np.diff(d) <= 0) and d[-1] > 0
+    MU = hf.MultiVector(N, r)
+    hf.MatMvMult(B, U, MU)
+    assert np.linalg.norm(U.dot_mv(MU) - np.eye(r)) / np.sqrt(r) < 1e-10, "U^T M U = I"
+    Md = wl.M @ U.to_dense()
+    assert rel(MU.to_dense(), Md) < 1e-13, "encoder = M decoder"
+    AU = hf.MultiVector(N, r)
+    A.matMvMult(U, AU)
+    Rn = hf.MultiVector(AU)
+    hf.MvDSmatMult(MU, np.diag(d), Rn)                    # A U - M U diag(d)
+    Rn.axpy(-1.0, AU)
+    # the residual of a randomized solve is set by the discarded tail: lambda_85 / lambda_1 = exp(-0.08 * 84) = 1.2e-3
+    # for this synthetic spectrum (the reference's 1e-4 is for its faster-decaying prior covariance)
+    assert np.linalg.norm(Rn.norm()) / np.linalg.norm(AU.norm()) < 1e-2
+    # the same solve by the CPU restatement, operator in factored form
+    F, lam, M = wl.F_host, wl.lam, wl.M
+    lu = spla.splu(M.tocsc())
+    d_ref, _ = hp_o.double_pass_blas3(lambda W: np.asfortranarray(M @ (F @ (lam[:, None] * (F.T @ (M @ W))))),
+                                      np.asfortranarray(Omega.to_dense()), r, apply_B=lambda W: M @ W,
+                                      apply_Binv=lambda W: np.asfortranarray(lu.solve(np.ascontiguousarray(W))))
+    assert hp_o.eig_rel_err(d, d_ref) < 1e-9
+
+
 def test_config4_shard_of_eight_gpu_run(ctx):
     """The per-GPU share of config 4 at 8 GPUs (64 of 512 samples, N = 2e5, 10 GB of Jacobians): the local
     operator against the factored host form of the same samples, plus prior-free double-pass invariants."""
