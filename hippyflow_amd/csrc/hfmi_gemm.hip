@@ -10,11 +10,13 @@
 //
 // All blocks are column-major with every vector contiguous along N, so in tsgemm_tn BOTH
 // operands are contiguous along the reduction index: an MFMA k-step may use any 4 reduction
-// indices as long as A and B agree, which lets each lane fetch 16 contiguous bytes (2 doubles)
-// per operand per two k-steps straight from HBM -- no transposition through LDS.  The operand
-// shared by the 4 waves of a workgroup (B in tn, S in nn) is staged through LDS; the streamed
-// operand goes HBM -> VGPR directly with a register prefetch ring.  One wave per SIMD holds a
-// (16*MT) x (16*NT) fp64 accumulator tile (up to 40 MFMA tiles = 320 VGPRs).
+// indices as long as A and B agree, which lets each lane fetch 16 or 32 contiguous bytes of its own
+// vector straight from HBM into the fragment layout -- no transposition through LDS.  The operand
+// shared by the waves of a workgroup (B in tn, S in nn) is staged through LDS; the streamed
+// operand goes HBM -> VGPR directly, prefetched one iteration ahead.  A wave holds a
+// (16*MT) x (16*NT) fp64 accumulator tile: up to 16 MFMA tiles with two waves per SIMD (the default),
+// up to 32 with one.  A last column tile of at most 12 columns runs on the 4x4x4 MFMA (R4).
+// tsgemm_nn lives in hfmi_gemm_nn.hip, the skinny x skinny case of tn in hfmi_skinny.hip.
 //
 // MFMA fragment maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&15][kk = l>>4] and
 // B[kk = l>>4][j = l&15]; it receives D[row = (l>>4) + 4*reg][col = l&15], reg = 0..3.
@@ -24,7 +26,6 @@
 // tsgemm_tn
 // =====================================================================================
 constexpr int TN_BK = 32;   // reduction indices per LDS stage
-constexpr int TN_LDB = 34;  // LDS leading dimension (doubles): 16-byte aligned rows, spreads banks
 
 // Preconditions (guaranteed by the block layout, hfmi.h): lda, ldb multiples of 32 doubles, rows N..ld-1 of
 // every vector are zero, so the reduction runs over whole 32-row stages with NO masks or branches in the loop:
