@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--samples-total", type=int, default=512,
                     help="config 4 only: total Monte-Carlo samples (512 = BASELINE; 64 on one GPU reproduces the per-GPU "
                          "share of the 8-GPU run, for estimating the non-scaling part)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo lets several ranks SHARE one GPU (a functional check of the "
+                         "sharded path on a 1-GPU box: blocks are staged through the host, so its timing means nothing)")
     ap.add_argument("--dist-single", action="store_true",
                     help="exercise the multi-GPU code path (process group, TorchCollective, all-reduce hook) with one rank")
     return ap.parse_args()
@@ -166,13 +169,17 @@ def main():
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        dev = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(args.backend, rank=0, world_size=1,
+                                    **({"device_id": torch.device("cuda", dev)} if args.backend == "nccl" else {}))
+        elif args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("gloo")
         collective = hf.TorchCollective()
     else:
         collective = hf.NullCollective()
