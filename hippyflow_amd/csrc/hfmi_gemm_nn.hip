@@ -475,13 +475,6 @@ __global__ void k_reduce_nn(const double* __restrict__ part, int msplit, int64_t
   }
 }
 
-// tallest wave tile (in 16-row tiles along the long axis) for nt column tiles
-static inline int nn_tt(int nt, int waves) {
-  static const int t4[17] = {0, 8, 8, 8, 8, 6, 5, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2};
-  static const int t8[17] = {0, 8, 8, 5, 4, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1};
-  return waves == 4 ? t4[nt] : t8[nt];
-}
-
 // Launch plan of tsgemm_nn for a tile of `tile_rows` rows: how many ways to split the reduction axis m so that the
 // grid fills the 256 CUs in (nearly) whole rounds.  Time model (the kernel is MFMA bound, the split partials only
 // cost their own HBM round trip in k_reduce_nn): t = flops / (eff * rate) + (msplit + 1) * N * r * 8 / hbm.

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_ell_spmm(const int32_t* __restrict__ ei
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][jj] = d;
       }
       __syncthreads();
-      if (threadIdx.x < SPMM_EB && j0 + threadIdx.x < nvec)
+      if ((int)threadIdx.x < SPMM_EB && j0 + (int)threadIdx.x < nvec)
         part[(int64_t)(j0 + threadIdx.x) * gridDim.x + blockIdx.x] =
             (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
       __syncthreads();
