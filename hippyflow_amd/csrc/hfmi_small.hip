@@ -1359,6 +1359,71 @@ __global__ __launch_bounds__(128) void k_jacobi_vectors(const double2* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_jacobi_vectors_wave: the same replay with one WAVE per row (n <= 128 seats: lane P keeps the pair seated in
+// (2P, 2P+1) in registers).  A round is a rotation in registers and three lane shifts (the top row of the tournament
+// walks right, the bottom row left, the two end seats swap rows) -- no LDS, no barrier.
+// whole-wave shifts by one lane as DPP moves (wave_shr:1 = 0x138, wave_shl:1 = 0x130 on GFX9): two v_mov_b32_dpp per
+// double instead of two ds_bpermute round trips (with __shfl the replay was slower than the LDS version)
+__device__ __forceinline__ double lane_shr1(double v) {   // lane P <- lane P - 1 (lane 0 keeps its own)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_shl1(double v) {   // lane P <- lane P + 1 (lane 63 keeps its own)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void k_jacobi_vectors_wave(const double2* __restrict__ rotlog, int k,
+                                                             const hfmi_status_words* __restrict__ status,
+                                                             const int* __restrict__ perm, double* __restrict__ V, int ldv) {
+  __shared__ double rowbuf[4][130];
+  const int n = (k + 1) & ~1, np = n / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;                     // row of V handled by this wave (wave-uniform)
+  const int rounds = status->sweeps * (n - 1);
+  const bool act = lane < np;
+  double x = (2 * lane == i) ? 1.0 : 0.0, y = (2 * lane + 1 == i) ? 1.0 : 0.0;
+  constexpr int PF = 32;   // a round is ~100 cycles here: 8 rounds ahead no longer cover the memory latency
+  const double2* lg = rotlog + (act ? lane : 0);
+  double2 ring[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) ring[u] = (u < rounds) ? lg[(size_t)u * np] : make_double2(1.0, 0.0);
+  if (i < k) {
+    for (int r0 = 0; r0 < rounds; r0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int rr = r0 + u;
+        if (rr < rounds) {   // uniform
+          const double2 cs = act ? ring[u] : make_double2(1.0, 0.0);
+          const int nxt = rr + PF;
+          ring[u] = (nxt < rounds) ? lg[(size_t)nxt * np] : make_double2(1.0, 0.0);
+          const double nx = cs.x * x - cs.y * y, ny = cs.y * x + cs.x * y;
+          if (n > 2) {
+            const double xr = lane_shr1(nx), yr = lane_shr1(ny), yl = lane_shl1(ny);
+            x = (lane == 0) ? nx : (lane == 1) ? yr : xr;    // seat 0 stays, seat 1 climbs to seat 2, 2P-2 -> 2P
+            y = (lane == np - 1) ? nx : yl;                  // seat n-2 drops to n-1, 2P+3 -> 2P+1
+          } else {
+            x = nx;
+            y = ny;
+          }
+        }
+      }
+    }
+    if (act) {
+      rowbuf[wave][2 * lane] = x;
+      rowbuf[wave][2 * lane + 1] = y;
+    }
+  }
+  __syncthreads();
+  if (i < k) {
+    for (int c = lane; c < k; c += 64) V[i * ldv + c] = rowbuf[wave][perm[c]];
+    for (int c = k + lane; c < ((k + 15) & ~15); c += 64) V[i * ldv + c] = 0.0;
+  }
+}
+
 // One-sided (Hestenes) Jacobi SVD of a small square matrix R = U diag(sigma) V^T: column pairs of W (= R, then
 // R V) are rotated until mutually orthogonal; sigma_j = ||w_j||, U = W diag(1/sigma), V = product of the
 // rotations (logged, replayed by k_jacobi_vectors).  Full relative accuracy for small singular values (unlike
@@ -1563,8 +1628,12 @@ int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dval
 #undef JAC_LAUNCH
 #undef JAC_LAUNCH2
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
-                     sm_ptr(ctx, slot_v), SM_LD);
+  if (n <= 128 && !getenv("HFMI_JACOBI_REPLAY_LDS"))
+    hipLaunchKernelGGL(k_jacobi_vectors_wave, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
+                       sm_ptr(ctx, slot_v), SM_LD);
+  else
+    hipLaunchKernelGGL(k_jacobi_vectors, dim3(k), dim3(128), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
+                       sm_ptr(ctx, slot_v), SM_LD);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
