@@ -656,12 +656,14 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
   HFMI_TRY(ctx_tmp_block(ctx, 10, N, k, &P));
   HFMI_TRY(ctx_tmp_block(ctx, 11, N, k, &AP));
   void* sc = nullptr;
-  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)5 * k * sizeof(double), &sc));
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)6 * k * sizeof(double), &sc));
+  // two (r.z, r.r) pairs: an iteration reads r.z from one and writes the new r.z and r.r into the other (r.r must follow
+  // r.z_new: launch_pcg_update fills both with one final pass); the pairs swap roles instead of being copied
   double* rz = (double*)sc;       // r.z
-  double* rz_new = rz + k;
-  double* rr = rz + 2 * k;        // must follow rz_new (launch_pcg_update fills both with one final pass)
-  double* pap = rz + 3 * k;
-  double* bb = rz + 4 * k;
+  double* rz_new = rz + 2 * k;
+  double* rr = rz_new + k;
+  double* pap = rz + 4 * k;
+  double* bb = rz + 5 * k;
   std::vector<double> h_rr(k), h_bb(k);
   // x0 = 0, r = b
   HFMI_TRY(launch_fill(ctx, Y->p, N, k, Y->ld, 0.0, false));
@@ -680,9 +682,11 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
       HFMI_TRY(launch_ell_spmm_dot(ctx, M, P->p, P->ld, AP->p, AP->ld, k, pap));
       HFMI_TRY(launch_pcg_update(ctx, Y->p, Y->ld, R->p, R->ld, P->p, P->ld, AP->p, AP->ld, M->inv_diag, N, k, rz, pap, rz_new, rr));
       HFMI_TRY(launch_pcg_direction(ctx, P->p, P->ld, R->p, R->ld, M->inv_diag, N, k, rz_new, rz));
-      HIP_TRY(hipMemcpyAsync(rz, rz_new, (size_t)k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      double* const rr_done = rr;
+      std::swap(rz, rz_new);        // the pair just written becomes "current"
+      rr = rz_new + k;
       if ((it & 3) == 3 || it + 1 == op->max_iter) {
-        HFMI_TRY(read_back(ctx, rr, k, h_rr.data()));
+        HFMI_TRY(read_back(ctx, rr_done, k, h_rr.data()));
         done = true;
         for (int j = 0; j < k; ++j)
           if (h_rr[j] > op->rel_tol * op->rel_tol * h_bb[j]) done = false;
