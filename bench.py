@@ -66,11 +66,10 @@ def build_workload(args, hf, rank, world):
     elif args.workload == "pod":
         N, n, r, p = 500000 // scale, 2048, 128, 10
         assert n % world == 0
-        wl = workloads.pod_workload(N, n, latent=256, rate=0.05, seed=3)
-        if world > 1:
-            raise SystemExit("pod workload: single GPU only in this bench")
+        wl = workloads.pod_workload(N, n, latent=256, rate=0.05, seed=3, first_snapshot=rank * (n // world), n_local=n // world)
         desc = {"workload": "config3 PODProjector: %d snapshots x N=%d, r=%d, p=%d" % (n, N, r, p), "N": N, "snapshots": n,
-                "rank": r, "oversampling": p, "parallelism": "single GPU"}
+                "snapshots_per_gpu": n // world, "rank": r, "oversampling": p,
+                "parallelism": "single GPU" if world == 1 else "snapshot-parallel x%d, one all-reduce(avg) of the N x k block per operator application" % world}
         op = wl.operator
         B = Binv = None
     else:

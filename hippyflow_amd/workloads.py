@@ -43,20 +43,24 @@ def _expand(W0, S, ctx):
     return out
 
 
-def pod_workload(N, n, latent=256, rate=0.05, seed=3, ctx=None):
-    """n snapshots of length N; exact eigenvalues of (1/n) X^T X are sigma_j^2 / n."""
+def pod_workload(N, n, latent=256, rate=0.05, seed=3, ctx=None, first_snapshot=0, n_local=None):
+    """n snapshots of length N; exact eigenvalues of (1/n) X^T X are sigma_j^2 / n.  With ``n_local`` the workload holds
+    only the snapshots first_snapshot ... first_snapshot + n_local - 1 of the SAME n-snapshot set (the per-rank shard of a
+    snapshot-parallel run, PODProjector.py:359-363): its operator is the shard mean (1/n_local) X_g^T X_g, and the rank
+    average of P equal shards is the full operator."""
     ctx = ctx or L.Context.default()
     c = int(min(latent, n, 256))
+    n_local = int(n if n_local is None else n_local)
     wl = Workload()
-    wl.N, wl.n, wl.latent = int(N), int(n), c
+    wl.N, wl.n, wl.latent, wl.n_local, wl.first_snapshot = int(N), int(n), c, n_local, int(first_snapshot)
     wl.W0 = _orthonormal_block(N, c, seed, 100, ctx)
     rng = np.random.default_rng(seed)
     U0, _ = np.linalg.qr(rng.standard_normal((n, c)))
     wl.sigma = np.exp(-rate * np.arange(c))
     wl.U0 = U0
     S = (U0 * wl.sigma).T                               # c x n
-    wl.X = _expand(wl.W0, S, ctx)                       # one snapshot per vector
-    wl.operator = SnapshotGramOperator(wl.X, scale=1.0 / n)
+    wl.X = _expand(wl.W0, S[:, first_snapshot:first_snapshot + n_local], ctx)   # one snapshot per vector
+    wl.operator = SnapshotGramOperator(wl.X, scale=1.0 / n_local)
     wl.exact_eigenvalues = wl.sigma ** 2 / n
     return wl
 
