@@ -11,8 +11,10 @@ Jacobians in 288 GB of HBM) and it is the one path with a real exchange step, so
 timed at every N (strong scaling): the samples are sharded 512/N per rank and the block J^T J Omega is
 all-reduced (RCCL over xGMI) once per operator application.
 
-For N > 1 the driver launches this file through ``python -m torch.distributed.run`` (one rank per GPU).
-Rank 0 prints ONE JSON line.
+N > 1 runs one rank per GPU over the native communicator of libhfmi (RCCL over xGMI; no torch in this file).  Either
+launch works: plain ``python bench.py --gpus N`` (this process then only spawns the N ranks and touches no GPU), or
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE from
+the environment).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -42,11 +44,12 @@ def parse_args():
     ap.add_argument("--samples-total", type=int, default=512,
                     help="config 4 only: total Monte-Carlo samples (512 = BASELINE; 64 on one GPU reproduces the per-GPU "
                          "share of the 8-GPU run, for estimating the non-scaling part)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend; gloo lets several ranks SHARE one GPU (a functional check of the "
-                         "sharded path on a 1-GPU box: blocks are staged through the host, so its timing means nothing)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "p2p"],
+                    help="device transport of the native communicator (HFMI_COMM_TRANSPORT): auto = RCCL over xGMI when every "
+                         "rank has its own GPU, direct peer access (HIP IPC) when ranks SHARE a GPU -- the functional check of "
+                         "the sharded path on a 1-GPU box")
     ap.add_argument("--dist-single", action="store_true",
-                    help="exercise the multi-GPU code path (process group, TorchCollective, all-reduce hook) with one rank")
+                    help="exercise the multi-GPU code path (native communicator, all-reduce inside the fused solve) with one rank")
     return ap.parse_args()
 
 
@@ -150,41 +153,33 @@ def cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this parent touches no GPU; it starts N fresh child interpreters (one per
+        # device, nothing is re-exec'ed) and rank 0's JSON line arrives on the inherited stdout
+        from hippyflow_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     # stdout carries exactly ONE JSON line: anything libraries print (e.g. the RCCL version banner) goes to stderr
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.transport != "auto":
+        os.environ["HFMI_COMM_TRANSPORT"] = args.transport
 
     import hippyflow_amd as hf
-    dist = None
-    use_dist = world > 1 or args.dist_single
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        dev = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(dev)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group(args.backend, rank=0, world_size=1,
-                                    **({"device_id": torch.device("cuda", dev)} if args.backend == "nccl" else {}))
-        elif args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo")
-        collective = hf.TorchCollective()
-    else:
-        collective = hf.NullCollective()
     if hf.device_count() < 1:
         raise SystemExit("bench.py needs a GPU (libhfmi has no CPU path)")
-    ctx = hf.Context.default()
+    ctx = hf.Context.default()                       # cuda:LOCAL_RANK
+    use_dist = world > 1 or args.dist_single
+    if world > 1:
+        collective = hf.NativeCollective.from_env(ctx)          # id through $HFMI_COMM_ID_FILE / the launcher's temp file
+    elif args.dist_single:
+        collective = hf.NativeCollective.from_unique_id(hf.NativeCollective.unique_id(), 1, 0, ctx=ctx)
+    else:
+        collective = hf.NullCollective()
 
     wl, op, B, Binv, N, r, p, desc = build_workload(args, hf, rank, world)
     k = r + p
@@ -199,10 +194,7 @@ def main():
         return hf.doublePassG(A, B, Binv, Omega, r, s=1)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+        collective.barrier()                         # drains this rank's stream, then meets the other ranks
         ctx.synchronize()
 
     for _ in range(args.warmup):
@@ -215,15 +207,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if use_dist:
+        elapsed = collective.allReduceMax(elapsed)   # the slowest rank's clock
+    comm_info = {"ranks": collective.size(), "transport": getattr(collective, "transport", "none"),
+                 "launcher": os.environ.get("HFMI_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none")}
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        collective.barrier()
+        if use_dist:
+            collective.close()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -231,7 +222,7 @@ def main():
     out = {"metric": "randomized-SVD throughput (GDoF*rank/s)", "value": value, "unit": "GDoF*rank/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded latent-factor model, generated in HBM)",
-           "config": desc}
+           "config": desc, "communicator": comm_info}
 
     # roofline of the dominant kernel (= the (kernel, shape) group with the largest total time), from per-launch
     # HIP events recorded inside the timed region on the stream the kernels run on
@@ -301,9 +292,9 @@ def main():
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
     os.dup2(2, 1)                      # whatever the libraries print while shutting down stays off stdout
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    collective.barrier()
+    if use_dist:
+        collective.close()
 
 
 if __name__ == "__main__":

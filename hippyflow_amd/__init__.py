@@ -7,7 +7,7 @@ raises if libhfmi.so or a GPU is missing.
 """
 from ._lib import Context, HfmiError, device_count, load
 from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, MultipleSamePartitioningPDEsCollective,
-                          MultipleSerialPDEsCollective, NullCollective, TorchCollective)
+                          MultipleSerialPDEsCollective, NativeCollective, NullCollective, TorchCollective)
 from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector
 from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobianOperator, DeviceOperator, HostCallbackOperator,
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,

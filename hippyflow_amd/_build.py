@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhfmi.so")
-SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip"]
+SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip", "hfmi_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -58,7 +58,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or not _newer(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lrt", "-lpthread"])
     return LIB
 
 

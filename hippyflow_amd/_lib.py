@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("HFMI_LIB") or os.path.join(HERE, "libhfmi.so")   # HF
 LAYOUT_VECTORS = 0
 LAYOUT_DENSE = 1
 QR_CHOL, QR_MGS, QR_AUTO = 0, 1, 2
+UNIQUE_ID_BYTES = 256
+REDUCE_SUM, REDUCE_AVG, REDUCE_MAX = 0, 1, 2
 
 HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_int)
 POST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
@@ -65,7 +67,18 @@ SIGNATURES = {
     "hfmi_op_compose3": [_P, _P, _P, _P, _PP],
     "hfmi_op_host_callback": [_P, HOST_APPLY_FN, _P, C.c_int64, _PP],
     "hfmi_op_set_post_apply": [_P, POST_APPLY_FN, _P],
+    "hfmi_op_set_collective": [_P, _P, C.c_int],
     "hfmi_op_apply": [_P, _P, _P, C.c_int],
+    "hfmi_comm_unique_id": [_P],
+    "hfmi_comm_init_rank": [_P, _P, C.c_int, C.c_int, _PP],
+    "hfmi_comm_init_from_file": [_P, C.c_char_p, C.c_int, C.c_int, _PP],
+    "hfmi_comm_info": [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "hfmi_comm_barrier": [_P],
+    "hfmi_allreduce": [_P, _P, C.c_int],
+    "hfmi_bcast": [_P, _P, C.c_int],
+    "hfmi_allreduce_host": [_P, _P, C.c_int64, C.c_int],
+    "hfmi_bcast_host": [_P, _P, C.c_int64, C.c_int],
+    "hfmi_comm_destroy": [_P],
     "hfmi_op_destroy": [_P],
     "hfmi_borth_qr": [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int)],
     "hfmi_sym_eig_small": [_P, _P, C.c_int, C.c_int, _P, _P],
@@ -91,12 +104,18 @@ def _preload_hip_runtime():
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
-            pass
+            return
+        # the communicator opens librccl at run time: pair torch's HIP runtime with torch's RCCL build (and let a later
+        # `import torch` find that copy already loaded) unless the caller chose one
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("HFMI_RCCL_LIB", rccl)
 
 
 def load():

@@ -7,23 +7,40 @@ Reference (under /root/reference/hippyflow/collectives):
   CollectiveOperator                       collectiveOperator.py:14-55
   MatrixMultCollectiveOperator             collectiveOperator.py:58-97
 
-Here the communicator is ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on
-CPU), one process per GPU.  A whole N x k block is reduced in ONE all-reduce on its device memory
-(the reference sends k messages of length N through host copies, collective.py:98-111).
+Here the communicator is ``NativeCollective``: an ``hfmi_comm`` of libhfmi (include/hfmi.h), one process per
+GPU, RCCL over xGMI underneath.  A whole N x k block is reduced by ONE all-reduce on its device memory, on the
+context's stream (the reference sends k messages of length N through host copies, collective.py:98-111).  No torch
+is imported on this path.  ``TorchCollective`` offers the same protocol over an existing ``torch.distributed``
+process group (hosts that already run one; the gloo tests on CPU).
+
+What a collective accepts (collective.py:74-159): a float / int (returned), a numpy array (overwritten,
+returned), a device Vector or MultiVector (reduced in place in HBM), a dolfin-like vector
+(``get_local`` / ``set_local`` / ``apply``), or any container with ``nvec()`` and ``[i]``.  ``op`` is 'sum' or 'avg',
+any case.  Anything else raises NotImplementedError.
 """
 import ctypes as C
+import os
+import tempfile
 
 import numpy as np
 
 from . import _lib as L
 from .multivector import MultiVector, Vector
 
+_REDUCE_CODES = {"sum": 0, "avg": 1}
+_SCALAR_FLOATS = (float, np.floating)
+_SCALAR_INTS = (int, np.integer)
+
+
+def _reduce_code(op, who):
+    code = _REDUCE_CODES.get(op.lower() if isinstance(op, str) else None)
+    if code is None:
+        raise NotImplementedError("%s: reduction %r is not available (use 'sum' or 'avg')" % (who, op))
+    return code
+
 
 class NullCollective:
-    """No-overhead "parallel" reduction utilities on one process (collective.py:19-38)."""
-
-    def bcast(self, v, root=0):
-        return v
+    """The one-process communicator (collective.py:19-38): reductions and broadcasts hand their argument back."""
 
     def size(self):
         return 1
@@ -32,10 +49,224 @@ class NullCollective:
         return 0
 
     def allReduce(self, v, op):
-        if op.lower() not in ["sum", "avg"]:
-            err_msg = "Unknown operation *{0}* in NullCollective.allReduce".format(op)
-            raise NotImplementedError(err_msg)
+        _reduce_code(op, "NullCollective.allReduce")
         return v
+
+    def bcast(self, v, root=0):
+        return v
+
+    def barrier(self):
+        pass
+
+
+def _payload_kind(v):
+    """Which of the payload shapes of collective.py:74-159 ``v`` is (bool is not a number here)."""
+    if isinstance(v, bool):
+        return None
+    if isinstance(v, _SCALAR_FLOATS):
+        return "float"
+    if isinstance(v, _SCALAR_INTS):
+        return "int"
+    if isinstance(v, np.ndarray):
+        return "array"
+    if isinstance(v, MultiVector):
+        return "block"
+    if isinstance(v, Vector):
+        return "vector"
+    if hasattr(v, "get_local") and hasattr(v, "set_local"):
+        return "dolfin"
+    if hasattr(v, "nvec"):
+        return "container"
+    return None
+
+
+class _Collective:
+    """Payload dispatch shared by the communicators.  A subclass supplies four primitives:
+    ``_reduce_f64(arr, code)`` and ``_bcast_raw(arr, root)`` on contiguous host arrays (in place),
+    ``_reduce_block(mv, code)`` and ``_bcast_block(mv, root)`` on device blocks (in place)."""
+
+    name = "collective"
+
+    # ---- reductions
+    def allReduce(self, v, op):
+        code = _reduce_code(op, self.name + ".allReduce")
+        kind = _payload_kind(v)
+        handler = getattr(self, "_reduce_" + kind, None) if kind else None
+        if handler is None:
+            raise NotImplementedError("%s.allReduce: no rule for a payload of type %s" % (self.name, type(v).__name__))
+        return handler(v, code)
+
+    def _reduce_float(self, v, code):
+        box = np.array([v], dtype=np.float64)
+        self._reduce_f64(box, code)
+        return box[0]
+
+    def _reduce_int(self, v, code):
+        total = self._reduce_float(float(v), code)
+        return type(v)(total) if code == 0 else total      # the mean of integers is a float (collective.py:90-93)
+
+    def _reduce_array(self, v, code):
+        if v.dtype == np.float64 and v.flags.c_contiguous:
+            self._reduce_f64(v, code)
+        else:
+            tmp = np.ascontiguousarray(v, dtype=np.float64)
+            self._reduce_f64(tmp, code)
+            v[...] = tmp
+        return v
+
+    def _reduce_vector(self, v, code):
+        self._reduce_block(v._mv, code)
+        return v
+
+    def _reduce_dolfin(self, v, code):
+        local = np.ascontiguousarray(v.get_local(), dtype=np.float64)
+        self._reduce_f64(local, code)
+        v.set_local(local)
+        v.apply("")
+        return v
+
+    def _reduce_container(self, v, code):
+        op = "sum" if code == 0 else "avg"
+        for i in range(v.nvec()):
+            self.allReduce(v[i], op)
+        return v
+
+    # ---- broadcasts
+    def bcast(self, v, root=0):
+        kind = _payload_kind(v)
+        handler = getattr(self, "_bcast_" + kind, None) if kind else None
+        if handler is None:
+            raise NotImplementedError("%s.bcast: no rule for a payload of type %s" % (self.name, type(v).__name__))
+        return handler(v, root)
+
+    def _bcast_float(self, v, root):
+        box = np.array([v], dtype=np.float64)
+        self._bcast_raw(box, root)
+        return type(v)(box[0])
+
+    def _bcast_int(self, v, root):
+        box = np.array([v], dtype=np.int64)
+        self._bcast_raw(box, root)
+        return type(v)(box[0])
+
+    def _bcast_array(self, v, root):
+        if v.flags.c_contiguous:
+            self._bcast_raw(v, root)
+        else:
+            tmp = np.ascontiguousarray(v)
+            self._bcast_raw(tmp, root)
+            v[...] = tmp
+        return v
+
+    def _bcast_vector(self, v, root):
+        self._bcast_block(v._mv, root)
+        return v
+
+    def _bcast_dolfin(self, v, root):
+        local = np.ascontiguousarray(v.get_local(), dtype=np.float64)
+        self._bcast_raw(local, root)
+        v.set_local(local)
+        v.apply("")
+        return v
+
+    def _bcast_container(self, v, root):
+        for i in range(v.nvec()):
+            self.bcast(v[i], root=root)
+        return v
+
+
+def default_id_file():
+    """Where the ranks of one launch meet when nobody names a file: the temp directory, keyed by the launcher's
+    pid (the common parent of the ranks, e.g. the torch.distributed.run agent) and MASTER_PORT."""
+    key = "%s-%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    return os.path.join(tempfile.gettempdir(), "hfmi-comm-%s.id" % key)
+
+
+class NativeCollective(_Collective):
+    """``hfmi_comm`` behind the collective protocol: counterpart of MultipleSamePartitioningPDEsCollective
+    (collective.py:43-159) with RCCL in place of mpi4py.  Blocks are reduced / broadcast in place in HBM on the
+    context's stream; host payloads go through the node's shared segment."""
+
+    name = "NativeCollective"
+    TRANSPORTS = {0: "host", 1: "rccl", 2: "p2p"}
+
+    def __init__(self, handle, ctx, is_serial_check=False):
+        self._comm = handle
+        self.ctx = ctx
+        self.is_serial_check = is_serial_check
+        n, r, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        L.call("hfmi_comm_info", self._comm, C.byref(n), C.byref(r), C.byref(t))
+        self._size, self._rank, self.transport = n.value, r.value, self.TRANSPORTS.get(t.value, str(t.value))
+
+    # ---- construction
+    @staticmethod
+    def unique_id():
+        """Bytes to be made on ONE rank and shipped to the others (e.g. ``comm.bcast`` of mpi4py)."""
+        buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+        L.call("hfmi_comm_unique_id", buf)
+        return buf.raw
+
+    @classmethod
+    def from_unique_id(cls, id_bytes, nranks, rank, ctx=None, host_only=False):
+        if len(id_bytes) != L.UNIQUE_ID_BYTES:
+            raise ValueError("communicator id must be %d bytes" % L.UNIQUE_ID_BYTES)
+        ctx = None if host_only else (ctx or L.Context.default())
+        h = C.c_void_p()
+        L.call("hfmi_comm_init_rank", ctx.handle if ctx else None, C.c_char_p(id_bytes), int(nranks), int(rank), C.byref(h))
+        return cls(h, ctx)
+
+    @classmethod
+    def from_env(cls, ctx=None, id_file=None, host_only=False):
+        """One rank per process, numbered by RANK / WORLD_SIZE (set by ``hippyflow_amd.launch`` or by
+        ``python -m torch.distributed.run``); the id travels through ``id_file`` / $HFMI_COMM_ID_FILE / a file in
+        the temp directory keyed by the launcher."""
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        path = id_file or os.environ.get("HFMI_COMM_ID_FILE") or default_id_file()
+        ctx = None if host_only else (ctx or L.Context.default())
+        h = C.c_void_p()
+        L.call("hfmi_comm_init_from_file", ctx.handle if ctx else None, path.encode(), world, rank, C.byref(h))
+        return cls(h, ctx)
+
+    # ---- protocol
+    def size(self):
+        return self._size
+
+    def rank(self):
+        return self._rank
+
+    def barrier(self):
+        L.call("hfmi_comm_barrier", self._comm)
+
+    def allReduceMax(self, value):
+        """Largest value over the ranks (bench.py's max-over-ranks timing; not part of the reference's protocol)."""
+        box = np.array([value], dtype=np.float64)
+        L.call("hfmi_allreduce_host", self._comm, L.ptr(box), 1, 2)
+        return float(box[0])
+
+    def _reduce_f64(self, arr, code):
+        L.call("hfmi_allreduce_host", self._comm, L.ptr(arr), int(arr.size), code)
+
+    def _bcast_raw(self, arr, root):
+        L.call("hfmi_bcast_host", self._comm, L.ptr(arr), int(arr.nbytes), int(root))
+
+    def _reduce_block(self, mv, code):
+        L.call("hfmi_allreduce", self._comm, mv.handle, code)
+        return mv
+
+    def _bcast_block(self, mv, root):
+        L.call("hfmi_bcast", self._comm, mv.handle, int(root))
+        return mv
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            L.load().hfmi_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _CudaArrayView:
@@ -46,13 +277,12 @@ class _CudaArrayView:
                                          "version": 2, "strides": None}
 
 
-class TorchCollective:
-    """Counterpart of MultipleSamePartitioningPDEsCollective over a torch.distributed process group.
+class TorchCollective(_Collective):
+    """The same protocol over a ``torch.distributed`` process group ("nccl" = RCCL on the GPUs, "gloo" on CPU), for
+    hosts that already run one.  Device blocks are handed to torch zero-copy and the collective is ordered on
+    libhfmi's stream."""
 
-    ``allReduce(v, op)``: ``op`` in {"sum", "avg"} (case-insensitive); ``v`` may be a float / int
-    (returned), a numpy array (overwritten, returned), a device Vector or MultiVector (reduced in place
-    in HBM), or any object with ``nvec``/``[i]``.  ``bcast(v, root)`` likewise.  Anything else raises
-    NotImplementedError, as in the reference (collective.py:112-117,153-159)."""
+    name = "TorchCollective"
 
     def __init__(self, group=None, is_serial_check=False):
         import torch.distributed as dist
@@ -68,6 +298,9 @@ class TorchCollective:
     def rank(self):
         return self.dist.get_rank(self.group)
 
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
     # -- helpers
     def _backend_device(self):
         import torch
@@ -75,19 +308,18 @@ class TorchCollective:
             return torch.device("cuda", torch.cuda.current_device())
         return torch.device("cpu")
 
-    def _allReduce_array(self, v, op):
+    def _reduce_f64(self, arr, code):
         import torch
-        err_msg = "Unknown operation *{0}* in TorchCollective.allReduce".format(op)
-        if op not in ("sum", "avg"):
-            raise NotImplementedError(err_msg)
-        t = torch.from_numpy(np.ascontiguousarray(v)).to(self._backend_device())
+        t = torch.from_numpy(arr).to(self._backend_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        receive = t.cpu().numpy()
-        if op == "sum":
-            v[:] = receive
-        else:
-            v[:] = (1. / float(self.size())) * receive
-        return v
+        out = t.cpu().numpy()
+        arr[...] = out if code == 0 else out * (1.0 / float(self.size()))
+
+    def _bcast_raw(self, arr, root):
+        import torch
+        t = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(self._backend_device())
+        self.dist.broadcast(t, src=root, group=self.group)
+        arr.view(np.uint8).reshape(-1)[...] = t.cpu().numpy()
 
     def _tensor_of(self, mv):
         """torch tensor aliasing the block's storage (including the zero padding rows).  Returns
@@ -120,112 +352,47 @@ class TorchCollective:
             return None
         return torch.cuda.stream(torch.cuda.ExternalStream(sp, device=torch.device("cuda", mv.ctx.device)))
 
-    def _reduce_block(self, mv, op):
+    def _block_collective(self, mv, run):
         import torch
-        if op not in ("sum", "avg"):
-            raise NotImplementedError("Unknown operation *{0}* in TorchCollective.allReduce".format(op))
         t, stage = self._tensor_of(mv)
         cm = self._on_block_stream(mv) if stage is None else None
-        if cm is None:
-            mv.ctx.synchronize()                   # libhfmi's stream -> host: the block is complete
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            if op == "avg":
-                t.mul_(1.0 / float(self.size()))
-            torch.cuda.current_stream(mv.ctx.device).synchronize()   # RCCL + scale done before libhfmi reads
-            if stage is not None:
-                mv.copy_from(stage)
-                mv.ctx.synchronize()
+        if cm is not None:
+            with cm:
+                run(t)
             return mv
-        with cm:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            if op == "avg":
-                t.mul_(1.0 / float(self.size()))
+        mv.ctx.synchronize()                   # libhfmi's stream -> host: the block is complete
+        run(t)
+        torch.cuda.current_stream(mv.ctx.device).synchronize()   # the collective is done before libhfmi reads
+        if stage is not None:
+            mv.copy_from(stage)
+            mv.ctx.synchronize()
         return mv
+
+    def _reduce_block(self, mv, code):
+        def run(t):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if code == 1:
+                t.mul_(1.0 / float(self.size()))
+        return self._block_collective(mv, run)
 
     def _bcast_block(self, mv, root):
-        import torch
-        t, stage = self._tensor_of(mv)
-        cm = self._on_block_stream(mv) if stage is None else None
-        if cm is None:
-            mv.ctx.synchronize()
-            self.dist.broadcast(t, src=root, group=self.group)
-            torch.cuda.current_stream(mv.ctx.device).synchronize()
-            if stage is not None:
-                mv.copy_from(stage)
-                mv.ctx.synchronize()
-            return mv
-        with cm:
-            self.dist.broadcast(t, src=root, group=self.group)
-        return mv
-
-    def allReduce(self, v, op):
-        op = op.lower()
-        if type(v) in [float, np.float64]:
-            v_array = np.array([v], dtype=np.float64)
-            self._allReduce_array(v_array, op)
-            return v_array[0]
-        elif type(v) in [int, np.int32, np.int64]:
-            v_array = np.array([v], dtype=np.float64)
-            self._allReduce_array(v_array, op)
-            return type(v)(v_array[0]) if op == "sum" else v_array[0]
-        elif type(v) is np.ndarray:
-            return self._allReduce_array(v, op)
-        elif isinstance(v, MultiVector):
-            return self._reduce_block(v, op)
-        elif isinstance(v, Vector):
-            self._reduce_block(v._mv, op)
-            return v
-        elif hasattr(v, "mpi_comm") and hasattr(v, "get_local"):
-            v_array = v.get_local()
-            self._allReduce_array(v_array, op)
-            v.set_local(v_array)
-            v.apply("")
-            return v
-        elif hasattr(v, 'nvec'):
-            for i in range(v.nvec()):
-                self.allReduce(v[i], op)
-            return v
-        else:
-            msg = "TorchCollective.allReduce not implement for v of type {0}".format(type(v))
-            raise NotImplementedError(msg)
-
-    def bcast(self, v, root=0):
-        import torch
-        if type(v) in [float, np.float64, int, np.int32, np.int64]:
-            t = torch.tensor([float(v)], dtype=torch.float64, device=self._backend_device())
-            self.dist.broadcast(t, src=root, group=self.group)
-            return type(v)(t.item())
-        if type(v) is np.ndarray:
-            t = torch.from_numpy(np.ascontiguousarray(v)).to(self._backend_device())
-            self.dist.broadcast(t, src=root, group=self.group)
-            v[...] = t.cpu().numpy()
-            return v
-        elif isinstance(v, MultiVector):
-            return self._bcast_block(v, root)
-        elif isinstance(v, Vector):
-            self._bcast_block(v._mv, root)
-            return v
-        elif hasattr(v, "mpi_comm") and hasattr(v, "get_local"):
-            v_local = v.get_local()
-            self.bcast(v_local, root=root)
-            v.set_local(v_local)
-            v.apply("")
-            return v
-        elif hasattr(v, 'nvec'):
-            for i in range(v.nvec()):
-                self.bcast(v[i], root=root)
-            return v
-        else:
-            msg = "TorchCollective.bcast not implement for v of type {0}".format(type(v))
-            raise NotImplementedError(msg)
+        return self._block_collective(mv, lambda t: self.dist.broadcast(t, src=root, group=self.group))
 
 
-def MultipleSamePartitioningPDEsCollective(group=None, is_serial_check=False):
-    return TorchCollective(group, is_serial_check=is_serial_check)
+def MultipleSamePartitioningPDEsCollective(comm=None, is_serial_check=False):
+    """The reference's constructor name (collective.py:43).  ``comm``: None = the ranks of this launch
+    (``NativeCollective.from_env``), an existing collective (returned), or a torch.distributed group."""
+    if comm is None:
+        coll = NativeCollective.from_env()
+        coll.is_serial_check = is_serial_check
+        return coll
+    if isinstance(comm, (_Collective, NullCollective)):
+        return comm
+    return TorchCollective(comm, is_serial_check=is_serial_check)
 
 
-def MultipleSerialPDEsCollective(group=None):
-    return TorchCollective(group, is_serial_check=True)
+def MultipleSerialPDEsCollective(comm=None):
+    return MultipleSamePartitioningPDEsCollective(comm, is_serial_check=True)
 
 
 class CollectiveOperator:

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 
 #include "hfmi_internal.h"
@@ -189,9 +190,9 @@ static int block_alloc(hfmi_ctx* ctx, int64_t N, int nvec, hfmi_block** out) {
   b->p = nullptr;
   hipError_t e = hipMalloc((void**)&b->p, (size_t)b->ld * nvec * sizeof(double));
   if (e != hipSuccess) {
+    const double gb = (double)b->ld * nvec * 8 / 1e9;
     delete b;
-    HFMI_FAIL(HFMI_ERR_HIP, "hipMalloc of a %lld x %d block (%.2f GB) failed: %s", (long long)N, nvec,
-              (double)b->ld * nvec * 8 / 1e9, hipGetErrorString(e));
+    HFMI_FAIL(HFMI_ERR_HIP, "hipMalloc of a %lld x %d block (%.2f GB) failed: %s", (long long)N, nvec, gb, hipGetErrorString(e));
   }
   *out = b;
   return HFMI_OK;
@@ -628,6 +629,14 @@ extern "C" int hfmi_op_set_post_apply(hfmi_op* op, hfmi_post_apply_fn fn, void* 
   op->post_user = user;
   return HFMI_OK;
 }
+extern "C" int hfmi_op_set_collective(hfmi_op* op, hfmi_comm* comm, int reduce_op) {
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "null op");
+  if (comm && reduce_op != HFMI_REDUCE_SUM && reduce_op != HFMI_REDUCE_AVG)
+    HFMI_FAIL(HFMI_ERR_INVALID, "op_set_collective: reduce_op must be HFMI_REDUCE_SUM or HFMI_REDUCE_AVG");
+  op->comm = comm;
+  op->comm_op = reduce_op;
+  return HFMI_OK;
+}
 extern "C" int hfmi_op_destroy(hfmi_op* op) {
   if (!op) return HFMI_OK;
   if (op->gamma_inv) {
@@ -689,7 +698,10 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
         HFMI_TRY(read_back(ctx, rr_done, k, h_rr.data()));
         done = true;
         for (int j = 0; j < k; ++j)
-          if (h_rr[j] > op->rel_tol * op->rel_tol * h_bb[j]) done = false;
+          if (!(h_rr[j] <= op->rel_tol * op->rel_tol * h_bb[j])) done = false;
+        for (int j = 0; j < k; ++j)
+          if (!std::isfinite(h_rr[j]) || !std::isfinite(h_bb[j]))
+            HFMI_FAIL(HFMI_ERR_NUMERIC, "csr_pcg: non-finite residual in vector %d at iteration %d (matrix not SPD, or non-finite input)", j, it + 1);
       }
       continue;
     }
@@ -706,7 +718,10 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
       HFMI_TRY(read_back(ctx, rr, k, h_rr.data()));
       done = true;
       for (int j = 0; j < k; ++j)
-        if (h_rr[j] > op->rel_tol * op->rel_tol * h_bb[j]) done = false;
+        if (!(h_rr[j] <= op->rel_tol * op->rel_tol * h_bb[j])) done = false;
+      for (int j = 0; j < k; ++j)
+        if (!std::isfinite(h_rr[j]) || !std::isfinite(h_bb[j]))
+          HFMI_FAIL(HFMI_ERR_NUMERIC, "csr_pcg: non-finite residual in vector %d at iteration %d (matrix not SPD, or non-finite input)", j, it + 1);
     }
   }
   op->last_iters = it;
@@ -816,8 +831,9 @@ extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, in
   if (W->nvec != Y->nvec) HFMI_FAIL(HFMI_ERR_INVALID, "x and y have non-matching number of vectors (%d vs %d)", W->nvec, Y->nvec);
   if (W->p == Y->p) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: input and output blocks must not alias");
   HIP_TRY(hipSetDevice(op->ctx->device));
-  if (accumulate && op->post_fn) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: accumulate with a post-apply hook is ambiguous");
+  if (accumulate && (op->post_fn || op->comm)) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: accumulate with a rank reduction attached is ambiguous");
   HFMI_TRY(op_apply_raw(op, W, Y, accumulate ? 1.0 : 0.0));
+  if (op->comm) HFMI_TRY(comm_allreduce_device(op->comm, Y->p, Y->ld * (int64_t)Y->nvec, op->comm_op));
   if (op->post_fn) {
     const int rc = op->post_fn(op->post_user, Y);
     if (rc != 0) HFMI_FAIL(HFMI_ERR_CALLBACK, "post-apply hook returned %d", rc);
@@ -930,7 +946,8 @@ static int qr_mgs(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* R_host /* k
   }
   std::vector<double> R((size_t)k * k, 0.0), s(k);
   void* dv = nullptr;
-  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)(k + 16) * 16 * sizeof(double), &dv));
+  // its own slot: hfmi_op_apply(B, ...) inside the column loop may regrow WS_G (Gram-form / composed / PCG operators)
+  HFMI_TRY(ctx_ws(ctx, WS_MGS, (size_t)(k + 16) * 16 * sizeof(double), &dv));
   double* dsmall = (double*)dv;  // device scratch: coefficient column (ld 16) / scalars
   int total_sweeps = 0;
   for (int j = 0; j < k; ++j) {
@@ -1093,6 +1110,7 @@ static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T
     HFMI_TRY(launch_zero_pad(ctx, Gc2, m, k, ldm));
   }
   HFMI_TRY(launch_tsgemm_tn(ctx, Gc, ldm, k, Gc2, ldm, k, m, A->scale, 0.0, sm_ptr(ctx, slot_T), SM_LD, 1, 0));
+  if (A->comm) HFMI_TRY(comm_allreduce_device(A->comm, sm_ptr(ctx, slot_T), (int64_t)SM_LD * k, A->comm_op));
   if (A->post_fn) {
     hfmi_block t;
     t.ctx = ctx;

@@ -32,7 +32,7 @@ void hfmi_set_error(const char* fmt, ...);
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------ objects
-enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_NSLOTS };
+enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_MGS, WS_NSLOTS };
 
 struct hfmi_block {
   hfmi_ctx* ctx;
@@ -121,7 +121,11 @@ struct hfmi_op {
   int64_t host_N;
   hfmi_post_apply_fn post_fn;
   void* post_user;
+  hfmi_comm* comm;       // rank average / sum of the result block (hfmi_op_set_collective), null = none
+  int comm_op;
 };
+// in-place all-reduce of `count` doubles of device memory on the communicator's context stream (hfmi_comm.hip)
+int comm_allreduce_device(hfmi_comm* c, double* data, int64_t count, int op);
 
 // ------------------------------------------------------------------ kernel launchers (hfmi_gemm.hip)
 // C (m x k) = scale * A^T B (+ beta * C); A: N x m, B: N x k column-major blocks.

@@ -123,17 +123,27 @@ def _is_root():
 
 
 def _save(directory, name, array):
-    os.makedirs(directory, exist_ok=True)
-    np.save(os.path.join(directory, name), array)
+    """np.save(output_directory + name), the reference's convention (activeSubspaceProjector.py:475-480,
+    PODProjector.py:382-384, KLEProjector.py:190-192): ``output_directory`` is a PREFIX ('out/' or 'out/run1_')."""
+    parent = os.path.dirname(directory + name)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    np.save(directory + name, array)
 
 
 def _draw_omega(N, nvec, collective, ctx, stored=None):
-    """Probe block: every rank draws the same Philox stream (replaces rank-0 draw + bcast,
-    activeSubspaceProjector.py:433-443); a stored Omega (unit-test path) is broadcast from rank 0."""
+    """Probe block.  The reference draws on rank 0 and broadcasts k vectors of length N
+    (activeSubspaceProjector.py:433-443,536-551).  Here rank 0's generator state (seed, stream) -- 16 bytes -- is
+    what is broadcast; every rank then regenerates the same counter-based Philox block in its own HBM, whatever
+    its own generator had been used for before (per-rank sample draws, perturbations ...).  A stored Omega
+    (unit-test path) is broadcast from rank 0 as a block."""
     if stored is not None:
         Omega = MultiVector(stored)
         collective.bcast(Omega, root=0)
         return Omega
+    state = np.array([parRandom.seed & (2 ** 64 - 1), parRandom.stream & 0xFFFFFFFF], dtype=np.uint64)
+    state = collective.bcast(state, root=0)
+    parRandom.reseed(int(state[0]), int(state[1]))
     Omega = MultiVector(int(N), int(nvec), ctx=ctx)
     parRandom.normal(1., Omega)
     return Omega
@@ -369,8 +379,7 @@ class KLEProjector:
 
     def random_input_projector(self):
         """A random orthonormal projection basis (:114-128)."""
-        Omega = MultiVector(self.N, self.parameters['rank'] + self.parameters['oversampling'], ctx=self.ctx)
-        parRandom.normal(1., Omega)
+        Omega = _draw_omega(self.N, self.parameters['rank'] + self.parameters['oversampling'], self.collective, self.ctx)
         Omega.orthogonalize()
         return Omega
 

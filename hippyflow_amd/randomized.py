@@ -9,8 +9,9 @@ modeling/activeSubspaceProjector.py:449-463,556-577,654).
 
 Two execution routes, same arithmetic:
 * fused: when A (and B, Binv) are device operators -- possibly wrapped in a CollectiveOperator --
-  one call to ``hfmi_double_pass[_g]`` keeps every intermediate in HBM; the rank average is a
-  post-apply hook that all-reduces the result block in place (RCCL over xGMI);
+  one call to ``hfmi_double_pass[_g]`` keeps every intermediate in HBM; with a ``NativeCollective`` the rank
+  average is an RCCL all-reduce enqueued by the C solve itself (``hfmi_op_set_collective``), with any other
+  collective object it is a post-apply hook that all-reduces the result block in place;
 * generic: any object with the reference's ``mult`` / ``matMvMult`` protocol; the steps
   (MatMvMult, (B-)orthogonalize, dot_mv, small eigensolve, MvDSmatMult) are each a C-ABI call.
 """
@@ -19,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
+from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NativeCollective, NullCollective
 from .multivector import MatMvMult, MultiVector, MvDSmatMult, Vector
 from .operators import DeviceOperator, Solver2Operator, as_device_operator
 
@@ -110,7 +111,17 @@ def _fused(A_dev, collective, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs,
         else:
             L.call("hfmi_double_pass_g", A_dev._op, B_dev._op, Binv_dev._op, Omega.handle, int(k), int(s), flags, L.ptr(d), U.handle)
 
-    if collective is not None and not isinstance(collective, NullCollective):
+    if isinstance(collective, NativeCollective):
+        # the rank average runs inside the C solve on the context's stream (RCCL): no Python between the kernels
+        code = {"sum": L.REDUCE_SUM, "avg": L.REDUCE_AVG}.get(str(mpi_op).lower())
+        if code is None:
+            raise NotImplementedError("reduction %r is not available (use 'sum' or 'avg')" % (mpi_op,))
+        L.call("hfmi_op_set_collective", A_dev._op, collective._comm, code)
+        try:
+            run()
+        finally:
+            L.call("hfmi_op_set_collective", A_dev._op, None, 0)
+    elif collective is not None and not isinstance(collective, NullCollective):
         hook = _PostApplyHook(A_dev, collective, mpi_op)
         with hook:
             try:

@@ -41,7 +41,8 @@ typedef enum {
   HFMI_ERR_NO_DEVICE = -3,    /* no usable gfx950 device */
   HFMI_ERR_NUMERIC = -4,      /* breakdown (e.g. Gram matrix not SPD after shifting) */
   HFMI_ERR_CALLBACK = -5,     /* a host callback operator returned non-zero */
-  HFMI_ERR_NOT_CONVERGED = -6 /* iterative kernel hit its iteration cap */
+  HFMI_ERR_NOT_CONVERGED = -6,/* iterative kernel hit its iteration cap */
+  HFMI_ERR_COMM = -7          /* communicator failure (RCCL error, peer rank missing, time-out) */
 } hfmi_status;
 
 /* host <-> block layouts */
@@ -52,6 +53,7 @@ typedef struct hfmi_ctx hfmi_ctx;
 typedef struct hfmi_block hfmi_block;
 typedef struct hfmi_csr hfmi_csr;
 typedef struct hfmi_op hfmi_op;
+typedef struct hfmi_comm hfmi_comm;
 
 /* ---------------------------------------------------------------- context */
 const char* hfmi_last_error(void);
@@ -142,8 +144,42 @@ int hfmi_op_host_callback(hfmi_ctx* ctx, hfmi_host_apply_fn fn, void* user, int6
  *     post-apply hook called with the result block, e.g. an RCCL all-reduce. */
 typedef int (*hfmi_post_apply_fn)(void* user, hfmi_block* Y);
 int hfmi_op_set_post_apply(hfmi_op* op, hfmi_post_apply_fn fn, void* user);
+/*     the same average done natively: the result block of every apply (and the k x k Rayleigh quotient of the
+ *     Gram-form solves) is all-reduced over `comm` on the context's stream, no host code inside the solve.
+ *     reduce_op HFMI_REDUCE_SUM | HFMI_REDUCE_AVG; comm NULL detaches. */
+int hfmi_op_set_collective(hfmi_op* op, hfmi_comm* comm, int reduce_op);
 int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, int accumulate);
 int hfmi_op_destroy(hfmi_op* op);
+
+/* ---------------------------------------------------------------- communicator
+ * The reference's sample-parallel collective (hippyflow/collectives/collective.py): one process per GPU.
+ *   _allReduce_array, collective.py:61-71          -> hfmi_allreduce_host
+ *   allReduce of a MultiVector, :98-111 (k Allreduce calls of length N, through host copies)
+ *                                                   -> hfmi_allreduce: ONE RCCL all-reduce of the N x k block in
+ *                                                      HBM on the context's stream, 1/P of 'avg' fused (ncclAvg)
+ *   bcast of a MultiVector, :144-152 (k Bcast calls) -> hfmi_bcast
+ *   comm.Get_size / Get_rank, :52-58                -> hfmi_comm_info
+ * Bootstrap: rank 0 calls hfmi_comm_unique_id and ships the HFMI_UNIQUE_ID_BYTES bytes to the other ranks (any
+ * channel: mpi4py bcast, a file -- hfmi_comm_init_from_file does the file exchange itself); every rank then calls
+ * hfmi_comm_init_rank with its own context.  Transports (hfmi_comm_info): 1 = RCCL over xGMI (each rank its own
+ * GPU), 2 = direct peer access through HIP IPC staging buffers (ranks sharing a GPU, or HFMI_COMM_TRANSPORT=p2p),
+ * 0 = host-only (ctx NULL on every rank: host payloads and barriers only).  Ranks of one communicator live on one
+ * node unless HFMI_COMM_TRANSPORT=rccl.  A peer that never arrives fails the call after HFMI_COMM_TIMEOUT_S
+ * (300 s) with HFMI_ERR_COMM instead of hanging. */
+#define HFMI_UNIQUE_ID_BYTES 256
+#define HFMI_REDUCE_SUM 0
+#define HFMI_REDUCE_AVG 1
+#define HFMI_REDUCE_MAX 2
+int hfmi_comm_unique_id(void* id_out);
+int hfmi_comm_init_rank(hfmi_ctx* ctx_or_null, const void* id, int nranks, int rank, hfmi_comm** out);
+int hfmi_comm_init_from_file(hfmi_ctx* ctx_or_null, const char* path, int nranks, int rank, hfmi_comm** out);
+int hfmi_comm_info(const hfmi_comm* comm, int* nranks, int* rank, int* transport);
+int hfmi_comm_barrier(hfmi_comm* comm);               /* drains the context's stream, then meets the other ranks */
+int hfmi_allreduce(hfmi_comm* comm, hfmi_block* Y, int reduce_op);           /* in place, stream-ordered */
+int hfmi_bcast(hfmi_comm* comm, hfmi_block* Y, int root);
+int hfmi_allreduce_host(hfmi_comm* comm, double* v, int64_t count, int reduce_op);   /* in place */
+int hfmi_bcast_host(hfmi_comm* comm, void* v, int64_t nbytes, int root);
+int hfmi_comm_destroy(hfmi_comm* comm);
 
 /* ---------------------------------------------------------------- QR (a7)
  * MultiVector.orthogonalize() / Borthogonalize(B): thin QR with Q^T B Q = I,

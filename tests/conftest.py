@@ -12,6 +12,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU-marked tests are skipped, not failed, on a box without a GPU (the device count is read through libhfmi)."""
+    if not any("gpu" in item.keywords for item in items):
+        return
+    try:
+        import hippyflow_amd
+        have_gpu = hippyflow_amd.device_count() > 0
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible (libhfmi has no CPU path)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

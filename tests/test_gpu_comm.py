@@ -1,0 +1,66 @@
+"""GPU tests of the native communicator (include/hfmi.h "communicator"): RCCL transport with a one-rank group
+(all a one-GPU box can offer: RCCL refuses two ranks on one device) and the p2p transport with 2 and 4 ranks sharing
+the GPU, both through the same C entry points the multi-GPU run uses."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "helpers", "gpu_comm_worker.py")
+
+
+def test_one_rank_rccl_communicator_is_bit_transparent():
+    import hippyflow_amd as hf
+    from hippyflow_amd import workloads
+    coll = hf.NativeCollective.from_unique_id(hf.NativeCollective.unique_id(), 1, 0)
+    assert coll.size() == 1 and coll.rank() == 0 and coll.transport == "rccl"
+    X = hf.MultiVector(7001, 9)
+    hf.parRandom.reseed(3)
+    hf.parRandom.normal(1.0, X)
+    ref = X.to_dense()
+    for op in ("sum", "avg"):
+        assert coll.allReduce(X, op) is X
+        np.testing.assert_array_equal(X.to_dense(), ref)             # ncclAllReduce over one rank: the same bits
+    coll.bcast(X, root=0)
+    np.testing.assert_array_equal(X.to_dense(), ref)
+    assert coll.allReduce(2.0, "avg") == 2.0 and coll.allReduceMax(3.5) == 3.5
+    arr = np.arange(5.0)
+    assert coll.allReduce(arr, "sum") is arr
+    coll.barrier()
+    # the fused solve with the all-reduce enqueued natively == the solve without a collective, bit for bit
+    wl = workloads.as_workload(4001, 6, q=5, latent=5, rate=0.3, seed=4)
+    Omega = hf.MultiVector(4001, 8)
+    hf.parRandom.normal(1.0, Omega)
+    for kw in ({}, {"literal_T": True}):
+        d0, U0 = hf.doublePass(wl.operator, Omega, 5, s=1, **kw)
+        d1, U1 = hf.doublePass(hf.CollectiveOperator(wl.operator, coll, mpi_op="avg"), Omega, 5, s=1, **kw)
+        np.testing.assert_array_equal(d0, d1)
+        np.testing.assert_array_equal(U0.to_dense(), U1.to_dense())
+    with pytest.raises(NotImplementedError):
+        hf.doublePass(hf.CollectiveOperator(wl.operator, coll, mpi_op="max"), Omega, 5, s=1)
+    coll.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharing_the_gpu_p2p_transport(tmp_path, world):
+    from hippyflow_amd.launch import spawn_ranks
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="120")
+    assert spawn_ranks([WORKER, str(tmp_path)], world, env=env, timeout=600) == 0
+    rs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for rank, r in enumerate(rs):
+        assert int(r["size"]) == world and int(r["rank"]) == rank
+        assert str(r["transport"]) in ("p2p", "rccl")                 # rccl only where every rank has its own GPU
+        assert float(r["sum_err"]) == 0.0                             # same summation order as the expectation
+        assert float(r["avg_err"]) < 1e-15 and float(r["bcast_err"]) == 0.0 and float(r["vector_err"]) < 1e-14
+        assert float(r["big_err"]) < 1e-15
+        assert float(r["host_sum"]) == world * (world + 1) / 2
+        np.testing.assert_array_equal(r["avg_block"], rs[0]["avg_block"])
+        for name in ("gram", "literal"):
+            np.testing.assert_array_equal(r["d_" + name], rs[0]["d_" + name])      # every rank holds the same result
+            np.testing.assert_array_equal(r["U_" + name], rs[0]["U_" + name])
+            np.testing.assert_allclose(r["d_" + name], rs[0]["d_all"], rtol=1e-11)  # == one rank over all samples
+        np.testing.assert_allclose(r["d_unfused"], rs[0]["d_all"], rtol=1e-11)
+    sgn = np.sign(np.sum(rs[0]["U_gram"] * rs[0]["U_all"], axis=0))
+    np.testing.assert_allclose(rs[0]["U_gram"] * sgn, rs[0]["U_all"], atol=1e-9)
