@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: randomized double-pass eigensolve throughput (GDoF*rank/s) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload as|pod|kle] [--quick]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload as|pod|kle] [--prior] [--quick]
 
 One "step" = one full double pass (Omega already in HBM -> eigenvalues on the host, eigenvectors in
 HBM) over one synthetic workload whose operator data is resident in HBM.  The default workload is
-BASELINE config 4 (ActiveSubspaceProjector: 512 Monte-Carlo Jacobian samples of 100 x 2e5, r=64, p=10):
-it is the configuration the metric's "1/2/4/8 GPU" clause is quoted on, it fits one GPU at N=1 (82 GB of
-Jacobians in 288 GB of HBM) and it is the one path with a real exchange step, so the SAME total work is
-timed at every N (strong scaling): the samples are sharded 512/N per rank and the block J^T J Omega is
-all-reduced (RCCL over xGMI) once per operator application.
+BASELINE config 4 (ActiveSubspaceProjector: 512 Monte-Carlo Jacobian samples of 100 x 2e5, r=64, p=10,
+J_i = A_i P^T + 0.01 E_i as SURVEY.md section 8d specifies): it is the configuration the metric's "1/2/4/8 GPU"
+clause is quoted on, it fits one GPU at N=1 (82 GB of Jacobians in 288 GB of HBM) and it is the one path with a
+real exchange step, so the SAME total work is timed at every N (strong scaling): the samples are sharded 512/N
+per rank and the block J^T J Omega is all-reduced (RCCL over xGMI) once per operator application.
+``--prior`` runs the reference's DEFAULT form of that solve (construct_input_subspace(prior_preconditioned=True),
+activeSubspaceProjector.py:447-453): doublePassG with B = prior.R (CSR on the device) and B^-1 = prior.Rsolver,
+a HOST sparse-LU black box reached through the pinned, pipelined callback path.
 
 N > 1 runs one rank per GPU over the native communicator of libhfmi (RCCL over xGMI; no torch in this file).  Either
 launch works: plain ``python bench.py --gpus N`` (this process then only spawns the N ranks and touches no GPU), or
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE from
 the environment).  Rank 0 prints ONE JSON line.
+
+Parity (``parity`` in the JSON): the CPU oracle (oracle/) runs the same algorithm on the SAME inputs -- the operator
+data is streamed from HBM to the host in slabs and applied densely there (no knowledge of how it was generated).
 """
 import argparse
 import json
@@ -38,9 +44,14 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="as", choices=["as", "pod", "kle"])
+    ap.add_argument("--prior", action="store_true",
+                    help="config 4, prior-preconditioned (the reference's default): doublePassG with B = R = A M_l^-1 A as CSR "
+                         "on the device and B^-1 = a host sparse-LU callback")
+    ap.add_argument("--noise", type=float, default=0.01, help="config 4: J_i = A_i P^T + noise * E_i (SURVEY 8d: 0.01; 0 = exactly rank 100)")
     ap.add_argument("--quick", action="store_true", help="1/8-size problem (smoke / profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-literal", action="store_true", help="skip the extra literal-T steps after the timed region")
     ap.add_argument("--samples-total", type=int, default=512,
                     help="config 4 only: total Monte-Carlo samples (512 = BASELINE; 64 on one GPU reproduces the per-GPU "
                          "share of the 8-GPU run, for estimating the non-scaling part)")
@@ -53,19 +64,34 @@ def parse_args():
     return ap.parse_args()
 
 
+AS_RATE, AS_SEED = 0.06, 4
+
+
 def build_workload(args, hf, rank, world):
     from hippyflow_amd import workloads
     scale = 8 if args.quick else 1
+    prior = None
     if args.workload == "as":
-        N, ns_total, q, r, p = 200000 // scale, args.samples_total, 100, 64, 10
+        nx, ny = 500, 400 // scale
+        N, ns_total, q, r, p = nx * ny, args.samples_total, 100, 64, 10
         assert ns_total % world == 0
         ns_local = ns_total // world
-        wl = workloads.as_workload(N, ns_local, q=q, latent=q, rate=0.06, seed=4, first_sample=rank * ns_local, ns_total=ns_total)
-        desc = {"workload": "config4 ActiveSubspaceProjector: mean J^T J, %d samples x (%d x %d), r=%d, p=%d" % (ns_total, q, N, r, p),
+        wl = workloads.as_workload(N, ns_local, q=q, latent=q, rate=AS_RATE, seed=AS_SEED, first_sample=rank * ns_local,
+                                   ns_total=ns_total, noise=args.noise)
+        desc = {"workload": "config4 ActiveSubspaceProjector%s: mean J^T J, %d samples x (%d x %d), J_i = A_i P^T + %g E_i, r=%d, p=%d"
+                            % (" (prior-preconditioned, doublePassG)" if args.prior else "", ns_total, q, N, args.noise, r, p),
                 "N": N, "samples_total": ns_total, "samples_per_gpu": ns_local, "outputs": q, "rank": r, "oversampling": p,
+                "noise": args.noise,
                 "parallelism": "sample-parallel x%d, one all-reduce(avg) of the N x k block per operator application" % world}
         op = wl.operator
         B = Binv = None
+        if args.prior:
+            prior = workloads.BiLaplacianPrior(nx, ny, delta=1.0, gamma=0.1)
+            B = hf.CsrOperator(prior.R)
+            Binv = hf.HostCallbackOperator(prior.Rsolver, N)
+            desc.update({"B": "R = A M_l^-1 A, A = M + 0.1 K on a %d x %d P1 grid: CSR on the device, %.1f nnz/row" % (nx, ny, prior.R.nnz / N),
+                         "Binv": "host sparse LU of A (SuperLU), two triangular sweeps per vector on %d host threads, slabs of %d vectors "
+                                 "through pinned double buffers" % (prior.Rsolver.threads, Binv.chunk_vectors)})
     elif args.workload == "pod":
         N, n, r, p = 500000 // scale, 2048, 128, 10
         assert n % world == 0
@@ -76,81 +102,223 @@ def build_workload(args, hf, rank, world):
         op = wl.operator
         B = Binv = None
     else:
-        nx, ny, r, p = 400, 250 // scale, 64, 20
-        wl = workloads.kle_workload(nx, ny, latent=256, rate=0.08, seed=2)
-        N = wl.N
         if world > 1:
             raise SystemExit("kle workload: replicas only (KLEProjector.py:148-149); run at --gpus 1")
-        desc = {"workload": "config2 KLEProjector(mass): dense covariance N=%d, r=%d, p=%d" % (N, r, p), "N": N, "rank": r,
-                "oversampling": p, "parallelism": "single GPU"}
+        nx, ny, N, r, p = 316, 317, 100000 // (scale * scale), 64, 20
+        wl = workloads.kle_matern_workload(nx, ny, N=N, sigma=1.0, ell=0.1)
+        desc = {"workload": "config2 KLEProjector(mass): dense Matern-3/2 covariance (sigma=1, ell=0.1) on N=%d nodes of a %d x %d grid, r=%d, p=%d"
+                            % (N, nx, ny, r, p), "N": N, "rank": r, "oversampling": p, "parallelism": "single GPU"}
         op = hf.MassPreconditionedCovarianceOperator(wl.C_operator, wl.M_operator)
         B = wl.M_operator
         Binv = hf.CsrPCGSolver(wl.M_operator.csr)
-    return wl, op, B, Binv, N, r, p, desc
+    return wl, op, B, Binv, prior, N, r, p, desc
 
 
-def host_reference(args, wl, Omega_host, r, hf_o, hp_o):
-    """The oracle on the SAME inputs, evaluated in factored form on the host (see workloads.py)."""
+# ---------------------------------------------------------------------------------------------- host side (oracle legs)
+def _stream_rows(block, rows_per):
+    """Slabs (first, count, host array (count, N)) of a device block, one vector per row."""
+    n = block.nvec()
+    for first in range(0, n, rows_per):
+        cnt = min(rows_per, n - first)
+        yield first, cnt, block.view(first, cnt).to_vectors()
+
+
+def dense_streaming_operator(args, hf, wl, world):
+    """apply_A(W) on the host from the operator DATA: slabs of the device-resident Jacobians / snapshots / covariance
+    rows are copied to the host and contracted there (BLAS-3).  With several ranks, rank 0 regenerates the other ranks'
+    shards slab by slab on its own GPU (the generator is keyed by the global sample index)."""
     from hippyflow_amd import workloads
     if args.workload == "as":
-        P = wl.P.to_dense()
-        H = workloads.as_reduced_matrix(4, wl.ns_total, wl.q, wl.latent, 0.06)   # all samples of all ranks
-        apply_A = lambda W: np.asfortranarray(P @ (H @ (P.T @ W)))
-        return hp_o.double_pass_blas3(apply_A, Omega_host, r)
+        q, ns_total = wl.q, wl.ns_total
+        per = 32                                            # samples per slab: 32 x 100 x 2e5 doubles = 5.1 GB
+
+        def slabs():
+            if world == 1:
+                for _, cnt, Jh in _stream_rows(wl.J, per * q):
+                    yield Jh
+            else:
+                for first in range(0, ns_total, per):
+                    cnt = min(per, ns_total - first)
+                    part = workloads.as_workload(wl.N, cnt, q=q, latent=wl.latent, rate=AS_RATE, seed=AS_SEED, first_sample=first,
+                                                 ns_total=ns_total, noise=wl.noise, P=wl.P)
+                    yield part.J.to_vectors()
+
+        def apply_A(W):
+            Y = np.zeros((wl.N, W.shape[1]))
+            for Jh in slabs():
+                Y += Jh.T @ (Jh @ W)
+            return np.asfortranarray(Y / ns_total)
+        return apply_A
     if args.workload == "pod":
-        apply_A = workloads.pod_host_apply(wl, wl.W0.to_dense())
-        return hp_o.double_pass_blas3(apply_A, Omega_host, r)
-    import scipy.sparse.linalg as spla
-    F, lam, M = wl.F_host, wl.lam, wl.M
-    lu = spla.splu(M.tocsc())
-    apply_A = lambda W: np.asfortranarray(M @ (F @ (lam[:, None] * (F.T @ (M @ W)))))
-    return hp_o.double_pass_blas3(apply_A, Omega_host, r, apply_B=lambda W: M @ W, apply_Binv=lambda W: np.asfortranarray(lu.solve(np.ascontiguousarray(W))))
+        assert world == 1 or True
+        n = wl.n
+
+        def slabs():
+            if world == 1:
+                for _, cnt, Xh in _stream_rows(wl.X, 512):
+                    yield Xh
+            else:
+                for first in range(0, n, 512):
+                    part = workloads.pod_workload(wl.N, n, latent=256, rate=0.05, seed=3, first_snapshot=first, n_local=min(512, n - first))
+                    yield part.X.to_vectors()
+
+        def apply_A(W):
+            Y = np.zeros((wl.N, W.shape[1]))
+            for Xh in slabs():
+                Y += Xh.T @ (Xh @ W)
+            return np.asfortranarray(Y / n)
+        return apply_A
+    M = wl.M
+
+    def apply_A(W):                                          # M C M, the covariance streamed by rows (C is symmetric)
+        MW = M @ W
+        CMW = np.empty_like(MW)
+        for first, cnt, Ch in _stream_rows(wl.C, 4000):
+            CMW[first:first + cnt] = Ch @ MW
+        return np.asfortranarray(M @ CMW)
+    return apply_A
 
 
-def cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o):
-    """CPU port of the reference path (BLAS-3 "best-effort" form) on a bounded sample."""
+def host_reference(args, hf, wl, prior, world, Omega_host, r, hp_o):
+    apply_A = dense_streaming_operator(args, hf, wl, world)
+    if args.workload == "kle":
+        import scipy.sparse.linalg as spla
+        lu = spla.splu(wl.M.tocsc())
+        return hp_o.double_pass_blas3(apply_A, Omega_host, r, apply_B=lambda W: wl.M @ W,
+                                      apply_Binv=lambda W: np.asfortranarray(lu.solve(np.ascontiguousarray(W)))), (lambda W: wl.M @ W)
+    if prior is not None:
+        return hp_o.double_pass_blas3(apply_A, Omega_host, r, apply_B=lambda W: prior.R @ W,
+                                      apply_Binv=lambda W: np.asfortranarray(prior.Rsolver.solve_block(W))), (lambda W: prior.R @ W)
+    return hp_o.double_pass_blas3(apply_A, Omega_host, r), None
+
+
+def _timed(fn, *a):
+    t0 = time.perf_counter()
+    out = fn(*a)
+    return out, time.perf_counter() - t0
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
+    """The reference's CPU path on the GPU box's host cores, on bounded samples scaled to the full workload (every
+    scaling factor is stated).  Two legs, each at all threads and at one thread:
+      reference_style -- what hippylib executes for hippyflow's operators: the operator applied one Omega column at a
+                         time (MatMvMult's fallback loop, collectiveOperator.py:31-38, over the in-tree numpy statement
+                         MeanJTJfromDataOperator.mult / LowRankOperator), column-by-column MGS with re-orthogonalisation,
+                         numpy eigh, MvDSmatMult;
+      blas3           -- the best-effort CPU form: block applies as threaded GEMMs, Householder QR."""
+    from threadpoolctl import threadpool_limits
     cores = os.cpu_count() or 1
     k = Omega_host.shape[1]
-    if args.workload == "as":
-        ns_s = 16
-        Jh = wl.J.view(0, ns_s * wl.q).to_vectors().reshape(ns_s, wl.q, N)     # dense Jacobians of the sample
-        W = Omega_host
-        t0 = time.perf_counter()
-        Y = hf_o.mean_jtj_block_blas3(Jh, W)
-        t_apply = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        Q, _ = hp_o._qr_posdiag(Y)
-        T = Y.T @ Q
-        np.linalg.eigh(0.5 * (T + T.T))
-        U = Q @ T[:, :r]
-        t_rest = time.perf_counter() - t0
-        t_full = 2.0 * t_apply * (wl.ns_total / ns_s) + t_rest
-        sample = "dense BLAS-3 mean-JtJ apply timed on %d of %d samples (full N=%d, k=%d) and scaled linearly in samples, + QR/Rayleigh-Ritz at full size" % (ns_s, wl.ns_total, N, k)
-    elif args.workload == "pod":
-        n_s = 256
-        Xh = wl.X.view(0, n_s).to_vectors()
-        t0 = time.perf_counter()
-        Y = hf_o.snapshot_gram_block(Xh, Omega_host)
-        t_apply = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        Q, _ = hp_o._qr_posdiag(Y)
-        T = Y.T @ Q
-        np.linalg.eigh(0.5 * (T + T.T))
-        t_rest = time.perf_counter() - t0
-        t_full = 2.0 * t_apply * (wl.n / n_s) + t_rest
-        sample = "BLAS-3 snapshot-Gram apply timed on %d of %d snapshots and scaled linearly, + QR/Rayleigh-Ritz at full size" % (n_s, wl.n)
-    else:
-        rows = 4000
-        Ch = wl.C.view(0, rows).to_vectors()
-        t0 = time.perf_counter()
-        _ = Ch @ Omega_host
-        t_apply = time.perf_counter() - t0
-        t_full = 2.0 * t_apply * (N / rows)
-        sample = "dense C*Omega timed on %d of %d rows and scaled linearly (sparse M, M^-1 and QR not included)" % (rows, N)
-    return {"value": N * r / t_full / 1e9, "unit": "GDoF*rank/s", "cores": cores, "kind": "port", "sample": sample,
-            "seconds_full_estimate": t_full}
+    legs = {"reference_style": {}, "blas3": {}}
+    notes = {}
+    for label, limit in (("threads_all", cores), ("threads_1", 1)):
+        with threadpool_limits(limits=limit):
+            # ------------------------------------------------------------ reference-style leg, on a reduced problem
+            N_s = max(1000, N // 8)
+            k_s = 4
+            W_s = np.ascontiguousarray(Omega_host[:N_s, :k_s])
+            Z = hp_o.as_block(Omega_host[:N_s])
+            if args.workload == "as":
+                ns_s = 4
+                J_s = wl.J.view(0, ns_s * wl.q).to_vectors()[:, :N_s].reshape(ns_s, wl.q, N_s).copy()
+                op = hf_o.MeanJTJOperator(J_s)
+                units, units_s = wl.ns_total, ns_s
+            elif args.workload == "pod":
+                n_s = 64
+                X_s = wl.X.view(0, n_s).to_vectors()[:, :N_s].copy()
+                op = hf_o.SnapshotGramOperator(X_s)
+                units, units_s = wl.n, n_s
+            else:
+                rows_s = 500
+                C_s = wl.C.view(0, rows_s).to_vectors()[:, :N_s].copy()
+
+                class _Rows:                       # rows_s rows of y = C x per call (dense mat-vec, as npToDolfinOperator.mult)
+                    def mult(self, x, y):
+                        y[:rows_s] = C_s @ x
+                op = _Rows()
+                units, units_s = N, rows_s
+            y = np.zeros(N_s)
+
+            def ref_apply():
+                for j in range(k_s):
+                    op.mult(W_s[:, j], y)
+            _, t_apply = _timed(ref_apply)
+            _, t_mgs = _timed(hp_o.mgs_reortho, Z)
+            T = Z.T @ Z
+            _, t_eig = _timed(np.linalg.eigh, T)
+            U_s = hp_o.new_block(N_s, r)
+            _, t_back = _timed(hp_o.mv_ds_mat_mult, Z, np.ascontiguousarray(T[:, :r]), U_s)
+            fN = N / N_s
+            full_apply = t_apply * (k / k_s) * (units / units_s) * (fN if args.workload != "kle" else fN)
+            t_ref = 2.0 * full_apply + (t_mgs + t_back) * fN + t_eig
+            legs["reference_style"][label] = {"seconds_full_estimate": t_ref, "value": N * r / t_ref / 1e9,
+                                              "measured_seconds": {"apply": t_apply, "mgs_reortho": t_mgs, "eigh": t_eig, "MvDSmatMult": t_back}}
+            notes["reference_style"] = ("operator applied to %d of %d Omega columns on %d of %d %s at N/%d = %d rows, scaled linearly in "
+                                        "columns, %s and N, x2 applications; MGS with re-orthogonalisation and MvDSmatMult at N/%d scaled "
+                                        "linearly in N; eigh at full k=%d%s"
+                                        % (k_s, k, units_s, units, {"as": "samples", "pod": "snapshots", "kle": "covariance rows"}[args.workload],
+                                           N // N_s, N_s, {"as": "samples", "pod": "snapshots", "kle": "rows"}[args.workload], N // N_s, k,
+                                           "; B / B^-1 applications not included" if (prior is not None or args.workload == "kle") else ""))
+            # ------------------------------------------------------------ BLAS-3 leg, full N, bounded operator sample
+            if args.workload == "as":
+                ns_b = 16
+                Jh = wl.J.view(0, ns_b * wl.q).to_vectors()
+                _, t_apply = _timed(lambda: Jh.T @ (Jh @ Omega_host))
+                t_apply *= wl.ns_total / ns_b
+                note_b = "mean-JtJ apply as two GEMMs on %d of %d samples at full N=%d, k=%d, scaled linearly in samples, x2" % (ns_b, wl.ns_total, N, k)
+            elif args.workload == "pod":
+                n_b = 256
+                Xh = wl.X.view(0, n_b).to_vectors()
+                _, t_apply = _timed(lambda: Xh.T @ (Xh @ Omega_host))
+                t_apply *= wl.n / n_b
+                note_b = "snapshot-Gram apply as two GEMMs on %d of %d snapshots at full N, scaled linearly, x2" % (n_b, wl.n)
+            else:
+                rows_b = 4000
+                Ch = wl.C.view(0, rows_b).to_vectors()
+                _, t_c = _timed(lambda: Ch @ Omega_host)
+                _, t_m = _timed(lambda: wl.M @ Omega_host)
+                t_apply = t_c * (N / rows_b) + 2.0 * t_m
+                note_b = "M C M apply: dense C rows GEMM on %d of %d rows scaled linearly + 2 sparse M products, x2" % (rows_b, N)
+            extra = 0.0
+            if args.workload == "kle":
+                import scipy.sparse.linalg as spla
+                lu, t_fac = _timed(lambda: spla.splu(wl.M.tocsc()))
+                _, t_sol = _timed(lambda: lu.solve(np.ascontiguousarray(Omega_host)))
+                _, t_bq = _timed(lambda: hp_o._borth_blas3(Omega_host.copy(order="F"), lambda W: wl.M @ W))
+                extra = t_fac + t_sol + t_bq
+                note_b += "; + splu(M) factorisation, one block solve and the M-orthogonal QR (Householder + 2 Cholesky-QR rounds) at full size"
+            elif prior is not None:
+                _, t_sol = _timed(lambda: prior.Rsolver.solve_block(Omega_host))
+                _, t_bq = _timed(lambda: hp_o._borth_blas3(Omega_host.copy(order="F"), lambda W: prior.R @ W))
+                extra = t_sol + t_bq
+                note_b += "; + one R^-1 block solve (factorisation of A not counted: the prior owns it) and the R-orthogonal QR at full size"
+            else:
+                _, extra = _timed(lambda: hp_o._qr_posdiag(Omega_host))
+                note_b += "; + Householder QR at full size"
+            T = Omega_host[:k].T @ Omega_host[:k]
+            _, t_eig = _timed(np.linalg.eigh, T)
+            _, t_back = _timed(lambda: Omega_host @ T[:, :r])
+            t_b = 2.0 * t_apply + extra + t_eig + t_back
+            legs["blas3"][label] = {"seconds_full_estimate": t_b, "value": N * r / t_b / 1e9}
+            notes["blas3"] = note_b + "; eigh and U = Q V at full size"
+    best = legs["blas3"]["threads_all"]
+    return {"value": best["value"], "unit": "GDoF*rank/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": "blas3 leg at all threads: " + notes["blas3"], "seconds_full_estimate": best["seconds_full_estimate"],
+            "reference_style": dict(legs["reference_style"], sample=notes["reference_style"]),
+            "blas3": dict(legs["blas3"], sample=notes["blas3"])}
 
 
+# ---------------------------------------------------------------------------------------------- the benchmark
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -168,6 +336,8 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.transport != "auto":
         os.environ["HFMI_COMM_TRANSPORT"] = args.transport
+    if args.prior and args.workload != "as":
+        raise SystemExit("--prior belongs to the config-4 workload (--workload as)")
 
     import hippyflow_amd as hf
     if hf.device_count() < 1:
@@ -181,17 +351,17 @@ def main():
     else:
         collective = hf.NullCollective()
 
-    wl, op, B, Binv, N, r, p, desc = build_workload(args, hf, rank, world)
+    wl, op, B, Binv, prior, N, r, p, desc = build_workload(args, hf, rank, world)
     k = r + p
     A = hf.CollectiveOperator(op, collective, mpi_op="avg") if use_dist else op
     hf.parRandom.reseed(1)
     Omega = hf.MultiVector(N, k)
     hf.parRandom.normal(1.0, Omega)          # identical on every rank (counter-based RNG): no broadcast
 
-    def step():
+    def step(**kw):
         if B is None:
-            return hf.doublePass(A, Omega, r, s=1)
-        return hf.doublePassG(A, B, Binv, Omega, r, s=1)
+            return hf.doublePass(A, Omega, r, s=1, **kw)
+        return hf.doublePassG(A, B, Binv, Omega, r, s=1, **kw)
 
     def barrier():
         collective.barrier()                         # drains this rank's stream, then meets the other ranks
@@ -207,22 +377,40 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
+    phases = ctx.profile_phases()
     if use_dist:
         elapsed = collective.allReduceMax(elapsed)   # the slowest rank's clock
+    # the same solve with T = (A Q)^T Q formed literally, as the reference does (4 long contractions instead of 3):
+    # reported next to the headline number, never part of it
+    literal_ms = None
+    if not args.no_literal and B is None:
+        nl = max(1, min(3, args.steps))
+        step(literal_T=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nl):
+            step(literal_T=True)
+        barrier()
+        literal_ms = (time.perf_counter() - t0) / nl * 1e3
+        if use_dist:
+            literal_ms = collective.allReduceMax(literal_ms)
     comm_info = {"ranks": collective.size(), "transport": getattr(collective, "transport", "none"),
                  "launcher": os.environ.get("HFMI_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none")}
-    if rank != 0:
-        collective.barrier()
-        if use_dist:
-            collective.close()
+    if use_dist:
+        collective.close()                           # collective: every rank leaves the communicator here;
+    if rank != 0:                                    # rank 0 goes on alone with the oracle legs
         return
 
     ms_per_step = elapsed / args.steps * 1e3
     value = N * r / (elapsed / args.steps) / 1e9
     out = {"metric": "randomized-SVD throughput (GDoF*rank/s)", "value": value, "unit": "GDoF*rank/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (seeded latent-factor model, generated in HBM)",
-           "config": desc, "communicator": comm_info}
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic (seeded, generated in HBM: SURVEY.md section 8d recipes)",
+           "config": desc, "communicator": comm_info, "build_tag": hf.build_tag()}
+    if literal_ms is not None:
+        out["literal_T_ms_per_step"] = literal_ms
+    out["phases_ms_per_step"] = {name: ms / args.steps for name, ms in phases.items()}
 
     # roofline of the dominant kernel (= the (kernel, shape) group with the largest total time), from per-launch
     # HIP events recorded inside the timed region on the stream the kernels run on
@@ -248,16 +436,20 @@ def main():
                                 "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                                 "fp64_mfma_frac": tflops / FP64_MFMA_PEAK_TFLOPS})
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
-        # correction + WRITE_SIZE; profiles/pmc_traffic.json) -- bench.py cannot run the profiler on itself
+        # correction + WRITE_SIZE; profiles/pmc_traffic.json) -- bench.py cannot run the profiler on itself.  The
+        # record is used only if it was measured on THIS build of the kernels.
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             rec = tr["kernels"].get(out["roofline"]["kernel"])
-            if rec:
+            if rec and tr.get("build_tag") == hf.build_tag():
                 out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr["source"]
                 out["roofline"]["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / pk["bytes_per_launch"]
                 out["roofline"]["pmc_mfma_pipe_util"] = rec.get("mfma_pipe_util")
                 out["roofline"]["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
+            elif rec:
+                out["roofline"]["traffic_note"] = ("profiles/pmc_traffic.json was measured on build %s, this is build %s: record not used"
+                                                   % (tr.get("build_tag"), hf.build_tag()))
         except (OSError, ValueError, KeyError):
             pass
         mfma_ms = sum(g["ms"] for g in prof) / args.steps
@@ -276,25 +468,24 @@ def main():
     Omega_host = np.asfortranarray(Omega.to_dense())
     if not args.no_check:
         t0 = time.perf_counter()
-        d_ref, U_ref = host_reference(args, wl, Omega_host, r, hf_o, hp_o)
+        (d_ref, U_ref), apply_B = host_reference(args, hf, wl, prior, world, Omega_host, r, hp_o)
         Ud = np.asfortranarray(U.to_dense())
         lead = max(1, r // 2)
-        if B is None:
-            angle = hp_o.principal_angle(Ud[:, :lead], U_ref[:, :lead])
-        else:
-            angle = hp_o.principal_angle(Ud[:, :lead], U_ref[:, :lead], lambda W: wl.M @ W)
+        angle = hp_o.principal_angle(Ud[:, :lead], U_ref[:, :lead], apply_B)
+        BU = Ud if apply_B is None else apply_B(Ud)
         out["parity"] = {"eig_rel_err_vs_oracle": hp_o.eig_rel_err(d, d_ref), "principal_angle_rad_leading_%d" % lead: angle,
-                         "eigenvalue_range": [float(d[0]), float(d[-1])], "oracle_seconds": time.perf_counter() - t0,
-                         "note": "oracle = CPU restatement of the reference path on the same Omega and the same operator (factored form)"}
+                         "orthonormality_defect": float(np.abs(Ud.T @ BU - np.eye(r)).max()),
+                         "eigenvalue_range": [float(d[0]), float(d[-1])],
+                         "relative_gap_below_leading_%d" % lead: float((d_ref[lead - 1] - d_ref[lead]) / d_ref[lead - 1]),
+                         "oracle_seconds": time.perf_counter() - t0,
+                         "note": "oracle = CPU restatement of the reference path (oracle/) on the same Omega and the same operator data, "
+                                 "streamed from HBM to the host and applied densely there"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, wl, Omega_host, r, N, hp_o, hf_o)
+        out["cpu_baseline"] = cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
     os.dup2(2, 1)                      # whatever the libraries print while shutting down stays off stdout
-    collective.barrier()
-    if use_dist:
-        collective.close()
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ Host code is Python over a C ABI (include/hfmi.h, hippyflow_amd/libhfmi.so: hand
 There is no CPU fallback: importing the package is cheap and GPU-free, but any compute call
 raises if libhfmi.so or a GPU is missing.
 """
-from ._lib import Context, HfmiError, device_count, load
+from ._lib import Context, HfmiError, build_tag, device_count, load
 from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, MultipleSamePartitioningPDEsCollective,
                           MultipleSerialPDEsCollective, NativeCollective, NullCollective, TorchCollective)
 from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector

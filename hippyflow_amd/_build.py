@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhfmi.so")
-SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip", "hfmi_comm.hip"]
+SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip", "hfmi_comm.hip", "hfmi_eig_large.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -32,19 +32,37 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def source_tag():
+    """Identity of the kernel sources this library is built from (first 12 hex digits of a SHA-256 over csrc/ and the
+    public header).  ``hfmi_build_tag()`` returns it; profiles/pmc_traffic.json records it, and bench.py only uses PMC
+    traffic figures that were measured on the same build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    h.update(open(os.path.join(INCLUDE, "hfmi.h"), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=True):
     """Compile every translation unit for gfx950 and link hippyflow_amd/libhfmi.so."""
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, "hfmi_internal.h"), os.path.join(CSRC, "hfmi_gemm_common.h"), os.path.join(INCLUDE, "hfmi.h")]
+    tag = source_tag()
+    tag_file = os.path.join(OBJDIR, "source_tag.txt")
+    tag_changed = not os.path.exists(tag_file) or open(tag_file).read().strip() != tag
     jobs = []
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or not _newer(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+        carries_tag = src == "hfmi_api.hip"
+        if force or not _newer(o, [s] + headers) or (carries_tag and tag_changed):
+            jobs.append([hipcc] + FLAGS + (['-DHFMI_BUILD_TAG="%s"' % tag] if carries_tag else []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -57,6 +75,7 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
+    open(tag_file, "w").write(tag + "\n")
     if jobs or force or not _newer(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lrt", "-lpthread"])
     return LIB

@@ -54,11 +54,13 @@ SIGNATURES = {
     "hfmi_block_norms": [_P, _P],
     "hfmi_randn_fill": [_P, C.c_uint64, C.c_uint32, C.c_double],
     "hfmi_philox_raw": [_P, C.c_uint64, C.c_uint32, _P],
+    "hfmi_block_fill_matern32": [_P, C.c_int, C.c_int, C.c_double, C.c_double],
     "hfmi_block_dot": [_P, _P, _P],
     "hfmi_block_gemm_small": [_P, _P, C.c_double, C.c_double, _P],
     "hfmi_csr_create": [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _PP],
     "hfmi_csr_destroy": [_P],
     "hfmi_op_snapshot_gram": [_P, _P, C.c_double, _PP],
+    "hfmi_op_low_rank": [_P, _P, _P, _PP],
     "hfmi_op_jtj": [_P, _P, C.c_int, C.c_int, _P, C.c_double, _PP],
     "hfmi_op_jjt": [_P, _P, C.c_int, C.c_int, C.c_double, _PP],
     "hfmi_op_dense_sym": [_P, _P, _PP],
@@ -66,6 +68,7 @@ SIGNATURES = {
     "hfmi_op_csr_pcg": [_P, _P, C.c_double, C.c_int, _PP],
     "hfmi_op_compose3": [_P, _P, _P, _P, _PP],
     "hfmi_op_host_callback": [_P, HOST_APPLY_FN, _P, C.c_int64, _PP],
+    "hfmi_op_host_set_chunk": [_P, C.c_int],
     "hfmi_op_set_post_apply": [_P, POST_APPLY_FN, _P],
     "hfmi_op_set_collective": [_P, _P, C.c_int],
     "hfmi_op_apply": [_P, _P, _P, C.c_int],
@@ -89,11 +92,12 @@ SIGNATURES = {
     "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
     "hfmi_bench_peaks": [_P, _D, _D, _D],
     "hfmi_profile_begin": [_P],
+    "hfmi_profile_phases": [_P, _D],
     "hfmi_tuning_set": [C.c_char_p, C.c_int],
     "hfmi_profile_end": [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), _D,
                          C.POINTER(C.c_int64), _D, _D],
 }
-NON_STATUS = {"hfmi_last_error": (C.c_char_p, []), "hfmi_version": (C.c_int, [])}
+NON_STATUS = {"hfmi_last_error": (C.c_char_p, []), "hfmi_version": (C.c_int, []), "hfmi_build_tag": (C.c_char_p, [])}
 
 _lib = None
 
@@ -147,6 +151,10 @@ def check(status):
 
 def call(name, *args):
     check(getattr(load(), name)(*args))
+
+
+def build_tag():
+    return load().hfmi_build_tag().decode()
 
 
 def device_count():
@@ -225,6 +233,17 @@ class Context:
         names = ("k_tsgemm_tn", "k_tsgemm_nn")
         return [{"kernel": names[kind[g]], "m": shape[3 * g], "k": shape[3 * g + 1], "N": shape[3 * g + 2], "ms": ms[g],
                  "launches": int(n[g]), "flops_per_launch": fl[g], "bytes_per_launch": by[g]} for g in range(ng.value)]
+
+    PHASES = ("apply_A", "apply_Binv", "orthogonalize", "rayleigh_quotient", "small_eig", "back_transform", "allreduce",
+              "host_d2h_wait", "host_function", "host_h2d")
+
+    def profile_phases(self):
+        """Milliseconds per phase of the fused solves between profile_begin and profile_end (call after profile_end).
+        ``allreduce`` is inside ``apply_A`` / ``rayleigh_quotient``; the ``host_*`` legs (wall clock) are inside the
+        phase whose operator is a host callback, normally ``apply_Binv``."""
+        out = (C.c_double * len(self.PHASES))()
+        call("hfmi_profile_phases", self.handle, out)
+        return {name: out[i] for i, name in enumerate(self.PHASES)}
 
     def close(self):
         if self.handle:

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cmath>
@@ -23,6 +24,10 @@ void hfmi_set_error(const char* fmt, ...) {
 }
 extern "C" const char* hfmi_last_error(void) { return g_err; }
 extern "C" int hfmi_version(void) { return HFMI_VERSION; }
+#ifndef HFMI_BUILD_TAG
+#define HFMI_BUILD_TAG "untagged"
+#endif
+extern "C" const char* hfmi_build_tag(void) { return HFMI_BUILD_TAG; }
 
 extern "C" int hfmi_device_count(int* count) {
   if (!count) HFMI_FAIL(HFMI_ERR_INVALID, "device_count: null argument");
@@ -85,12 +90,16 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   }
   c->pinned = nullptr;
   c->pinned_bytes = 0;
+  c->pinned_cb = nullptr;
+  c->pinned_cb_bytes = 0;
+  for (int i = 0; i < HFMI_PHASE_COUNT; ++i) c->phase_ms[i] = 0.0;
   c->profiling = false;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_status, hipEventDisableTiming));
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_cb[i], hipEventDisableTiming));
   HIP_TRY(hipMalloc((void**)&c->small, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->small, 0, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double), c->stream));
   HIP_TRY(hipMalloc((void**)&c->status_dev, sizeof(hfmi_status_words)));
@@ -113,6 +122,8 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   for (int i = 0; i < WS_NSLOTS; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_cb) (void)hipHostFree(ctx->pinned_cb);
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_cb[i]);
   (void)hipFree(ctx->small);
   (void)hipFree(ctx->status_dev);
   (void)hipHostFree(ctx->status_host);
@@ -414,6 +425,13 @@ extern "C" int hfmi_randn_fill(hfmi_block* b, uint64_t seed, uint32_t stream, do
   if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
   return launch_randn(b->ctx, b->p, b->N, b->nvec, b->ld, seed, stream, sigma);
 }
+extern "C" int hfmi_block_fill_matern32(hfmi_block* C, int nx, int ny, double sigma, double ell) {
+  if (!C) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
+  if (C->N != C->nvec) HFMI_FAIL(HFMI_ERR_INVALID, "fill_matern32: the block must be square (%lld x %d)", (long long)C->N, C->nvec);
+  if (nx < 2 || ny < 2 || (int64_t)nx * ny < C->N) HFMI_FAIL(HFMI_ERR_INVALID, "fill_matern32: a %d x %d grid has fewer than %lld nodes", nx, ny, (long long)C->N);
+  if (!(ell > 0.0)) HFMI_FAIL(HFMI_ERR_INVALID, "fill_matern32: correlation length must be positive");
+  return launch_matern32(C->ctx, C->p, C->N, C->nvec, C->ld, nx, ny, sigma, ell);
+}
 extern "C" int hfmi_philox_raw(hfmi_block* shape_of, uint64_t seed, uint32_t stream, uint32_t* host_out) {
   if (!shape_of || !host_out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   hfmi_ctx* ctx = shape_of->ctx;
@@ -545,6 +563,19 @@ extern "C" int hfmi_op_snapshot_gram(hfmi_ctx* ctx, const hfmi_block* X, double 
   *out = op;
   return HFMI_OK;
 }
+extern "C" int hfmi_op_low_rank(hfmi_ctx* ctx, const hfmi_block* U, const double* host_d, hfmi_op** out) {
+  if (!ctx || !U || !host_d || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_op* op = op_new(ctx, OP_SNAPSHOT_GRAM);
+  if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+  op->X = *U;
+  op->X.owner = false;
+  op->scale = 1.0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMalloc((void**)&op->weights, (size_t)U->nvec * sizeof(double)));
+  HIP_TRY(hipMemcpy(op->weights, host_d, (size_t)U->nvec * sizeof(double), hipMemcpyHostToDevice));
+  *out = op;
+  return HFMI_OK;
+}
 static int op_jac(hfmi_ctx* ctx, hfmi_op_kind kind, const hfmi_block* J, int ndata, int q, const double* host_gamma_inv,
                   double scale, hfmi_op** out) {
   if (!ctx || !J || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
@@ -623,6 +654,12 @@ extern "C" int hfmi_op_host_callback(hfmi_ctx* ctx, hfmi_host_apply_fn fn, void*
   *out = op;
   return HFMI_OK;
 }
+extern "C" int hfmi_op_host_set_chunk(hfmi_op* op, int vectors) {
+  if (!op || op->kind != OP_HOST) HFMI_FAIL(HFMI_ERR_INVALID, "op_host_set_chunk: not a host-callback operator");
+  if (vectors < 0) HFMI_FAIL(HFMI_ERR_INVALID, "op_host_set_chunk: negative slab size");
+  op->host_chunk = vectors;
+  return HFMI_OK;
+}
 extern "C" int hfmi_op_set_post_apply(hfmi_op* op, hfmi_post_apply_fn fn, void* user) {
   if (!op) HFMI_FAIL(HFMI_ERR_INVALID, "null op");
   op->post_fn = fn;
@@ -639,9 +676,10 @@ extern "C" int hfmi_op_set_collective(hfmi_op* op, hfmi_comm* comm, int reduce_o
 }
 extern "C" int hfmi_op_destroy(hfmi_op* op) {
   if (!op) return HFMI_OK;
-  if (op->gamma_inv) {
+  if (op->gamma_inv || op->weights) {
     (void)hipStreamSynchronize(op->ctx->stream);
-    (void)hipFree(op->gamma_inv);
+    if (op->gamma_inv) (void)hipFree(op->gamma_inv);
+    if (op->weights) (void)hipFree(op->weights);
   }
   delete op;
   return HFMI_OK;
@@ -729,6 +767,81 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
   return HFMI_OK;
 }
 
+// Host black box on a device block (hfmi_op_host_callback): W goes device -> pinned host, the callback fills Y on the
+// host, Y goes pinned host -> device.  With a slab size (hfmi_op_host_set_chunk) the three legs are pipelined over
+// slabs of vectors: while the host works on slab i, slab i+1 is already arriving on the auxiliary stream and slab i-1
+// is on its way back on the main stream.  The host-side wall clock of the three legs is kept for the phase report.
+static double wall_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static int host_apply_pipelined(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
+  hfmi_ctx* ctx = op->ctx;
+  const int64_t N = W->N, NY = Y->N;
+  const int k = W->nvec;
+  const int chunk = (op->host_chunk > 0 && op->host_chunk < k) ? op->host_chunk : k;
+  const int nchunks = (k + chunk - 1) / chunk;
+  const size_t wslab = (size_t)chunk * N, yslab = (size_t)chunk * NY;
+  const int nbuf = nchunks > 1 ? 2 : 1;
+  const size_t need = (size_t)nbuf * (wslab + yslab) * sizeof(double);
+  if (need > ctx->pinned_cb_bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned_cb) HIP_TRY(hipHostFree(ctx->pinned_cb));
+    ctx->pinned_cb = nullptr;
+    ctx->pinned_cb_bytes = 0;
+    HIP_TRY(hipHostMalloc(&ctx->pinned_cb, need, hipHostMallocDefault));
+    ctx->pinned_cb_bytes = need;
+  }
+  double* wbuf[2] = {(double*)ctx->pinned_cb, (double*)ctx->pinned_cb + (nbuf - 1) * wslab};
+  double* ybuf[2] = {(double*)ctx->pinned_cb + nbuf * wslab, (double*)ctx->pinned_cb + nbuf * wslab + (nbuf - 1) * yslab};
+  auto fetch = [&](int c) -> int {      // slab c of W -> wbuf[c & 1] on the auxiliary stream
+    const int c0 = c * chunk, nc = std::min(chunk, k - c0);
+    HIP_TRY(hipMemcpy2DAsync(wbuf[c & 1], (size_t)N * sizeof(double), W->p + (int64_t)c0 * W->ld, (size_t)W->ld * sizeof(double),
+                             (size_t)N * sizeof(double), (size_t)nc, hipMemcpyDeviceToHost, ctx->aux_stream));
+    HIP_TRY(hipEventRecord(ctx->ev_cb[c & 1], ctx->aux_stream));
+    return HFMI_OK;
+  };
+  // W is complete once the main stream reaches this point
+  HIP_TRY(hipEventRecord(ctx->ev_status, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_status, 0));
+  HFMI_TRY(fetch(0));
+  double t_d2h = 0.0, t_fn = 0.0, t_h2d = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int c0 = c * chunk, nc = std::min(chunk, k - c0);
+    double t0 = wall_ms();
+    HIP_TRY(hipEventSynchronize(ctx->ev_cb[c & 1]));                       // slab c has arrived
+    if (c + 1 < nchunks) HFMI_TRY(fetch(c + 1));                           // wbuf[(c+1)&1] was consumed by call c-1
+    double t1 = wall_ms();
+    t_d2h += t1 - t0;
+    if (c >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_cb[2 + (c & 1)]));     // ybuf[c&1] has left for the device (slab c-2)
+    double t2 = wall_ms();
+    t_h2d += t2 - t1;
+    memset(ybuf[c & 1], 0, (size_t)nc * NY * sizeof(double));
+    const int rc = op->host_fn(op->host_user, wbuf[c & 1], ybuf[c & 1], N, nc);
+    double t3 = wall_ms();
+    t_fn += t3 - t2;
+    if (rc != 0) {
+      (void)hipStreamSynchronize(ctx->aux_stream);
+      (void)hipStreamSynchronize(ctx->stream);
+      HFMI_FAIL(HFMI_ERR_CALLBACK, "host operator callback returned %d", rc);
+    }
+    HIP_TRY(hipMemcpy2DAsync(Y->p + (int64_t)c0 * Y->ld, (size_t)Y->ld * sizeof(double), ybuf[c & 1], (size_t)NY * sizeof(double),
+                             (size_t)NY * sizeof(double), (size_t)nc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_cb[2 + (c & 1)], ctx->stream));
+    t_h2d += wall_ms() - t3;
+  }
+  double t0 = wall_ms();
+  HIP_TRY(hipStreamSynchronize(ctx->stream));                              // the pinned slabs are free again
+  t_h2d += wall_ms() - t0;
+  if (ctx->profiling) {
+    ctx->phase_ms[HFMI_PHASE_HOST_D2H] += t_d2h;
+    ctx->phase_ms[HFMI_PHASE_HOST_FN] += t_fn;
+    ctx->phase_ms[HFMI_PHASE_HOST_H2D] += t_h2d;
+  }
+  return HFMI_OK;
+}
+
 static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double beta);
 
 static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double beta) {
@@ -747,6 +860,7 @@ static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double 
       HFMI_TRY(launch_tsgemm_tn(ctx, X.p, X.ld, m, W->p, W->ld, k, X.N, op->scale, 0.0, (double*)G, ldg, 1, 0));
       if (op->kind == OP_JTJ && op->gamma_inv)
         HFMI_TRY(launch_gamma_apply(ctx, (double*)G, ldg, op->ndata, op->q, k, op->gamma_inv, (int)round_up(op->q, 16)));
+      if (op->weights) HFMI_TRY(launch_row_scale(ctx, (double*)G, ldg, m, k, op->weights));
       HFMI_TRY(launch_tsgemm_nn(ctx, X.p, X.ld, m, (const double*)G, ldg, k, 1.0, beta, Y->p, Y->ld, X.N));
       return HFMI_OK;
     }
@@ -809,18 +923,19 @@ static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double 
     case OP_HOST: {
       const int64_t N = W->N;
       if (op->host_N > 0 && op->host_N != N) HFMI_FAIL(HFMI_ERR_INVALID, "host operator acts on vectors of length %lld, got %lld", (long long)op->host_N, (long long)N);
-      std::vector<double> hw((size_t)N * k), hy((size_t)Y->N * k, 0.0);
-      HFMI_TRY(hfmi_block_download(W, hw.data(), HFMI_LAYOUT_VECTORS));
-      const int rc = op->host_fn(op->host_user, hw.data(), hy.data(), N, k);
-      if (rc != 0) HFMI_FAIL(HFMI_ERR_CALLBACK, "host operator callback returned %d", rc);
-      if (beta == 0.0) return hfmi_block_upload(Y, hy.data(), HFMI_LAYOUT_VECTORS);
-      hfmi_block* T = nullptr;
-      HFMI_TRY(ctx_tmp_block(ctx, 13, Y->N, k, &T));
-      hfmi_block v = *T;
-      v.nvec = k;
-      HFMI_TRY(hfmi_block_upload(&v, hy.data(), HFMI_LAYOUT_VECTORS));
+      hfmi_block* dst = Y;
+      hfmi_block tmpv;
+      if (beta != 0.0) {
+        hfmi_block* T = nullptr;
+        HFMI_TRY(ctx_tmp_block(ctx, 13, Y->N, k, &T));
+        tmpv = *T;
+        tmpv.nvec = k;
+        dst = &tmpv;
+      }
+      HFMI_TRY(host_apply_pipelined(op, W, dst));
+      if (beta == 0.0) return HFMI_OK;
       if (beta != 1.0) HFMI_TRY(launch_scale(ctx, Y->p, Y->ld, Y->N, k, beta));
-      return launch_axpy(ctx, Y->p, Y->ld, 1.0, v.p, v.ld, Y->N, k);
+      return launch_axpy(ctx, Y->p, Y->ld, 1.0, dst->p, dst->ld, Y->N, k);
     }
   }
   HFMI_FAIL(HFMI_ERR_INVALID, "unknown operator kind");
@@ -833,7 +948,11 @@ extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, in
   HIP_TRY(hipSetDevice(op->ctx->device));
   if (accumulate && (op->post_fn || op->comm)) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: accumulate with a rank reduction attached is ambiguous");
   HFMI_TRY(op_apply_raw(op, W, Y, accumulate ? 1.0 : 0.0));
-  if (op->comm) HFMI_TRY(comm_allreduce_device(op->comm, Y->p, Y->ld * (int64_t)Y->nvec, op->comm_op));
+  if (op->comm) {
+    const int ph = phase_begin(op->ctx, HFMI_PHASE_ALLREDUCE);
+    HFMI_TRY(comm_allreduce_device(op->comm, Y->p, Y->ld * (int64_t)Y->nvec, op->comm_op));
+    phase_end(op->ctx, ph);
+  }
   if (op->post_fn) {
     const int rc = op->post_fn(op->post_user, Y);
     if (rc != 0) HFMI_FAIL(HFMI_ERR_CALLBACK, "post-apply hook returned %d", rc);
@@ -1037,8 +1156,9 @@ extern "C" int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* 
 // ------------------------------------------------------------------ Rayleigh-Ritz
 extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d, double* host_V) {
   if (!ctx || !host_T || !host_d) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
-  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_small: k=%d out of range [1,%d]", k, SM_MAXK);
+  if (k < 1 || k > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_small: k=%d out of range [1,4096]", k);
   HIP_TRY(hipSetDevice(ctx->device));
+  if (k > SM_MAXK) return sym_eig_large(ctx, host_T, k, sort_by_abs, host_d, host_V);   // whole-GPU one-sided Jacobi
   HFMI_TRY(upload_small(ctx, host_T, k, k, sm_ptr(ctx, SM_T), SM_LD));
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
@@ -1087,7 +1207,7 @@ extern "C" int hfmi_svd_small(hfmi_ctx* ctx, const double* host_R, int k, double
 // reduction GEMM G = X Q (no N x k block A Q, i.e. one of the four big contractions of the solve disappears).  A rank
 // average attached to the operator (CollectiveOperator 'avg'/'sum') is linear, so the hook is applied to T itself: the
 // second all-reduce of the solve shrinks from N x k to k x k.
-static bool op_has_gram_form(const hfmi_op* A) { return A->kind == OP_SNAPSHOT_GRAM || A->kind == OP_JTJ; }
+static bool op_has_gram_form(const hfmi_op* A) { return (A->kind == OP_SNAPSHOT_GRAM && !A->weights) || A->kind == OP_JTJ; }
 
 // fold_rinv: Q stands for Q R^-1 with R^-1 in SM_RINV (deferred last QR pass): X (Q R^-1) = (X Q) R^-1 is applied to
 // the small m x k intermediate instead of the N x k block.
@@ -1110,7 +1230,11 @@ static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T
     HFMI_TRY(launch_zero_pad(ctx, Gc2, m, k, ldm));
   }
   HFMI_TRY(launch_tsgemm_tn(ctx, Gc, ldm, k, Gc2, ldm, k, m, A->scale, 0.0, sm_ptr(ctx, slot_T), SM_LD, 1, 0));
-  if (A->comm) HFMI_TRY(comm_allreduce_device(A->comm, sm_ptr(ctx, slot_T), (int64_t)SM_LD * k, A->comm_op));
+  if (A->comm) {
+    const int ph = phase_begin(ctx, HFMI_PHASE_ALLREDUCE);
+    HFMI_TRY(comm_allreduce_device(A->comm, sm_ptr(ctx, slot_T), (int64_t)SM_LD * k, A->comm_op));
+    phase_end(ctx, ph);
+  }
   if (A->post_fn) {
     hfmi_block t;
     t.ctx = ctx;
@@ -1149,12 +1273,18 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     cur = Omega;
     for (int it = 0; it < s; ++it) {
       if (Binv) {
+        int ph = phase_begin(ctx, HFMI_PHASE_APPLY);
         HFMI_TRY(hfmi_op_apply(A, cur, &Y, 0));
+        phase_end(ctx, ph);
+        ph = phase_begin(ctx, HFMI_PHASE_BINV);
         HFMI_TRY(hfmi_op_apply(Binv, &Y, &Q, 0));
+        phase_end(ctx, ph);
         cur = &Q;
       } else {
         hfmi_block* dst = (cur == &Q) ? &Y : &Q;
+        const int ph = phase_begin(ctx, HFMI_PHASE_APPLY);
         HFMI_TRY(hfmi_op_apply(A, cur, dst, 0));
+        phase_end(ctx, ph);
         cur = dst;
       }
     }
@@ -1164,6 +1294,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   bool deferred = false;                                   // last Cholesky-QR pass left as R^-1 in SM_RINV
   hfmi_block* Qp = const_cast<hfmi_block*>(cur);           // holds the block to orthogonalise
   hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
+  int ph = phase_begin(ctx, HFMI_PHASE_QR);
   if (flags & 2) {
     HFMI_TRY(hfmi_borth_qr(Qp, B, nullptr, nullptr, HFMI_QR_MGS, nullptr));
   } else {
@@ -1180,6 +1311,8 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
       return qs;
     }
   }
+  phase_end(ctx, ph);
+  ph = phase_begin(ctx, HFMI_PHASE_RAYLEIGH);
   if (op_has_gram_form(A) && !(flags & 4)) {
     HFMI_TRY(op_rayleigh_quotient_gram(A, Qp, SM_T, deferred));
   } else {
@@ -1187,16 +1320,21 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     HFMI_TRY(hfmi_op_apply(A, Qp, AQ, 0));
     HFMI_TRY(launch_tsgemm_tn(ctx, AQ->p, AQ->ld, k, Qp->p, Qp->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_T), SM_LD, 1, 0));
   }
+  phase_end(ctx, ph);
   // small eigensolve, U = Q V[:, :r]
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
+  ph = phase_begin(ctx, HFMI_PHASE_EIG);
   HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1));
+  phase_end(ctx, ph);
+  ph = phase_begin(ctx, HFMI_PHASE_BACK);
   if (deferred) {   // U = (Q R^-1) V = Q (R^-1 V)
     HFMI_TRY(launch_small_matmul(ctx, k, r, SM_RINV, SM_V, SM_TMP2));
     HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_TMP2), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
   } else {
     HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_V), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
   }
+  phase_end(ctx, ph);
   hfmi_status_words st;
   HFMI_TRY(read_status(ctx, &st));
   if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: Jacobi eigensolve did not converge (off-diagonal %.2e)", st.offdiag);
@@ -1232,6 +1370,23 @@ int prof_stop(hfmi_ctx* ctx, int idx) {
   if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream);
   return HFMI_OK;
 }
+int phase_begin(hfmi_ctx* ctx, int phase) {
+  if (!ctx->profiling) return -1;
+  hfmi_ctx::phase_rec r;
+  r.phase = phase;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+  (void)hipEventRecord(r.e0, ctx->stream);
+  ctx->phase_events.push_back(r);
+  return (int)ctx->phase_events.size() - 1;
+}
+void phase_end(hfmi_ctx* ctx, int idx) {
+  if (idx >= 0) (void)hipEventRecord(ctx->phase_events[idx].e1, ctx->stream);
+}
+extern "C" int hfmi_profile_phases(hfmi_ctx* ctx, double* ms_out) {
+  if (!ctx || !ms_out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  for (int i = 0; i < HFMI_PHASE_COUNT; ++i) ms_out[i] = ctx->phase_ms[i];
+  return HFMI_OK;
+}
 extern "C" int hfmi_profile_begin(hfmi_ctx* ctx) {
   if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
   for (auto& r : ctx->prof) {
@@ -1239,6 +1394,12 @@ extern "C" int hfmi_profile_begin(hfmi_ctx* ctx) {
     (void)hipEventDestroy(r.e1);
   }
   ctx->prof.clear();
+  for (auto& r : ctx->phase_events) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->phase_events.clear();
+  for (int i = 0; i < HFMI_PHASE_COUNT; ++i) ctx->phase_ms[i] = 0.0;
   ctx->profiling = true;
   return HFMI_OK;
 }
@@ -1274,6 +1435,13 @@ extern "C" int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int
     launches[g] += 1;
   }
   ctx->prof.clear();
+  for (auto& r : ctx->phase_events) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) ctx->phase_ms[r.phase] += t;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->phase_events.clear();
   *ngroups = ng;
   return HFMI_OK;
 }

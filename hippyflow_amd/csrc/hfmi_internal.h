@@ -79,7 +79,18 @@ struct hfmi_ctx {
   bool profiling;
   struct prof_rec { int kind; int64_t m, k, N; hipEvent_t e0, e1; double flops, bytes; };
   std::vector<prof_rec> prof;
+  // phases of the fused solves (HFMI_PHASE_*, include/hfmi.h): event pairs on the stream while profiling, plus the
+  // host-side wall clock of the host-callback legs
+  struct phase_rec { int phase; hipEvent_t e0, e1; };
+  std::vector<phase_rec> phase_events;
+  double phase_ms[HFMI_PHASE_COUNT];
+  // second pinned staging area (host-callback operators: double-buffered W and Y slabs)
+  void* pinned_cb;
+  size_t pinned_cb_bytes;
+  hipEvent_t ev_cb[4];            // D2H done x2, H2D done x2
 };
+int phase_begin(hfmi_ctx* ctx, int phase);     // returns a record index or -1 when not profiling
+void phase_end(hfmi_ctx* ctx, int idx);
 int prof_start(hfmi_ctx* ctx, int kind, int64_t m, int64_t k, int64_t N);  // returns record index or -1
 int prof_stop(hfmi_ctx* ctx, int idx);
 
@@ -110,6 +121,7 @@ struct hfmi_op {
   hfmi_block X;          // snapshot / Jacobian / dense block (by value: a view, not owned)
   int ndata, q;
   double* gamma_inv;     // device q x q row-major (ld = round_up(q,16)) or null
+  double* weights;       // device, one per vector of X (general diagonal of a low-rank operator) or null
   double scale;
   const hfmi_csr* csr;
   double rel_tol;
@@ -119,6 +131,7 @@ struct hfmi_op {
   hfmi_host_apply_fn host_fn;
   void* host_user;
   int64_t host_N;
+  int host_chunk;        // > 0: the callback is invoked on slabs of this many vectors (pipelined with the copies)
   hfmi_post_apply_fn post_fn;
   void* post_user;
   hfmi_comm* comm;       // rank average / sum of the result block (hfmi_op_set_collective), null = none
@@ -148,6 +161,8 @@ int launch_tsgemm_nn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
 // ------------------------------------------------------------------ kernel launchers (hfmi_misc.hip)
 int launch_fill(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, double value, bool include_pad);
 int launch_zero_pad(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld);
+int launch_row_scale(hfmi_ctx* ctx, double* G, int ld, int m, int k, const double* w);
+int launch_matern32(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, int nx, int ny, double sigma, double ell);
 int launch_copy(hfmi_ctx* ctx, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t N, int nvec);
 int launch_scale(hfmi_ctx* ctx, double* p, int64_t ld, int64_t N, int nvec, double alpha);
 int launch_axpy(hfmi_ctx* ctx, double* y, int64_t ldy, double alpha, const double* x, int64_t ldx, int64_t N, int nvec);
@@ -201,6 +216,9 @@ int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);
 int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int slot_c);
 // R (k x k, slot_r) = U diag(s) V^T: singular values descending in svals (device), U -> slot_u, V -> slot_v (columns)
 int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, double* svals);
+
+// symmetric eigensolve for 256 < n <= 4096 (hfmi_eig_large.hip): host in, host out
+int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V);
 
 // micro-benchmarks
 int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs);

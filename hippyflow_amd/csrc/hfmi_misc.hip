@@ -31,6 +31,45 @@ __global__ void k_zero_pad(double* __restrict__ p, int64_t N, int nvec, int64_t 
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padn; t += (int64_t)gridDim.x * blockDim.x) c[t] = 0.0;
   }
 }
+// Synthetic config-2 covariance: vector j of the block is column j of the Matern-3/2 kernel matrix
+// sigma^2 (1 + a) exp(-a), a = sqrt(3) |x_i - x_j| / ell, over the first N nodes (row-major numbering) of an nx x ny grid
+// on the unit square.  Written once per run; 16-byte stores.
+__global__ void k_matern32(double* __restrict__ p, int64_t N, int nvec, int64_t ld, int nx, double hx, double hy, double sigma2,
+                           double inv_ell) {
+  for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
+    double* c = p + (int64_t)j * ld;
+    const double xj = (j % nx) * hx, yj = (j / nx) * hy;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < N; t += (int64_t)gridDim.x * blockDim.x * 2) {
+      double v[2];
+      for (int e = 0; e < 2; ++e) {
+        const int64_t i = t + e;
+        const double dx = (i % nx) * hx - xj, dy = (i / nx) * hy - yj;
+        const double a = 1.7320508075688772 * sqrt(dx * dx + dy * dy) * inv_ell;
+        v[e] = sigma2 * (1.0 + a) * exp(-a);
+      }
+      if (t + 1 < N) *reinterpret_cast<d2*>(c + t) = d2{v[0], v[1]};
+      else c[t] = v[0];
+    }
+  }
+}
+int launch_matern32(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, int nx, int ny, double sigma, double ell) {
+  hipLaunchKernelGGL(k_matern32, ew_grid(N, nvec), dim3(256), 0, ctx->stream, p, N, nvec, ld, nx, 1.0 / (nx - 1), 1.0 / (ny - 1),
+                     sigma * sigma, 1.0 / ell);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+// G (m x k, row-major, ld) <- diag(w) G: the diagonal of hp.LowRankOperator(d, U) between its two contractions
+__global__ void k_row_scale(double* __restrict__ G, int ld, int m, int k, const double* __restrict__ w) {
+  const int i = blockIdx.x;
+  const double wi = w[i];
+  for (int j = threadIdx.x; j < k; j += blockDim.x) G[(int64_t)i * ld + j] *= wi;
+}
+int launch_row_scale(hfmi_ctx* ctx, double* G, int ld, int m, int k, const double* w) {
+  if (m <= 0 || k <= 0) return HFMI_OK;
+  hipLaunchKernelGGL(k_row_scale, dim3(m), dim3(64), 0, ctx->stream, G, ld, m, k, w);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
 int launch_fill(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, double value, bool include_pad) {
   if (N <= 0 || nvec <= 0) return HFMI_OK;
   const int64_t rows = include_pad ? ld : N;

@@ -83,12 +83,37 @@ class SnapshotGramOperator(DeviceOperator):
         L.call("hfmi_op_snapshot_gram", self.ctx.handle, snapshots.handle, self.scale, C.byref(self._op))
 
 
-def LowRankOperator(d, U, init_vector=None):
-    """hp.LowRankOperator(d, U, init) for the constant-d case the path uses (d = ones/n)."""
-    d = np.asarray(d, dtype=np.float64)
-    if not np.allclose(d, d.flat[0]):
-        raise NotImplementedError("LowRankOperator: only a constant diagonal is on the hot path (PODProjector.py:359)")
-    return SnapshotGramOperator(U, scale=float(d.flat[0]))
+class LowRankOperator(DeviceOperator):
+    """hp.LowRankOperator(d, U, init_vector): ``mult`` y = U diag(d) U^T x (``dot_v`` + ``reduce`` in hippylib, two
+    contractions with a row scaling between them here) and ``solve(y, x)`` y = U diag(1/d) U^T x -- the object hippylib's
+    priors expose as ``prior.Hlr`` and hippyflow passes as both B and B^-1 (activeSubspaceProjector.py:455-459).  The
+    constant diagonal ``ones/n`` of PODProjector.py:359-361 is the snapshot-Gram operator."""
+
+    def __init__(self, d, U, init_vector=None, ctx=None):
+        if not isinstance(U, MultiVector):
+            U = MultiVector.from_vectors(U, ctx=ctx)
+        d = np.ascontiguousarray(np.broadcast_to(np.asarray(d, dtype=np.float64), (U.nvec(),)))
+        super().__init__(ctx or U.ctx, U.size())
+        self.U, self.d = U, d
+        self._init_vector = init_vector
+        self._inverse = None
+        L.call("hfmi_op_low_rank", self.ctx.handle, U.handle, L.ptr(d), C.byref(self._op))
+
+    def init_vector(self, x, dim=0):
+        if self._init_vector is not None:
+            return self._init_vector(x, dim)
+        return DeviceOperator.init_vector(self, x, dim)
+
+    def inverse(self):
+        """U diag(1/d) U^T as an operator (what ``solve`` applies)."""
+        if self._inverse is None:
+            if np.any(self.d == 0.0):
+                raise ZeroDivisionError("LowRankOperator.solve: zero entry in d")
+            self._inverse = LowRankOperator(1.0 / self.d, self.U, self._init_vector)
+        return self._inverse
+
+    def solve(self, y, x):
+        self.inverse().mult(x, y)
 
 
 class MeanJTJfromDataOperator(DeviceOperator):
@@ -221,22 +246,30 @@ class HostCallbackOperator(DeviceOperator):
     """A host black box plugged into the device solve (FEniCS/hIPPYlib PDE solves stay on the host).
 
     ``fn`` is one of: a callable mapping an (N, k) array to an (N, k) array; an object with
-    ``matMvMult_np(X) -> Y``; an object with ``solve(y, x)`` or ``mult(x, y)`` on 1-D numpy arrays
-    (applied column by column, like hp.MatMvMult's fallback loop)."""
+    ``matMvMult_np(X) -> Y`` or (solvers) ``solve_block(X) -> Y`` on (N, k) arrays; an object with ``solve(y, x)`` or
+    ``mult(x, y)`` on 1-D numpy arrays (applied column by column, like hp.MatMvMult's fallback loop).
 
-    def __init__(self, fn, N, ctx=None):
+    ``chunk_vectors``: for black boxes that treat the vectors independently (solvers), the callback is invoked on
+    slabs of that many vectors and the PCIe copies of the neighbouring slabs overlap the host work
+    (``hfmi_op_host_set_chunk``).  Default: solver-like objects (``solve`` / ``solve_block``) 16, everything else the
+    whole block in one call (a serialized-sampling Jacobian operator re-solves its PDEs on every call)."""
+
+    def __init__(self, fn, N, ctx=None, chunk_vectors=None):
         super().__init__(ctx, N)
         self.fn = fn
         self.error = None
+        solver_like = hasattr(fn, "solve") or hasattr(fn, "solve_block")
 
         def _cb(user, w_ptr, y_ptr, n, k):
             try:
                 W = np.ctypeslib.as_array(w_ptr, shape=(k, n))    # one vector per row
                 Y = np.ctypeslib.as_array(y_ptr, shape=(k, n))
-                if callable(fn) and not hasattr(fn, "mult") and not hasattr(fn, "solve"):
+                if callable(fn) and not hasattr(fn, "mult") and not solver_like:
                     Y[...] = np.asarray(fn(W.T)).T
                 elif hasattr(fn, "matMvMult_np"):
                     Y[...] = np.asarray(fn.matMvMult_np(W.T)).T
+                elif hasattr(fn, "solve_block"):
+                    Y[...] = np.asarray(fn.solve_block(W.T)).T
                 elif hasattr(fn, "solve"):
                     for j in range(k):
                         fn.solve(Y[j], W[j])
@@ -250,6 +283,11 @@ class HostCallbackOperator(DeviceOperator):
 
         self._cb = L.HOST_APPLY_FN(_cb)
         L.call("hfmi_op_host_callback", self.ctx.handle, self._cb, None, int(N), C.byref(self._op))
+        if chunk_vectors is None:
+            chunk_vectors = 16 if solver_like else 0
+        self.chunk_vectors = int(chunk_vectors)
+        if self.chunk_vectors:
+            L.call("hfmi_op_host_set_chunk", self._op, self.chunk_vectors)
 
     def _raise_pending(self):
         if self.error is not None:
@@ -331,7 +369,7 @@ def as_device_operator(obj, N=None, ctx=None):
         pass
     if isinstance(obj, np.ndarray) and obj.ndim == 2:
         return npToDeviceOperator(obj, ctx=ctx)
-    if callable(obj) or hasattr(obj, "mult") or hasattr(obj, "solve") or hasattr(obj, "matMvMult_np"):
+    if callable(obj) or hasattr(obj, "mult") or hasattr(obj, "solve") or hasattr(obj, "matMvMult_np") or hasattr(obj, "solve_block"):
         if N is None:
             raise ValueError("as_device_operator: vector length needed to wrap a host operator")
         return HostCallbackOperator(obj, N, ctx=ctx)

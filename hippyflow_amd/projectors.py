@@ -550,8 +550,8 @@ def weighted_l2_norm_vector(x, W):
 class PODProjectorFromData:
     """Deterministic mass-weighted POD from a snapshot matrix (PODProjector.py:666-852).
     ``method='hep'`` (n << N) runs on the device: the n x n Gram matrix X^T M X and the back-transform
-    phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is the Jacobi kernel
-    (n <= 256) -- same steps as :812-833.
+    phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is a Jacobi kernel (one workgroup up to
+    256 snapshots, one workgroup per column pair over the whole GPU up to 4096) -- same steps as :812-833.
 
     ``method='ghep'`` (H = M X (M X)^T / n against M, :743-773) and ``'inverse_ghep'`` (H = X X^T / n against
     M^-1, :775-810) are ARPACK Lanczos iterations on the host in the reference.  Both pencils have their
@@ -578,8 +578,8 @@ class PODProjectorFromData:
         else:
             u_shift = np.zeros(u_data.shape[1])
         if method in ('hep', 'ghep', 'inverse_ghep'):
-            if n_data > 256:
-                raise NotImplementedError("the device Gram route handles up to 256 snapshots (one-workgroup eigensolve); "
+            if n_data > 4096:
+                raise NotImplementedError("the device Gram route handles up to 4096 snapshots (n x n eigensolve on the device); "
                                           "use PODProjector (randomized) for larger snapshot sets")
             X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector
             Mop = CsrOperator(self.M_csr, ctx=self.ctx)

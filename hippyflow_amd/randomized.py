@@ -161,6 +161,14 @@ def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, 
     return d, U
 
 
+def _as_solver_operator(Binv, N, ctx):
+    """B^-1 as an operator.  An object that is both the operator and its own solver (``prior.Hlr``: ``mult`` applies B,
+    ``solve`` applies B^-1; activeSubspaceProjector.py:455-459) contributes its ``inverse()``."""
+    if isinstance(Binv, DeviceOperator) and hasattr(Binv, "inverse"):
+        return Binv.inverse()
+    return as_device_operator(Binv, N, ctx)
+
+
 def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True, literal_T=False):
     """Randomized double pass for A u = lambda B u (B SPD), U^T B U = I.
     ``Binv`` is a solver object (``solve(y, x)``) as in the reference, or an operator."""
@@ -170,11 +178,11 @@ def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_m
     A_dev, coll, mpi_op = _unwrap_collective(A)
     if fused and A_dev is not None:
         B_dev = as_device_operator(B, N, Omega.ctx)
-        Binv_dev = as_device_operator(Binv, N, Omega.ctx)
+        Binv_dev = _as_solver_operator(Binv, N, Omega.ctx)
         return _fused(A_dev, coll, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs, literal_T)
     # B^{-1}: a device operator / solver as is; a host solver object (solve(y, x) on numpy arrays, like the
     # PETSc solvers of the reference) is reached through a host-callback operator
-    Binv_op = as_device_operator(Binv, N, Omega.ctx)
+    Binv_op = _as_solver_operator(Binv, N, Omega.ctx)
     Ybar = MultiVector(N, nvec, ctx=Omega.ctx)
     Q = MultiVector(Omega)
     for _ in range(s):

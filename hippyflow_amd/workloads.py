@@ -14,6 +14,8 @@ factorisation whose operator spectrum is known in closed form:
 The latent factors are kept so that tests and bench.py can evaluate the SAME operator on the host in
 factored form (a few N x c products) -- that is what makes an oracle check affordable at full size.
 """
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -73,22 +75,39 @@ def pod_host_apply(wl, W0_host):
     return lambda W: np.asfortranarray(W0_host @ (H @ (W0_host.T @ W)))
 
 
+NOISE_STREAM0 = 0x10000     # Philox stream of sample i's noise block E_i: NOISE_STREAM0 + global sample index
+
+
 def as_workload(N, ns_local, q=100, latent=100, rate=0.06, seed=4, first_sample=0, ns_total=None, ctx=None,
-                noise_cov_inv=None):
+                noise_cov_inv=None, noise=0.0, P=None):
     """ns_local Jacobian samples (global indices first_sample ...) of shape q x N, stored as one block of
     ns_local*q vectors.  ``scale`` of the returned operator is 1/ns_local (the per-rank mean); the rank
-    average is the collective's job."""
+    average is the collective's job.
+
+    ``noise``: SURVEY section 8d's config 4 is ``J_i = A_i P^T + 0.01 E_i`` with E_i (q x N) i.i.d. Gaussian keyed
+    by the GLOBAL sample index (device Philox: seed, stream NOISE_STREAM0 + i, vector = row o, the element map of
+    ``hfmi_randn_fill``), so any rank regenerates exactly its shard and a host can regenerate E_i bit-for-bit from the
+    same counters.  With noise the operator is full rank (no closed-form spectrum): parity is then checked against a
+    dense host evaluation of the same J."""
     ctx = ctx or L.Context.default()
     c = int(latent)
     wl = Workload()
     wl.N, wl.ns_local, wl.q, wl.latent = int(N), int(ns_local), int(q), c
     wl.first_sample = int(first_sample)
     wl.ns_total = int(ns_total if ns_total is not None else ns_local)
-    wl.P = _orthonormal_block(N, c, seed, 200, ctx)
+    wl.P = P if P is not None else _orthonormal_block(N, c, seed, 200, ctx)     # shared by all samples (and ranks)
     wl.s = np.exp(-rate * np.arange(c))
     wl.A = np.stack([sample_factor(seed, first_sample + i, q, c) * wl.s[None, :] for i in range(ns_local)])   # (ns, q, c)
     S = wl.A.reshape(ns_local * q, c).T                 # c x (ns*q): column i*q+o = row o of A_i
     wl.J = _expand(wl.P, S, ctx)
+    wl.noise, wl.seed = float(noise), int(seed)
+    if noise:
+        E = MultiVector(int(N), int(q), ctx=ctx)
+        rnd = _ParRandom(seed)
+        for i in range(ns_local):
+            rnd.stream = NOISE_STREAM0 + first_sample + i
+            rnd.normal(1.0, E)
+            wl.J.view(i * q, q).axpy(float(noise), E)
     wl.operator = MeanJTJfromDataOperator.from_block(wl.J, ns_local, q, noise_cov_inv=noise_cov_inv)
     return wl
 
@@ -125,6 +144,117 @@ def grid_mass_matrix(nx, ny):
             vals.append(np.full(len(tris), area / 6.0 if a == b else area / 12.0))
     M = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nx * ny, nx * ny))
     return M.tocsr()
+
+
+def grid_stiffness_matrix(nx, ny):
+    """P1 stiffness matrix (Neumann) of the same nx x ny triangulation of the unit square as ``grid_mass_matrix``."""
+    import scipy.sparse as sp
+    hx, hy = 1.0 / (nx - 1), 1.0 / (ny - 1)
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    v00, v10, v01, v11 = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    rx, ry = 0.5 * hy / hx, 0.5 * hx / hy
+    rows, cols, vals = [], [], []
+
+    def add(a, b, v):
+        rows.append(a)
+        cols.append(b)
+        vals.append(np.full(len(a), v))
+
+    # both triangles of a cell are right-angled: (a, b, c) with the right angle at b, a-b along x, b-c along y
+    for a, b, c in ((v00, v10, v11), (v11, v01, v00)):
+        add(a, a, rx), add(b, b, rx + ry), add(c, c, ry)
+        add(a, b, -rx), add(b, a, -rx), add(b, c, -ry), add(c, b, -ry)
+    K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nx * ny, nx * ny))
+    return K.tocsr()
+
+
+class SparseLUPriorSolver:
+    """``prior.Rsolver`` of a bi-Laplacian prior, R^-1 = A^-1 M_l A^-1, as a HOST black box: sparse LU of A (SuperLU)
+    and two triangular-solve sweeps per vector.  ``solve(y, x)`` is the reference's solver protocol on 1-D arrays;
+    ``solve_block(X)`` serves (N, k) slabs, the vectors spread over a thread pool (SuperLU releases the GIL)."""
+
+    def __init__(self, A, M_lumped, threads=None):
+        import scipy.sparse.linalg as spla
+        self.N = A.shape[0]
+        self.lu = spla.splu(A.tocsc())
+        self.Ml = np.asarray(M_lumped, dtype=np.float64)
+        self.threads = int(threads or min(32, os.cpu_count() or 1))
+        self._pool = None
+        self.calls, self.vectors = 0, 0
+
+    def _one(self, X):
+        Z = self.lu.solve(np.asfortranarray(X))
+        Z *= self.Ml[:, None]
+        return self.lu.solve(Z)
+
+    def solve_block(self, X):
+        X = np.asarray(X)
+        k = X.shape[1]
+        self.calls, self.vectors = self.calls + 1, self.vectors + k
+        if self.threads <= 1 or k == 1:
+            return self._one(X)
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(self.threads)
+        step = max(1, -(-k // self.threads))
+        parts = list(self._pool.map(lambda c: self._one(X[:, c:c + step]), range(0, k, step)))
+        return np.concatenate(parts, axis=1)
+
+    def solve(self, y, x):
+        y[...] = self._one(np.asarray(x).reshape(-1, 1))[:, 0]
+
+
+class BiLaplacianPrior:
+    """The prior shape of the reference's tests (hp.BiLaplacianPrior, test_derivativeSubspace.py:40):
+    precision R = A M_l^-1 A with A = delta M + gamma K on an nx x ny P1 grid, ``R`` as a sparse matrix (applied on the
+    device as CSR), ``Rsolver`` a host sparse-LU black box, ``M`` the consistent mass matrix."""
+
+    def __init__(self, nx, ny, delta=1.0, gamma=0.1, threads=None):
+        import scipy.sparse as sp
+        self.nx, self.ny, self.delta, self.gamma = nx, ny, delta, gamma
+        self.M = grid_mass_matrix(nx, ny)
+        self.K = grid_stiffness_matrix(nx, ny)
+        self.A = (delta * self.M + gamma * self.K).tocsr()
+        self.M_lumped = np.asarray(self.M.sum(axis=1)).ravel()
+        self.R = (self.A @ sp.diags(1.0 / self.M_lumped) @ self.A).tocsr()
+        self.Rsolver = SparseLUPriorSolver(self.A, self.M_lumped, threads=threads)
+
+    def init_vector(self, x, dim):
+        x.init(self.R.shape[0])
+
+
+def matern32_covariance(C, nx, ny, sigma=1.0, ell=0.1):
+    """Fill the N x N block C (N = C.size() <= nx*ny grid nodes, row-major node numbering on the unit square) with the
+    Matern-3/2 kernel sigma^2 (1 + sqrt(3) d / ell) exp(-sqrt(3) d / ell) of SURVEY section 8d's config 2, on the device."""
+    import ctypes as C_
+    L.call("hfmi_block_fill_matern32", C.handle, int(nx), int(ny), float(sigma), float(ell))
+    return C
+
+
+def matern32_host(N, nx, ny, sigma=1.0, ell=0.1, rows=None):
+    """The same kernel on the host (rows ``rows`` of the N x N matrix; all rows by default): the dense evaluation the
+    miniature fixture and the streaming oracle use."""
+    idx = np.arange(N)
+    x, y = (idx % nx) / (nx - 1.0), (idx // nx) / (ny - 1.0)
+    r = idx if rows is None else np.asarray(rows)
+    d = np.sqrt((x[r, None] - x[None, :]) ** 2 + (y[r, None] - y[None, :]) ** 2)
+    a = np.sqrt(3.0) * d / ell
+    return sigma ** 2 * (1.0 + a) * np.exp(-a)
+
+
+def kle_matern_workload(nx, ny, N=None, sigma=1.0, ell=0.1, ctx=None):
+    """SURVEY 8d config 2 as specified: explicit dense Matern-3/2 covariance on the first N nodes of an nx x ny grid
+    (N = 1e5 of 316 x 317), the P1 mass matrix of that grid restricted to the same nodes."""
+    ctx = ctx or L.Context.default()
+    N = int(nx * ny if N is None else N)
+    wl = Workload()
+    wl.N, wl.nx, wl.ny, wl.sigma, wl.ell = N, nx, ny, sigma, ell
+    wl.C = MultiVector(N, N, ctx=ctx)
+    matern32_covariance(wl.C, nx, ny, sigma, ell)
+    wl.M = grid_mass_matrix(nx, ny)[:N, :N].tocsr()
+    wl.C_operator = npToDeviceOperator(wl.C)
+    wl.M_operator = CsrOperator(wl.M, ctx=ctx)
+    return wl
 
 
 def kle_workload(nx, ny, latent=256, rate=0.08, seed=2, ctx=None):

@@ -58,6 +58,7 @@ typedef struct hfmi_comm hfmi_comm;
 /* ---------------------------------------------------------------- context */
 const char* hfmi_last_error(void);
 int hfmi_version(void);
+const char* hfmi_build_tag(void);   /* identity of the kernel sources (hash); keys the PMC records bench.py may use */
 int hfmi_device_count(int* count);
 int hfmi_ctx_create(int device, hfmi_ctx** out);
 int hfmi_ctx_destroy(hfmi_ctx* ctx);
@@ -96,6 +97,10 @@ int hfmi_randn_fill(hfmi_block* b, uint64_t seed, uint32_t stream, double sigma)
 /* the raw 32-bit stream behind it (bit-exact parity test): out[nvec][ceil(N/2)][4] */
 int hfmi_philox_raw(hfmi_block* shape_of, uint64_t seed, uint32_t stream, uint32_t* host_out);
 
+/* synthetic config-2 input: C (N x N block) = Matern-3/2 covariance
+ * sigma^2 (1 + a) exp(-a), a = sqrt(3) d_ij / ell, over the first N nodes of an nx x ny grid on the unit square */
+int hfmi_block_fill_matern32(hfmi_block* C, int nx, int ny, double sigma, double ell);
+
 /* MultiVector.dot_mv / dot_v: out[i*nvecB + j] = <A_i, B_j>  (row-major nvecA x nvecB) */
 int hfmi_block_dot(const hfmi_block* A, const hfmi_block* B, double* host_out);
 /* MvDSmatMult / MultiVector.reduce: Y = alpha * A * S + beta * Y, S host (nvecA x nvecY) row-major */
@@ -114,6 +119,9 @@ int hfmi_csr_destroy(hfmi_csr* m);
 /* a2: hp.LowRankOperator(ones/n, snapshots)  -> Y = scale * X (X^T W)
  *     (PODProjector.py:359-361).  X: block, one vector per snapshot. */
 int hfmi_op_snapshot_gram(hfmi_ctx* ctx, const hfmi_block* X, double scale, hfmi_op** out);
+/*     general diagonal: hp.LowRankOperator(d, U) -> Y = U diag(d) (U^T W)  (prior.Hlr as B / B^-1,
+ *     activeSubspaceProjector.py:455-459; priorPreconditionedProjector.py:48-55).  host_d: one weight per vector of U. */
+int hfmi_op_low_rank(hfmi_ctx* ctx, const hfmi_block* U, const double* host_d, hfmi_op** out);
 /* a3: sample-averaged Jacobian Gram  Y = scale * sum_i J_i^T Gamma^{-1} J_i W
  *     (MeanJTJfromDataOperator.mult, operatorWrappers.py:95-114; JTJ summed by
  *     SummedListOperator / SeriallySampledJacobianOperator,
@@ -139,6 +147,11 @@ int hfmi_op_compose3(hfmi_ctx* ctx, hfmi_op* a, hfmi_op* b, hfmi_op* c, hfmi_op*
  *     reference's mult/matMvMult protocol plugs into the device solve. */
 typedef int (*hfmi_host_apply_fn)(void* user, const double* W_host, double* Y_host, int64_t N, int k);
 int hfmi_op_host_callback(hfmi_ctx* ctx, hfmi_host_apply_fn fn, void* user, int64_t N, hfmi_op** out);
+/*     For a callback that treats the vectors independently (a sparse-LU / Krylov solve per vector: prior.Rsolver,
+ *     activeSubspaceProjector.py:447-450; prior.Msolver): invoke it on slabs of `vectors` vectors.  The slabs go
+ *     through pinned double buffers and the device->host copy of slab i+1 and the host->device copy of slab i-1
+ *     overlap the host work on slab i.  0 (default) = one call with the whole block. */
+int hfmi_op_host_set_chunk(hfmi_op* op, int vectors);
 /*     average of a device operator over the ranks of a communicator is done by the
  *     caller between applies (CollectiveOperator, collectiveOperator.py:31-38): a
  *     post-apply hook called with the result block, e.g. an RCCL all-reduce. */
@@ -196,8 +209,10 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
 /* ---------------------------------------------------------------- Rayleigh-Ritz (a8)
  * np.linalg.eigh(T) + descending sort: symmetric k x k (host, row-major; the
  * symmetric part is used), eigenvalues descending (by |d| if sort_by_abs),
- * eigenvectors in the columns of V (row-major k x k).  One-workgroup parallel
- * cyclic Jacobi in LDS. */
+ * eigenvectors in the columns of V (row-major k x k).  k <= 256: one-workgroup parallel
+ * cyclic Jacobi in LDS (the Rayleigh-Ritz step of the double pass).  256 < k <= 4096: one-sided
+ * Jacobi over the whole GPU, one workgroup per column pair (the n x n Gram problem of the
+ * deterministic POD, la.eigh at PODProjector.py:821). */
 int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,
                        double* host_V);
 
@@ -242,6 +257,21 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * workgroups when it fits (short reductions: Q R^-1, U = Q V); ("ss", 0|1) route skinny x skinny contractions to
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized. */
 int hfmi_tuning_set(const char* key, int value);
+/* phases of hfmi_double_pass[_g], accumulated between hfmi_profile_begin and hfmi_profile_end (milliseconds, summed
+ * over the solves in the region; device phases by HIP events on the context's stream, the HOST_* legs by the host's
+ * wall clock -- they are part of the phase that called the host operator, normally BINV) */
+#define HFMI_PHASE_APPLY 0        /* power-iteration applies of A (incl. their all-reduce) */
+#define HFMI_PHASE_BINV 1         /* applies of B^-1 */
+#define HFMI_PHASE_QR 2           /* (B-)orthogonalisation */
+#define HFMI_PHASE_RAYLEIGH 3     /* second pass: T = Q^T A Q */
+#define HFMI_PHASE_EIG 4          /* small eigensolve */
+#define HFMI_PHASE_BACK 5         /* U = Q V */
+#define HFMI_PHASE_ALLREDUCE 6    /* rank reductions enqueued by the solve (inside APPLY / RAYLEIGH) */
+#define HFMI_PHASE_HOST_D2H 7     /* host callback: waiting for device -> pinned host copies */
+#define HFMI_PHASE_HOST_FN 8      /* host callback: inside the host function */
+#define HFMI_PHASE_HOST_H2D 9     /* host callback: issuing / draining pinned host -> device copies */
+#define HFMI_PHASE_COUNT 10
+int hfmi_profile_phases(hfmi_ctx* ctx, double* ms_out /* HFMI_PHASE_COUNT */);   /* after hfmi_profile_end */
 int hfmi_profile_begin(hfmi_ctx* ctx);
 int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int* kind, int64_t* shape, double* ms,
                      int64_t* launches, double* flops_per_launch, double* bytes_per_launch);
