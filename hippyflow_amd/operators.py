@@ -251,7 +251,7 @@ class HostCallbackOperator(DeviceOperator):
 
     ``chunk_vectors``: for black boxes that treat the vectors independently (solvers), the callback is invoked on
     slabs of that many vectors and the PCIe copies of the neighbouring slabs overlap the host work
-    (``hfmi_op_host_set_chunk``).  Default: solver-like objects (``solve`` / ``solve_block``) 16, everything else the
+    (``hfmi_op_host_set_chunk``).  Default: solver-like objects (``solve`` / ``solve_block``) 32, everything else the
     whole block in one call (a serialized-sampling Jacobian operator re-solves its PDEs on every call)."""
 
     def __init__(self, fn, N, ctx=None, chunk_vectors=None):
@@ -284,7 +284,7 @@ class HostCallbackOperator(DeviceOperator):
         self._cb = L.HOST_APPLY_FN(_cb)
         L.call("hfmi_op_host_callback", self.ctx.handle, self._cb, None, int(N), C.byref(self._op))
         if chunk_vectors is None:
-            chunk_vectors = 16 if solver_like else 0
+            chunk_vectors = 32 if solver_like else 0
         self.chunk_vectors = int(chunk_vectors)
         if self.chunk_vectors:
             L.call("hfmi_op_host_set_chunk", self._op, self.chunk_vectors)
