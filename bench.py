@@ -90,7 +90,7 @@ def build_workload(args, hf, rank, world):
             B = hf.CsrOperator(prior.R)
             Binv = hf.HostCallbackOperator(prior.Rsolver, N)
             desc.update({"B": "R = A M_l^-1 A, A = M + 0.1 K on a %d x %d P1 grid: CSR on the device, %.1f nnz/row" % (nx, ny, prior.R.nnz / N),
-                         "Binv": "host sparse LU of A (SuperLU), two triangular sweeps per vector on %d host threads, slabs of %d vectors "
+                         "Binv": "host sparse LU of A (SuperLU), two triangular sweeps per vector on %d host thread(s), slabs of %d vectors "
                                  "through pinned double buffers" % (prior.Rsolver.threads, Binv.chunk_vectors)})
     elif args.workload == "pod":
         N, n, r, p = 500000 // scale, 2048, 128, 10

@@ -171,14 +171,16 @@ def grid_stiffness_matrix(nx, ny):
 class SparseLUPriorSolver:
     """``prior.Rsolver`` of a bi-Laplacian prior, R^-1 = A^-1 M_l A^-1, as a HOST black box: sparse LU of A (SuperLU)
     and two triangular-solve sweeps per vector.  ``solve(y, x)`` is the reference's solver protocol on 1-D arrays;
-    ``solve_block(X)`` serves (N, k) slabs, the vectors spread over a thread pool (SuperLU releases the GIL)."""
+    ``solve_block(X)`` serves (N, k) slabs (optionally spread over a thread pool)."""
 
     def __init__(self, A, M_lumped, threads=None):
         import scipy.sparse.linalg as spla
         self.N = A.shape[0]
         self.lu = spla.splu(A.tocsc())
         self.Ml = np.asarray(M_lumped, dtype=np.float64)
-        self.threads = int(threads or min(32, os.cpu_count() or 1))
+        # one thread by default: scipy's SuperLU solve does not scale over Python threads (measured on a 256-core host:
+        # 74 vectors take 1.6 s on 1 thread, 6.3 s on 32, scripts/host_solver_probe.py)
+        self.threads = int(threads or 1)
         self._pool = None
         self.calls, self.vectors = 0, 0
 

@@ -154,7 +154,8 @@ def test_full_size_config4_prior_preconditioned_shard(ctx):
     # encoder = R decoder on the device
     enc = hf.MultiVector(N, r)
     hf.MatMvMult(B, U, enc)
-    assert rel(enc.to_dense(), RU) < 1e-12
+    # R u cancels heavily for the smooth eigenvectors (||R|| ||u|| / ||R u|| ~ 1e4): compare in the scale of |R| |u|
+    assert np.linalg.norm(enc.to_dense() - RU) < 1e-14 * np.linalg.norm(abs(prior.R) @ np.abs(Ud))
     Jh = wl.J.to_vectors()                                                          # (6400, 2e5): 10.2 GB on the host
     Oh = np.asfortranarray(Omega.to_dense())
     d_o, U_o = hp_o.double_pass_blas3(lambda W: np.asfortranarray(Jh.T @ (Jh @ W) / ns), Oh, r, s=1, apply_B=lambda W: prior.R @ W,
