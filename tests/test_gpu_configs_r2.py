@@ -171,7 +171,7 @@ def test_full_size_config4_prior_preconditioned_shard(ctx):
     # the whole-block callback (no slabs) gives the same result
     Binv1 = hf.HostCallbackOperator(prior.Rsolver, N, chunk_vectors=0)
     d1, U1 = hf.doublePassG(wl.operator, B, Binv1, Omega, r, s=1)
-    np.testing.assert_allclose(d1, d, rtol=1e-12)
+    np.testing.assert_allclose(d1, d, rtol=1e-8)      # SuperLU rounds a 74-vector solve and three slab solves differently; cond(R) amplifies it (observed 1.7e-9)
 
 
 def test_batched_equals_serialized_without_a_prior_solve_reference_tolerance(ctx):
