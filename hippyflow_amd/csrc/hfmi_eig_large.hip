@@ -1,14 +1,16 @@
-// Symmetric eigensolve for matrices too large for the one-workgroup Jacobi kernel (n > 256): one-sided (Hestenes)
-// Jacobi spread over the whole GPU.  Used by the deterministic POD of PODProjectorFromData when there are more than
-// 256 snapshots (the n x n Gram problem of PODProjector.py:812-833, la.eigh there).
+// Symmetric eigensolve for matrices too large for the one-workgroup Jacobi kernel (256 < n <= 4096): classical
+// two-sided Jacobi with a parallel (tournament) ordering, spread over the whole GPU.  Used by the deterministic POD of
+// PODProjectorFromData when there are more than 256 snapshots (the n x n Gram problem of PODProjector.py:812-833,
+// la.eigh there).
 //
-// Method: with s >= 0 chosen so that A + s I is positive definite, W = A + s I and V = I are rotated together from the
-// right, W <- W J, V <- V J, one plane rotation per column pair, until the columns of W are mutually orthogonal.  Then
-// W = (A + s I) V has orthogonal columns and V is orthogonal, so the columns of V are eigenvectors and
-// lambda_i = ||w_i|| - s.  The n/2 pairs of a round touch disjoint columns: one workgroup per pair, all pairs of a
-// round in one launch, rounds in a round-robin tournament; the host looks at the largest |cos| of a sweep once per
-// sweep.  Columns are contiguous, so every access is a coalesced stream; a column pair stays in registers between its
-// inner products and its rotation.
+// A round of the tournament holds n/2 disjoint index pairs (p, q).  T <- J^T T J with J the product of the round's
+// plane rotations is applied in two launches: (1) one workgroup per pair computes its rotation from T_pp, T_qq, T_pq
+// and rotates COLUMNS p, q of T and of the accumulated eigenvector matrix V (contiguous streams); (2) one workgroup
+// per column applies all the round's rotations to the ROW pairs inside its column.  A pair whose off-diagonal entry
+// is already negligible relative to its diagonal entries (|T_pq| <= eps sqrt(|T_pp T_qq|): high relative accuracy for
+// positive definite Gram matrices) is skipped; a sweep without a single rotation ends the iteration -- the host looks
+// at one counter per sweep.  (A one-sided Hestenes iteration on the columns of T was tried first: it works on T^2
+// implicitly and needed > 40 sweeps at cond(T) = 4e7; the two-sided form converges in 10-20.)
 #include <math.h>
 #include <string.h>
 
@@ -20,120 +22,76 @@
 
 namespace {
 constexpr int EL_THREADS = 256;
-constexpr int EL_MAXROWS = 16;        // rows per thread: n <= 4096
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// One round: workgroup b rotates columns (pairs[2b], pairs[2b+1]) of W and V.  offmax (device, double bits compared
-// as unsigned: all values are non-negative) collects max |w_i . w_j| / (||w_i|| ||w_j||) over the sweep.
-__global__ void __launch_bounds__(EL_THREADS) k_jacobi_large_round(double* __restrict__ W, double* __restrict__ V, int64_t ld, int n,
-                                                                   const int* __restrict__ pairs, unsigned long long* offmax,
-                                                                   double skip_tol) {
-  __shared__ double red[3][EL_THREADS / 64];
-  int ci = pairs[2 * blockIdx.x], cj = pairs[2 * blockIdx.x + 1];
-  if (ci >= n || cj >= n) return;     // the bye of an odd tournament
-  double* wi = W + (int64_t)ci * ld;
-  double* wj = W + (int64_t)cj * ld;
-  double a[EL_MAXROWS], b[EL_MAXROWS];
-  double aa = 0.0, bb = 0.0, ab = 0.0;
-#pragma unroll
-  for (int t = 0; t < EL_MAXROWS; ++t) {
-    const int r = threadIdx.x + t * EL_THREADS;
-    a[t] = r < n ? wi[r] : 0.0;
-    b[t] = r < n ? wj[r] : 0.0;
-    aa += a[t] * a[t];
-    bb += b[t] * b[t];
-    ab += a[t] * b[t];
+// launch 1 of a round: rotation of pair b from the current T, columns of T and V rotated, (c, s) kept for launch 2
+__global__ void __launch_bounds__(EL_THREADS) k_jacobi_large_cols(double* __restrict__ T, double* __restrict__ V, int64_t ld, int n,
+                                                                  const int* __restrict__ pairs, double2* __restrict__ cs,
+                                                                  unsigned int* __restrict__ nrot, double abs_floor) {
+  const int p = pairs[2 * blockIdx.x], q = pairs[2 * blockIdx.x + 1];
+  if (p >= n || q >= n) {             // the bye of an odd tournament
+    if (threadIdx.x == 0) cs[blockIdx.x] = make_double2(1.0, 0.0);
+    return;
   }
-  aa = wave_sum(aa);
-  bb = wave_sum(bb);
-  ab = wave_sum(ab);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    red[0][wave] = aa;
-    red[1][wave] = bb;
-    red[2][wave] = ab;
+  double* tp = T + (int64_t)p * ld;
+  double* tq = T + (int64_t)q * ld;
+  const double app = tp[p], aqq = tq[q], apq = tq[p];
+  const double eps = 2.220446049250313e-16;
+  const bool rotate = fabs(apq) > eps * sqrt(fabs(app * aqq)) && fabs(apq) > abs_floor;
+  if (!rotate) {
+    if (threadIdx.x == 0) cs[blockIdx.x] = make_double2(1.0, 0.0);
+    return;
   }
-  __syncthreads();
-  aa = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  bb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-  ab = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-  const double denom = sqrt(aa) * sqrt(bb);
-  const double cosv = denom > 0.0 ? fabs(ab) / denom : 0.0;
-  if (threadIdx.x == 0) atomicMax(offmax, (unsigned long long)__double_as_longlong(cosv));
-  if (!(cosv > skip_tol)) return;
-  // rotation that makes the two columns orthogonal (Rutishauser's formulas); the larger column ends up first
-  const double zeta = (bb - aa) / (2.0 * ab);
-  const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
-  // new norms: aa' = aa - tn ab, bb' = bb + tn ab; swap the roles if the second would be larger (de Rijk ordering)
-  const bool swap = (bb + tn * ab) > (aa - tn * ab);
-  double* vi = V + (int64_t)ci * ld;
-  double* vj = V + (int64_t)cj * ld;
-#pragma unroll
-  for (int t = 0; t < EL_MAXROWS; ++t) {
-    const int r = threadIdx.x + t * EL_THREADS;
-    if (r < n) {
-      const double x = c * a[t] - s * b[t], y = s * a[t] + c * b[t];
-      wi[r] = swap ? y : x;
-      wj[r] = swap ? x : y;
-      const double p = vi[r], q = vj[r];
-      const double xv = c * p - s * q, yv = s * p + c * q;
-      vi[r] = swap ? yv : xv;
-      vj[r] = swap ? xv : yv;
-    }
+  const double tau = (aqq - app) / (2.0 * apq);
+  const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+  if (threadIdx.x == 0) {
+    cs[blockIdx.x] = make_double2(c, s);
+    atomicAdd(nrot, 1u);
+  }
+  double* vp = V + (int64_t)p * ld;
+  double* vq = V + (int64_t)q * ld;
+  for (int r = threadIdx.x; r < n; r += EL_THREADS) {
+    const double x = tp[r], y = tq[r];
+    tp[r] = c * x - s * y;
+    tq[r] = s * x + c * y;
+    const double u = vp[r], w = vq[r];
+    vp[r] = c * u - s * w;
+    vq[r] = s * u + c * w;
   }
 }
-
-// out[j] = ||w_j||
-__global__ void __launch_bounds__(EL_THREADS) k_col_norms_large(const double* __restrict__ W, int64_t ld, int n, double* __restrict__ out) {
-  __shared__ double red[EL_THREADS / 64];
-  const double* w = W + (int64_t)blockIdx.x * ld;
-  double acc = 0.0;
-  for (int r = threadIdx.x; r < n; r += EL_THREADS) acc += w[r] * w[r];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(red[0] + red[1] + red[2] + red[3]);
+// launch 2: column blockIdx.x of T gets every rotation of the round applied to its row pairs
+__global__ void __launch_bounds__(EL_THREADS) k_jacobi_large_rows(double* __restrict__ T, int64_t ld, int n, int npairs,
+                                                                  const int* __restrict__ pairs, const double2* __restrict__ cs) {
+  double* col = T + (int64_t)blockIdx.x * ld;
+  for (int b = threadIdx.x; b < npairs; b += EL_THREADS) {
+    const double2 r = cs[b];
+    if (r.y == 0.0) continue;
+    const int p = pairs[2 * b], q = pairs[2 * b + 1];
+    const double x = col[p], y = col[q];
+    col[p] = r.x * x - r.y * y;
+    col[q] = r.y * x + r.x * y;
+  }
+}
+__global__ void k_diag_large(const double* __restrict__ T, int64_t ld, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = T[(int64_t)i * ld + i];
 }
 }  // namespace
 
 // host_T: n x n row-major symmetric (the symmetric part is used); host_d: n eigenvalues descending (by |d| if
 // sort_by_abs); host_V: n x n row-major, eigenvectors in the columns (may be null).
 int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V) {
-  if (n > EL_MAXROWS * EL_THREADS) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds %d", n, EL_MAXROWS * EL_THREADS);
+  if (n > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds 4096", n);
   const int64_t ld = round_up(n, 32);
   std::vector<double> A((size_t)ld * n, 0.0);      // column-major, symmetrised
-  double shift = 0.0;
-  {
-    double fro2 = 0.0, gersh = 0.0;
-    for (int j = 0; j < n; ++j) {
-      double off = 0.0;
-      for (int i = 0; i < n; ++i) {
-        const double v = 0.5 * (host_T[(size_t)i * n + j] + host_T[(size_t)j * n + i]);
-        A[(size_t)j * ld + i] = v;
-        fro2 += v * v;
-        if (i != j) off += fabs(v);
-      }
-      gersh = std::min(gersh, A[(size_t)j * ld + j] - off);
+  double fro2 = 0.0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      const double v = 0.5 * (host_T[(size_t)i * n + j] + host_T[(size_t)j * n + i]);
+      A[(size_t)j * ld + i] = v;
+      fro2 += v * v;
     }
-    // positive definite after the shift: every Gershgorin disc to the right of fro * 1e-3 (well away from zero so that
-    // no column of A + s I is numerically null); |lambda| <= fro bounds the loss of absolute accuracy to ~2 eps fro
-    const double fro = sqrt(fro2);
-    if (gersh < 1e-3 * fro) shift = std::min(fro, -gersh) + 1e-3 * fro;
-    if (!(fro > 0.0)) shift = 1.0;
-    for (int j = 0; j < n; ++j) A[(size_t)j * ld + j] += shift;
-  }
-  void *wv = nullptr, *pv = nullptr;
-  const size_t mat_bytes = (size_t)ld * n * sizeof(double);
-  HFMI_TRY(ctx_ws(ctx, WS_STAGE, 2 * mat_bytes + (size_t)n * sizeof(double) + 64, &wv));
-  double* W = (double*)wv;
-  double* V = W + (size_t)ld * n;
-  double* norms = V + (size_t)ld * n;
-  unsigned long long* offmax = (unsigned long long*)(norms + n);
+  const double fro = sqrt(fro2);
   // tournament schedule: m = n rounded up to even players, m - 1 rounds of m / 2 pairs
   const int m = (n + 1) & ~1, rounds = m - 1, np = m / 2;
   std::vector<int> sched((size_t)rounds * np * 2);
@@ -152,46 +110,45 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       pos[1] = last;
     }
   }
+  void *wv = nullptr, *pv = nullptr;
+  const size_t mat_bytes = (size_t)ld * n * sizeof(double);
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, 2 * mat_bytes + (size_t)n * sizeof(double) + (size_t)np * sizeof(double2) + 64, &wv));
+  double* T = (double*)wv;
+  double* V = T + (size_t)ld * n;
+  double* diag = V + (size_t)ld * n;
+  double2* cs = (double2*)(diag + n + (n & 1));    // 16-byte aligned
+  unsigned int* nrot = (unsigned int*)(cs + np);
   HFMI_TRY(ctx_ws(ctx, WS_MISC, sched.size() * sizeof(int), &pv));
   int* dpairs = (int*)pv;
   HIP_TRY(hipMemcpyAsync(dpairs, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(W, A.data(), mat_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(T, A.data(), mat_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));      // A and sched are pageable host memory
-  HFMI_TRY(launch_fill(ctx, V, ld, n, ld, 0.0, true));
-  {
-    std::vector<double> eye((size_t)ld * n, 0.0);
-    for (int j = 0; j < n; ++j) eye[(size_t)j * ld + j] = 1.0;
-    HIP_TRY(hipMemcpyAsync(V, eye.data(), mat_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-  }
-  const double eps = 2.220446049250313e-16;
-  const double tol = 8.0 * eps;                    // columns orthogonal to working precision
-  const int max_sweeps = 40;
+  std::fill(A.begin(), A.end(), 0.0);
+  for (int j = 0; j < n; ++j) A[(size_t)j * ld + j] = 1.0;
+  HIP_TRY(hipMemcpyAsync(V, A.data(), mat_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const double abs_floor = 1e-3 * 2.220446049250313e-16 * fro;   // entries this small are round-off of the matrix itself
+  const int max_sweeps = 60;
   int sweeps = 0;
-  double off = 1.0;
-  for (; sweeps < max_sweeps; ++sweeps) {
-    HIP_TRY(hipMemsetAsync(offmax, 0, sizeof(unsigned long long), ctx->stream));
-    for (int r = 0; r < rounds; ++r)
-      hipLaunchKernelGGL(k_jacobi_large_round, dim3(np), dim3(EL_THREADS), 0, ctx->stream, W, V, ld, n, dpairs + (size_t)r * np * 2, offmax,
-                         0.5 * tol);
-    HIP_TRY(hipGetLastError());
-    unsigned long long bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, offmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(&off, &bits, sizeof(off));
-    if (off <= tol) {
-      ++sweeps;
-      break;
+  unsigned int rotated = 1;
+  for (; sweeps < max_sweeps && rotated; ++sweeps) {
+    HIP_TRY(hipMemsetAsync(nrot, 0, sizeof(unsigned int), ctx->stream));
+    for (int r = 0; r < rounds; ++r) {
+      const int* rp = dpairs + (size_t)r * np * 2;
+      hipLaunchKernelGGL(k_jacobi_large_cols, dim3(np), dim3(EL_THREADS), 0, ctx->stream, T, V, ld, n, rp, cs, nrot, abs_floor);
+      hipLaunchKernelGGL(k_jacobi_large_rows, dim3(n), dim3(EL_THREADS), 0, ctx->stream, T, ld, n, np, rp, cs);
     }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&rotated, nrot, sizeof(rotated), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  if (!(off <= tol)) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig (n=%d): one-sided Jacobi did not converge in %d sweeps (max cosine %.2e)", n, max_sweeps, off);
-  hipLaunchKernelGGL(k_col_norms_large, dim3(n), dim3(EL_THREADS), 0, ctx->stream, W, ld, n, norms);
+  if (rotated) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig (n=%d): Jacobi still rotating %u pairs after %d sweeps", n, rotated, max_sweeps);
+  hipLaunchKernelGGL(k_diag_large, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, T, ld, n, diag);
   HIP_TRY(hipGetLastError());
   std::vector<double> lam(n);
-  HIP_TRY(hipMemcpyAsync(lam.data(), norms, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(lam.data(), diag, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(A.data(), V, mat_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (int j = 0; j < n; ++j) lam[j] -= shift;
   std::vector<int> perm(n);
   std::iota(perm.begin(), perm.end(), 0);
   std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {

@@ -210,8 +210,8 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
  * np.linalg.eigh(T) + descending sort: symmetric k x k (host, row-major; the
  * symmetric part is used), eigenvalues descending (by |d| if sort_by_abs),
  * eigenvectors in the columns of V (row-major k x k).  k <= 256: one-workgroup parallel
- * cyclic Jacobi in LDS (the Rayleigh-Ritz step of the double pass).  256 < k <= 4096: one-sided
- * Jacobi over the whole GPU, one workgroup per column pair (the n x n Gram problem of the
+ * cyclic Jacobi in LDS (the Rayleigh-Ritz step of the double pass).  256 < k <= 4096: two-sided
+ * Jacobi over the whole GPU, one workgroup per index pair of a round (the n x n Gram problem of the
  * deterministic POD, la.eigh at PODProjector.py:821). */
 int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,
                        double* host_V);

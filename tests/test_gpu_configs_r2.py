@@ -223,9 +223,10 @@ def test_sym_eig_beyond_one_workgroup(ctx, n):
     d, V = hf.sym_eig_small(G)
     w = np.linalg.eigvalsh(G)[::-1]
     np.testing.assert_allclose(d, w, rtol=1e-10, atol=1e-12 * w[0])
-    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+    assert np.abs(V.T @ V - np.eye(n)).max() < 2e-12
     assert np.abs(G @ V - V * d).max() < 1e-11 * w[0]
-    S = 0.5 * (rng.standard_normal((n, n)) + rng.standard_normal((n, n)).T)          # indefinite
+    S = rng.standard_normal((n, n))
+    S = 0.5 * (S + S.T)                                                              # indefinite
     d2, V2 = hf.sym_eig_small(S)
     w2 = np.linalg.eigvalsh(S)[::-1]
     np.testing.assert_allclose(d2, w2, atol=1e-11 * np.abs(w2).max())
