@@ -43,7 +43,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="as", choices=["as", "pod", "kle"])
+    ap.add_argument("--workload", default="as", choices=["as", "pod", "kle", "dipnet"],
+                    help="as / pod / kle: BASELINE configs 4 / 3 / 2 of the projector path; dipnet: config 5, the projected-network "
+                         "surrogate (PyTorch-ROCm bf16) fed by device AS x POD solves -- a separate JSON line with its own metric")
     ap.add_argument("--prior", action="store_true",
                     help="config 4, prior-preconditioned (the reference's default): doublePassG with B = R = A M_l^-1 A as CSR "
                          "on the device and B^-1 = a host sparse-LU callback")
@@ -319,8 +321,29 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
 
 
 # ---------------------------------------------------------------------------------------------- the benchmark
+def dipnet_line(args):
+    """Config 5: r_in = 50 AS x r_out = 50 POD projected residual network, bf16 training on one MI355X, relative l2 test
+    error next to the fp32 CPU run of the same PyTorch restatement (keras parity is unpinned: TensorFlow cannot run here)."""
+    import tempfile
+    from hippyflow_amd import workloads
+    from hippyflow_amd import surrogate
+    scale = 4 if args.quick else 1
+    wl = workloads.dipnet_workload(dM=20000 // scale, dQ=400, hidden=80, n_train=8192 // scale, n_test=1024, ns=64)
+    with tempfile.TemporaryDirectory() as tmp:
+        res = surrogate.run_config5(wl, tmp, r_in=50, r_out=50, epochs=max(1, args.steps * 3), batch_size=256)
+    out = {"metric": "projected-network surrogate training throughput (samples/s) + relative l2 test error", "value": res["gpu_samples_per_second"],
+           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast (fp32 parameters and optimiser state)", "data": "synthetic nonlinear map q = W2 tanh(W1^T m)",
+           "config": {"workload": "config5 DIPNet: ProjectedLowRankResidualNetwork, r_in=50 (device AS solve) x r_out=50 (device POD solve), "
+                                  "dM=%d, dQ=%d, %d training points, %d epochs of Adam" % (wl.dM, wl.dQ, wl.m_train.shape[0], max(1, args.steps * 3))},
+           "result": res}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.workload == "dipnet":
+        return dipnet_line(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this parent touches no GPU; it starts N fresh child interpreters (one per
         # device, nothing is re-exec'ed) and rank 0's JSON line arrives on the inherited stdout

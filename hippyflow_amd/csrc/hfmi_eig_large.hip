@@ -127,7 +127,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   for (int j = 0; j < n; ++j) A[(size_t)j * ld + j] = 1.0;
   HIP_TRY(hipMemcpyAsync(V, A.data(), mat_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  const double abs_floor = 1e-3 * 2.220446049250313e-16 * fro;   // entries this small are round-off of the matrix itself
+  // entries below eps ||T||_F / 10 are round-off of the matrix itself (a rank-deficient Gram matrix -- mean-shifted or
+  // low-rank snapshot sets -- has a whole block of them, which the relative test alone would rotate for ever); what is
+  // left unrotated perturbs an eigenvalue by at most n eps ||T||_F / 10, the absolute accuracy of LAPACK's eigh
+  const double abs_floor = 0.1 * 2.220446049250313e-16 * fro;
   const int max_sweeps = 60;
   int sweeps = 0;
   unsigned int rotated = 1;

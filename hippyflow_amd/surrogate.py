@@ -147,3 +147,66 @@ def train_surrogate(model, m_train, q_train, epochs=50, batch_size=128, lr=1e-3,
         if verbose:
             print("epoch %d  mse %.4e" % (ep, history[-1]))
     return history
+
+
+def relative_l2_error(model, m, q, batch=4096):
+    """mean_i ||q_i - f(m_i)||_2 / ||q_i||_2 on held-out data (confusion_training.py:139-217 prints 1 - this)."""
+    return 1.0 - l2_accuracy(model, m, q, batch)
+
+
+def run_config5(wl, out_dir, r_in=50, r_out=50, epochs=30, batch_size=256, lr=2e-3, ranks=(16, 16), device=None, seed=0, verbose=False):
+    """BASELINE config 5 end to end: device AS(r_in) and POD(r_out) solves of the projector path -> the .npy files the
+    reference's projectors write -> ``get_projectors`` / ``modify_projectors`` (confusion_utilities.py:115-225) ->
+    ``ProjectedLowRankResidualNetwork`` trained under bf16 autocast on the GPU, next to the same architecture, data and
+    seed trained in fp32 on the CPU.  Returns a dict with both relative-l2 test errors and the GPU training throughput."""
+    import time
+
+    from . import ActiveSubspaceParameterList, ActiveSubspaceProjector, PODParameterList, PODProjector
+    from .io_utils import get_projectors, modify_projectors
+    out_dir = out_dir if out_dir.endswith("/") else out_dir + "/"
+    ap = ActiveSubspaceParameterList()
+    ap["rank"], ap["oversampling"], ap["samples_per_process"] = r_in, 10, wl.ns
+    ap["serialized_sampling"], ap["verbose"], ap["output_directory"] = False, False, out_dir
+    t0 = time.perf_counter()
+    asp = ActiveSubspaceProjector(wl.observable, None, parameters=ap)
+    d_as, _, _ = asp.construct_input_subspace(prior_preconditioned=False)
+    pp = PODParameterList()
+    pp["rank"], pp["oversampling"], pp["verbose"], pp["output_directory"] = r_out, 10, False, out_dir
+    pod = PODProjector(wl.observable, None, parameters=pp)
+    pod.set_snapshots(wl.q_train[:2048].astype(np.float64))
+    pod.construct_subspace()
+    t_proj = time.perf_counter() - t0
+    projectors = get_projectors(out_dir, fixed_input_rank=r_in, fixed_output_rank=r_out)
+    input_projector, output_projector = modify_projectors(projectors, 'as', 'pod')
+
+    def make():
+        torch.manual_seed(seed)
+        return ProjectedLowRankResidualNetwork(input_projector, output_projector, ranks=list(ranks))
+
+    res = {"AS_eigenvalues_first_last": [float(d_as[0]), float(d_as[-1])], "POD_eigenvalues_first_last": [float(pod.d[0]), float(pod.d[-1])],
+           "projector_seconds": t_proj, "input_projector_shape": list(input_projector.shape),
+           "output_projector_shape": list(output_projector.shape)}
+    dev = device or (torch.device("cuda", 0) if torch.cuda.is_available() else None)
+    if dev is not None:
+        net = make().to(dev)
+        mt, qt = torch.from_numpy(wl.m_train).to(dev), torch.from_numpy(wl.q_train).to(dev)
+        train_surrogate(net, mt[:batch_size * 4], qt[:batch_size * 4], epochs=1, batch_size=batch_size, lr=0.0, seed=seed)   # warm-up, no update
+        net = make().to(dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        hist = train_surrogate(net, mt, qt, epochs=epochs, batch_size=batch_size, lr=lr, bf16=True, seed=seed, verbose=verbose)
+        torch.cuda.synchronize(dev)
+        t_train = time.perf_counter() - t0
+        res.update(gpu_bf16_rel_l2_test_error=relative_l2_error(net, torch.from_numpy(wl.m_test).to(dev), torch.from_numpy(wl.q_test).to(dev)),
+                   gpu_train_seconds=t_train, gpu_samples_per_second=epochs * wl.m_train.shape[0] / t_train,
+                   gpu_final_train_mse=hist[-1], gpu_first_train_mse=hist[0])
+    cpu = make()
+    t0 = time.perf_counter()
+    hist = train_surrogate(cpu, torch.from_numpy(wl.m_train), torch.from_numpy(wl.q_train), epochs=epochs, batch_size=batch_size, lr=lr,
+                           bf16=False, seed=seed)
+    t_cpu = time.perf_counter() - t0
+    res.update(cpu_fp32_rel_l2_test_error=relative_l2_error(cpu, torch.from_numpy(wl.m_test), torch.from_numpy(wl.q_test)),
+               cpu_train_seconds=t_cpu, cpu_samples_per_second=epochs * wl.m_train.shape[0] / t_cpu, cpu_final_train_mse=hist[-1])
+    # the un-trained network (projectors only) and the best rank-r_out linear output reconstruction, for scale
+    res["untrained_rel_l2_test_error"] = relative_l2_error(make(), torch.from_numpy(wl.m_test), torch.from_numpy(wl.q_test))
+    return res

@@ -288,3 +288,50 @@ def kle_workload(nx, ny, latent=256, rate=0.08, seed=2, ctx=None):
     wl.C_operator = npToDeviceOperator(wl.C)
     wl.M_operator = CsrOperator(wl.M, ctx=ctx)
     return wl
+
+
+class _DipnetObservable:
+    """The observable hooks the projectors ask for (projectors.py docstring), backed by the synthetic map."""
+
+    def __init__(self, wl):
+        self.wl = wl
+
+    def jacobian_data(self, n):
+        assert n == self.wl.ns
+        return self.wl.J, self.wl.ns, self.wl.dQ
+
+    def input_dimension(self):
+        return self.wl.dM
+
+    def output_dimension(self):
+        return self.wl.dQ
+
+    def sample_observables(self, n, prior, noise):
+        return self.wl.q_train[:n].astype(np.float64)
+
+
+def dipnet_workload(dM=20000, dQ=400, hidden=80, n_train=8192, n_test=1024, ns=64, rate=0.08, seed=5, ctx=None):
+    """BASELINE config 5's data source in synthetic form: a smooth nonlinear parameter-to-observable map
+    q(m) = W2 tanh(W1^T m) with W1 = P diag(sigma) (P: dM x hidden orthonormal in HBM, sigma_j = exp(-rate j)) and
+    Gaussian W2, inputs m ~ N(0, I).  Its Jacobian at m_i is J_i = W2 diag(1 - tanh^2(W1^T m_i)) W1^T, so the stacked
+    Jacobians of ``ns`` training points are one expansion of the block P -- the same layout the AS projector consumes
+    (the reference obtains them from PDE solves, activeSubspaceProjector.py:347-397)."""
+    ctx = ctx or L.Context.default()
+    rng = np.random.default_rng(seed)
+    wl = Workload()
+    wl.dM, wl.dQ, wl.hidden, wl.ns = int(dM), int(dQ), int(hidden), int(ns)
+    wl.P = _orthonormal_block(dM, hidden, seed, 400, ctx)
+    wl.sigma = np.exp(-rate * np.arange(hidden))
+    Ph = wl.P.to_dense()                                             # dM x hidden
+    wl.W1 = (Ph * wl.sigma).astype(np.float32)
+    wl.W2 = (rng.standard_normal((dQ, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    m = rng.standard_normal((n_train + n_test, dM)).astype(np.float32)
+    z = m @ wl.W1
+    q = np.tanh(z) @ wl.W2.T
+    wl.m_train, wl.q_train, wl.m_test, wl.q_test = m[:n_train], q[:n_train], m[n_train:], q[n_train:]
+    # J_i = (W2 D_i diag(sigma)) P^T: row o of sample i is vector i*dQ + o of the block
+    D = 1.0 - np.tanh(z[:ns].astype(np.float64)) ** 2                # ns x hidden
+    S = (wl.W2.astype(np.float64)[None, :, :] * (D * wl.sigma)[:, None, :]).reshape(ns * dQ, hidden).T   # hidden x (ns*dQ)
+    wl.J = _expand(wl.P, np.ascontiguousarray(S), ctx)
+    wl.observable = _DipnetObservable(wl)
+    return wl

@@ -73,3 +73,19 @@ def test_bf16_training_on_gpu_matches_fp32_evaluation():
     y_fp32 = cpu(torch.from_numpy(m[3584:3600])).detach()
     assert float(torch.linalg.norm(y_bf16 - y_fp32) / torch.linalg.norm(y_fp32)) < 3e-2
     assert abs(l2_accuracy(cpu, torch.from_numpy(m[3584:]), torch.from_numpy(q[3584:])) - acc_gpu) < 1e-3
+
+
+@pytest.mark.gpu
+def test_config5_end_to_end_device_projectors_feed_the_network(tmp_path):
+    """BASELINE config 5: device AS(50) and POD(50) solves -> the reference's .npy files -> get_projectors /
+    modify_projectors -> ProjectedLowRankResidualNetwork, bf16 on the GPU vs the same restatement in fp32 on the CPU."""
+    from hippyflow_amd import workloads
+    from hippyflow_amd.surrogate import run_config5
+    wl = workloads.dipnet_workload(dM=6000, dQ=200, hidden=80, n_train=4096, n_test=512, ns=32)
+    res = run_config5(wl, str(tmp_path), r_in=50, r_out=50, epochs=25, batch_size=128, lr=2e-3)
+    assert res["input_projector_shape"] == [6000, 50] and res["output_projector_shape"] == [200, 50]
+    assert res["AS_eigenvalues_first_last"][0] > res["AS_eigenvalues_first_last"][1] > 0
+    gpu, cpu, raw = res["gpu_bf16_rel_l2_test_error"], res["cpu_fp32_rel_l2_test_error"], res["untrained_rel_l2_test_error"]
+    assert gpu < 0.5 * raw and cpu < 0.5 * raw, res                       # training on the projected spaces learns the map
+    assert abs(gpu - cpu) < 0.03, res                                     # bf16 autocast tracks the fp32 run
+    assert res["gpu_samples_per_second"] > 0
