@@ -149,6 +149,7 @@ int launch_tsgemm_tn(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
 // skinny x skinny variant (hfmi_skinny.hip): both operands staged through LDS, m, k <= 160 and m + k <= 288 columns
 bool tsgemm_ss_applicable(int m, int k, bool same);
 void tsgemm_ss_set_percu(int v);
+void tsgemm_ss_set_blocked(int v);
 int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
                      int64_t N, double scale, double beta, double* C, int64_t rs, int64_t cs, int nsplit_req);
 // C[i*rs + j*cs] = scale * sum_sp part[sp][..] + beta * C, fixed summation order

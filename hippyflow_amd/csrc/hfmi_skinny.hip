@@ -260,6 +260,175 @@ __global__ __launch_bounds__(SS_THREADS, (TPW <= 4 ? 4 : 2)) void k_tsgemm_ss(
   }
 }
 
+// =====================================================================================
+// Blocked variant for two distinct operands with at least 2 x 4 output tiles (the MFMA-bound and the transition shapes
+// of the north-star kernel point: n = 32 ... 138 snapshots against k = 74 / 84 / 138 probe vectors).
+//
+// k_tsgemm_ss deals the 16 x 16 output tiles round-robin, so EVERY MFMA pair reads both of its fragments from LDS
+// (two ds_read_b128 per 128 matrix-pipe cycles per wave: about half of the LDS pipe).  Here the RT x CT
+// tile grid is cut into a 2 x 4 grid of rectangular blocks, one per wave, with compile-time block shapes: a wave with an
+// RB x CB block reads RB + CB fragments per k-step group and issues 2 RB CB MFMAs from them (5 x 3 block: 8 reads for 30
+// MFMAs instead of 30).  Waves w and w + 4 share a SIMD; the second row of blocks walks the column groups backwards so that
+// a wide block shares its SIMD with a narrow one.  Staging, LDS image and partial-tile output are those of k_tsgemm_ss.
+template <int RB, int CB, int NQ>
+__device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* __restrict__ Lnext, const int la, const int la1,
+                                          const int (&toa)[RB], const int (&tob)[CB], d4 (&acc)[RB][CB], const d2 (&r)[NQ],
+                                          const int dst0) {
+  constexpr int CT = NQ * 32;
+  d2 fa[2][RB], fb[2][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) fa[0][i] = *reinterpret_cast<const d2*>(L + toa[i] + la);
+#pragma unroll
+  for (int j = 0; j < CB; ++j) fb[0][j] = *reinterpret_cast<const d2*>(L + tob[j] + la);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (it + 1 < 4) {
+      const int lx = ((it + 1) & 1) ? la1 : la;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) fa[(it + 1) & 1][i] = *reinterpret_cast<const d2*>(L + toa[i] + lx + (it + 1) * (8 * CT));
+#pragma unroll
+      for (int j = 0; j < CB; ++j) fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(L + tob[j] + lx + (it + 1) * (8 * CT));
+    }
+    if (it >= 2) {   // the next stage goes to the other LDS buffer under the MFMAs of the last two groups
+      constexpr int H = (NQ + 1) / 2;
+#pragma unroll
+      for (int q = (it - 2) * H; q < ((it - 2) * H + H < NQ ? (it - 2) * H + H : NQ); ++q)
+        *reinterpret_cast<d2*>(Lnext + dst0 + q * 64) = r[q];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = MFMA_F64(fa[it & 1][i].x, fb[it & 1][j].x, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = MFMA_F64(fa[it & 1][i].y, fb[it & 1][j].y, acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int RB, int CB, int NQ>
+__device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* __restrict__ ptab, const int nstages, const int col0,
+                                        const int off, const int dst0, const int la, const int la1, const int row_tile0,
+                                        const int col_tile0, const int bcol0, double* __restrict__ P, const int kpad, const int r16,
+                                        const int kk) {
+  constexpr int BUF = NQ * 32 * SS_BK;
+  int toa[RB], tob[CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) toa[i] = (row_tile0 + i) * 32;
+#pragma unroll
+  for (int j = 0; j < CB; ++j) tob[j] = (bcol0 + (col_tile0 + j) * 16) * 2;
+  d4 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  // two register sets: while stage s is consumed, stage s+1 (already fetched) is written to the other LDS buffer and
+  // stage s+2 is on its way -- one stage of MFMAs is shorter than the HBM latency for the small blocks
+  d2 reg[2][NQ];
+  auto stage_load = [&](d2(&rr)[NQ], int s) {
+    if (s > nstages - 1) s = nstages - 1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) rr[q] = SS_LOAD(reinterpret_cast<gd2ptr>(ptab[col0 + 32 * q] + ((int64_t)s * SS_BK + off)));
+  };
+  if (nstages > 0) {
+    stage_load(reg[0], 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) *reinterpret_cast<d2*>(lds + dst0 + q * 64) = reg[0][q];
+    stage_load(reg[0], 1);
+    __syncthreads();
+  }
+  for (int s = 0; s < nstages; s += 2) {
+    stage_load(reg[1], s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    ssb_stage<RB, CB, NQ>(lds, lds + BUF, la, la1, toa, tob, acc, reg[0], dst0);
+    __syncthreads();
+    if (s + 1 < nstages) {
+      stage_load(reg[0], s + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      ssb_stage<RB, CB, NQ>(lds + BUF, lds, la, la1, toa, tob, acc, reg[1], dst0);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        P[(int64_t)((row_tile0 + i) * 16 + kk + 4 * e) * kpad + (col_tile0 + j) * 16 + r16] = acc[i][j][e];
+}
+
+template <int RT, int CTL, int NQ>
+__global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __restrict__ A, int64_t lda, int m,
+                                                              const double* __restrict__ B, int64_t ldb, int k, int64_t Npad,
+                                                              int64_t chunk, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CT = NQ * 32;
+  constexpr int BUF = CT * SS_BK;
+  constexpr int RB0 = (RT + 1) / 2, RB1 = RT / 2;
+  constexpr int CBF = CTL / 4, NBIG = CTL % 4, CBC = CBF + (NBIG ? 1 : 0);
+  static_assert(RB1 >= 1 && CBF >= 1, "blocked variant needs at least 2 x 4 tiles");
+  double* lds = reinterpret_cast<double*>(smem);
+  gdptr* ptab = reinterpret_cast<gdptr*>(lds + 2 * BUF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kk = lane >> 4;
+  constexpr int acols = RT * 16, ctot = (RT + CTL) * 16;
+  const int64_t t_begin = (int64_t)blockIdx.x * chunk;
+  int64_t t_end = t_begin + chunk;
+  if (t_end > Npad) t_end = Npad;
+  const int nstages = t_end > t_begin ? (int)((t_end - t_begin) / SS_BK) : 0;
+  const int col0 = tid >> 4, cq = tid & 15;
+  const int dst0 = (cq * CT + (col0 ^ (cq & 7))) * 2;
+  for (int v = tid; v < CT; v += SS_THREADS) ptab[v] = ss_colptr(v, ctot, acols, A, lda, m, B, ldb, k) + t_begin;
+  __syncthreads();
+  const int la = (kk * CT + (r16 ^ kk)) * 2, la1 = (kk * CT + (r16 ^ (kk + 4))) * 2;
+  const int rg = wave >> 2;
+  const int cg = rg ? 3 - (wave & 3) : (wave & 3);
+  const int row_tile0 = rg ? RB0 : 0;
+  const int col_tile0 = cg * CBF + (cg < NBIG ? cg : NBIG);
+  const bool wide = cg < NBIG;
+  constexpr int kpad = CTL * 16;
+  double* P = part + (int64_t)blockIdx.x * acols * kpad;
+#define SSB_RUN(RBV, CBV) ssb_run<RBV, CBV, NQ>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk)
+  if (rg == 0) {
+    if (NBIG && wide) SSB_RUN(RB0, CBC);
+    else SSB_RUN(RB0, CBF);
+  } else {
+    if (NBIG && wide) SSB_RUN(RB1, CBC);
+    else SSB_RUN(RB1, CBF);
+  }
+#undef SSB_RUN
+}
+
+template <int RT, int CTL>
+static int ssb_launch(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t Npad,
+                      int64_t chunk, int nsplit, double* part) {
+  constexpr int NQ = (RT + CTL + 1) / 2;
+  const size_t shmem = 2 * (size_t)NQ * 32 * SS_BK * sizeof(double) + (size_t)NQ * 32 * sizeof(double*);
+  auto kern = k_tsgemm_ssb<RT, CTL, NQ>;
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kern, dim3(nsplit), dim3(SS_THREADS), shmem, ctx->stream, A, lda, m, B, ldb, k, Npad, chunk, part);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+static int g_ss_blocked = 1;   // A/B knob "ss_blocked"
+void tsgemm_ss_set_blocked(int v) { g_ss_blocked = v; }
+// rt <= ct after the caller's role swap
+static bool ssb_has_instance(int rt, int ct) { return rt >= 2 && rt <= ct && (ct == 5 || ct == 6 || ct == 9) && rt + ct <= 18; }
+static int ssb_dispatch(hfmi_ctx* ctx, int rt, int ct, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,
+                        int64_t Npad, int64_t chunk, int nsplit, double* part) {
+#define SSB_CASE(R, Cc) \
+  if (rt == R && ct == Cc) return ssb_launch<R, Cc>(ctx, A, lda, m, B, ldb, k, Npad, chunk, nsplit, part);
+  SSB_CASE(2, 5) SSB_CASE(3, 5) SSB_CASE(4, 5) SSB_CASE(5, 5)
+  SSB_CASE(2, 6) SSB_CASE(3, 6) SSB_CASE(4, 6) SSB_CASE(5, 6) SSB_CASE(6, 6)
+  SSB_CASE(2, 9) SSB_CASE(3, 9) SSB_CASE(4, 9) SSB_CASE(5, 9) SSB_CASE(6, 9) SSB_CASE(7, 9) SSB_CASE(8, 9) SSB_CASE(9, 9)
+#undef SSB_CASE
+  HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_ssb: no instance for %d x %d tiles", rt, ct);
+}
+
 constexpr int ss_pf(int tpw, int nq) { return (tpw <= 4 && nq <= 6) ? 2 : 1; }
 
 template <int TPW, int NQ>
@@ -291,15 +460,17 @@ int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   const int64_t Npad = round_up(N, SS_BK);
   if (lda % 32 != 0 || ldb % 32 != 0 || lda < Npad || ldb < Npad)
     HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_ss: leading dimensions must be multiples of 32 and >= round_up(N,32)");
+  const bool swap = !same && rt > ct;                      // the blocked variant wants rt <= ct: exchange the operand roles
+  const bool blocked = !same && g_ss_blocked && ssb_has_instance(swap ? ct : rt, swap ? rt : ct);
   const int tpw = ((same ? rt * (rt + 1) / 2 : rt * ct) + 7) / 8;
   const int nq = (ctot + 31) / 32;  // staged columns are padded to 32 (one 16-byte chunk per thread per 32 columns)
   // unpadded stage buffers: one for the HBM-bound variants (PF = 2), two plus the column pointer table otherwise
   const size_t stage_bytes = (size_t)nq * 32 * SS_BK * sizeof(double);
-  const size_t shmem = ss_pf(tpw, nq) == 2 ? stage_bytes : 2 * stage_bytes + (size_t)nq * 32 * sizeof(double*);
+  const size_t shmem = (ss_pf(tpw, nq) == 2 && !blocked) ? stage_bytes : 2 * stage_bytes + (size_t)nq * 32 * sizeof(double*);
   // workgroups resident per CU: LDS (160 KB) and registers (TPW <= 4 compiles for 4 waves per SIMD = 2 workgroups)
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   int per_cu = (int)((160 * 1024) / shmem);
-  const int reg_cap = tpw <= 4 ? g_ss_percu : 1;
+  const int reg_cap = (tpw <= 4 && !blocked) ? g_ss_percu : 1;
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (per_cu < 1) per_cu = 1;
   const int64_t stages = Npad / SS_BK;
@@ -316,6 +487,16 @@ int launch_tsgemm_ss(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const d
   if (same && pidx >= 0) {   // symmetric output from ONE operand: algorithmic work N k (k + 1) flops, 8 (N k + k^2) bytes
     ctx->prof[pidx].flops = (double)N * k * (k + 1);
     ctx->prof[pidx].bytes = 8.0 * ((double)N * k + (double)k * k);
+  }
+  if (blocked) {
+    if (swap)
+      HFMI_TRY(ssb_dispatch(ctx, ct, rt, B, ldb, k, A, lda, m, Npad, chunk, nsplit, part));
+    else
+      HFMI_TRY(ssb_dispatch(ctx, rt, ct, A, lda, m, B, ldb, k, Npad, chunk, nsplit, part));
+    prof_stop(ctx, pidx);
+    // swapped roles: the partial tiles hold (A^T B)^T = B^T A, k x m with row stride mpad
+    return swap ? launch_reduce_partials(ctx, part, nsplit, (int64_t)mpad * kpad, mpad, true, m, k, scale, beta, C, rs, cs)
+                : launch_reduce_partials(ctx, part, nsplit, (int64_t)mpad * kpad, kpad, false, m, k, scale, beta, C, rs, cs);
   }
   int rc = HFMI_ERR_INVALID;
 #define SS_CASE(T, Q)                                                                                              \
