@@ -483,6 +483,11 @@ def main():
         out["ms_per_step_in_mfma_kernels"] = mfma_ms
     try:
         out["device_peaks_measured"] = ctx.bench_peaks()
+        if "roofline" in out:     # the same fraction against what this box sustains in this job (constant-operand MFMA loop / copy kernel)
+            pm = out["device_peaks_measured"]
+            out["roofline"]["frac_of_in_job_measured_peak"] = (out["roofline"]["fp64_mfma_frac"] * FP64_MFMA_PEAK_TFLOPS / pm["mfma_f64_tflops"]
+                                                               if out["roofline"]["bound"] == "mfma" else
+                                                               out["roofline"]["algorithmic_gbs"] / pm["hbm_copy_gbs"])
     except Exception as exc:   # the micro-benchmark is informative only
         out["device_peaks_measured"] = {"error": str(exc)}
 

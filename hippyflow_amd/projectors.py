@@ -118,7 +118,11 @@ def KLEParameterList():
     return ParameterList(parameters)
 
 
-def _is_root():
+def _is_root(collective=None):
+    """Rank 0 of the sample-parallel communicator writes files and prints (the reference tests
+    ``mesh_constructor_comm.rank == 0`` / world rank 0, activeSubspaceProjector.py:470-480)."""
+    if collective is not None and hasattr(collective, "rank"):
+        return int(collective.rank()) == 0
     return int(os.environ.get("RANK", "0")) == 0
 
 
@@ -266,10 +270,10 @@ class ActiveSubspaceProjector:
             self._output_subspace_construction_time = time.time() - t0
             result = (self.d_NG, output_decoder, output_encoder)
 
-        if self.parameters['verbose'] and _is_root():
+        if self.parameters['verbose'] and _is_root(self.collective):
             which = 'Input' if operation == 'JTJ' else 'Output'
             print((which + ' subspace construction took ' + str(time.time() - t0)[:5] + ' s').center(80))
-        if self.parameters['save_and_plot'] and _is_root() and self.parameters['output_directory'] is not None:
+        if self.parameters['save_and_plot'] and _is_root(self.collective) and self.parameters['output_directory'] is not None:
             name = 'AS_' + str(int(self.parameters['samples_per_process'] * self.collective.size()))
             if name_suffix is not None:
                 assert type(name_suffix) is str
@@ -405,9 +409,9 @@ class KLEProjector:
         else:
             raise ValueError(orthogonality)
         self._subspace_construction_time = time.time() - t0
-        if self.parameters['verbose'] and _is_root():
+        if self.parameters['verbose'] and _is_root(self.collective):
             print('Construction of input subspace took ', self._subspace_construction_time, 's')
-        if _is_root() and self.parameters['save_and_plot'] and self.parameters['output_directory'] is not None:
+        if _is_root(self.collective) and self.parameters['save_and_plot'] and self.parameters['output_directory'] is not None:
             _save(self.parameters['output_directory'], self.parameters['input_decoder_name'], mv_to_dense(self.V_KLE))
             _save(self.parameters['output_directory'], 'KLE_d', self.d_KLE)
         return self.d_KLE, kle_decoder, kle_encoder
@@ -522,9 +526,9 @@ class PODProjector:
         Omega_POD = _draw_omega(X.size(), self.parameters['rank'] + self.parameters['oversampling'], self.collective, self.ctx)
         self.d, self.U_MV = doublePass(GlobalPODOperator, Omega_POD, self.parameters['rank'], s=1)   # :376
         self._subspace_construction_time = time.time() - t0
-        if self.parameters['verbose'] and _is_root():
+        if self.parameters['verbose'] and _is_root(self.collective):
             print('Construction of POD subspace took ', self._subspace_construction_time, 's')
-        if _is_root() and self.parameters['output_directory'] is not None:
+        if _is_root(self.collective) and self.parameters['output_directory'] is not None:
             _save(self.parameters['output_directory'], 'POD_projector', mv_to_dense(self.U_MV))
             _save(self.parameters['output_directory'], 'POD_d', self.d)
 
