@@ -196,15 +196,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         load_a(a[(it + 1) & 1], ts + 8 * AH * (it + 1));
-        // probe bit 3 (A/B, results stay correct): the next stage goes to LDS BEFORE the last iteration's MFMAs, so the
-        // stores drain under them and the barrier finds them complete
-        if ((probe & 8) && it == NIT - 1 && has_next && !(probe & 2)) stage_store(lds + ((s + 1) & 1) * BUFD);
 #pragma unroll
         for (int h = 0; h < AH; ++h) mma(a[it & 1][h], L, it * AH + h, it * AH + h + 1 < NH);
       }
       if (!(probe & 2)) {
-      if (has_next && !(probe & 8)) stage_store(lds + ((s + 1) & 1) * BUFD);
-      if (!(probe & 4)) __syncthreads();   // probe bit 2: staging kept, barrier dropped (racy: timing only)
+      if (has_next) stage_store(lds + ((s + 1) & 1) * BUFD);
+      __syncthreads();
       }
     }
   }

@@ -308,7 +308,7 @@ __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* 
   }
 }
 
-template <int RB, int CB, int NQ>
+template <int RB, int CB, int NQ, int PF>
 __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* __restrict__ ptab, const int nstages, const int col0,
                                         const int off, const int dst0, const int la, const int la1, const int row_tile0,
                                         const int col_tile0, const int bcol0, double* __restrict__ P, const int kpad, const int r16,
@@ -326,7 +326,7 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     for (int j = 0; j < CB; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   // two register sets: while stage s is consumed, stage s+1 (already fetched) is written to the other LDS buffer and
   // stage s+2 is on its way -- one stage of MFMAs is shorter than the HBM latency for the small blocks
-  d2 reg[2][NQ];
+  d2 reg[PF][NQ];
   auto stage_load = [&](d2(&rr)[NQ], int s) {
     if (s > nstages - 1) s = nstages - 1;
 #pragma unroll
@@ -336,18 +336,27 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     stage_load(reg[0], 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) *reinterpret_cast<d2*>(lds + dst0 + q * 64) = reg[0][q];
-    stage_load(reg[0], 1);
+    if constexpr (PF == 2) stage_load(reg[0], 1);
     __syncthreads();
   }
-  for (int s = 0; s < nstages; s += 2) {
-    stage_load(reg[1], s + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    ssb_stage<RB, CB, NQ>(lds, lds + BUF, la, la1, toa, tob, acc, reg[0], dst0);
-    __syncthreads();
-    if (s + 1 < nstages) {
-      stage_load(reg[0], s + 3);
+  if constexpr (PF == 2) {
+    for (int s = 0; s < nstages; s += 2) {
+      stage_load(reg[1], s + 2);
       __builtin_amdgcn_sched_barrier(0);
-      ssb_stage<RB, CB, NQ>(lds + BUF, lds, la, la1, toa, tob, acc, reg[1], dst0);
+      ssb_stage<RB, CB, NQ>(lds, lds + BUF, la, la1, toa, tob, acc, reg[0], dst0);
+      __syncthreads();
+      if (s + 1 < nstages) {
+        stage_load(reg[0], s + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ssb_stage<RB, CB, NQ>(lds + BUF, lds, la, la1, toa, tob, acc, reg[1], dst0);
+        __syncthreads();
+      }
+    }
+  } else {   // large blocks: the accumulators need the registers, one stage in flight
+    for (int s = 0; s < nstages; ++s) {
+      stage_load(reg[0], s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      ssb_stage<RB, CB, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, acc, reg[0], dst0);
       __syncthreads();
     }
   }
@@ -392,7 +401,8 @@ __global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __re
   const bool wide = cg < NBIG;
   constexpr int kpad = CTL * 16;
   double* P = part + (int64_t)blockIdx.x * acols * kpad;
-#define SSB_RUN(RBV, CBV) ssb_run<RBV, CBV, NQ>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk)
+  constexpr int PF = (RB0 * CBC <= 8 && NQ <= 6) ? 2 : 1;   // two register stages only where they do not cost a spill
+#define SSB_RUN(RBV, CBV) ssb_run<RBV, CBV, NQ, PF>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk)
   if (rg == 0) {
     if (NBIG && wide) SSB_RUN(RB0, CBC);
     else SSB_RUN(RB0, CBF);

@@ -13,7 +13,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $out/${tag}_pmc_$w/pmc_$name/counter_collection.csv
 done
-python3 $R/profiles/summarize_pmc.py $out/${tag}_pmc_$w ${MIN_MS:-0.2} > $out/${tag}_pmc_${w}_summary.json
+python3 $R/profiles/summarize_pmc.py $out/${tag}_pmc_$w ${MIN_MS:-2.0} > $out/${tag}_pmc_${w}_summary.json
 python3 - <<PY
 import json
 d = json.load(open("$out/${tag}_pmc_${w}_summary.json"))
