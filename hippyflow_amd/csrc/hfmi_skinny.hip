@@ -265,29 +265,44 @@ __global__ __launch_bounds__(SS_THREADS, (TPW <= 4 ? 4 : 2)) void k_tsgemm_ss(
 // of the north-star kernel point: n = 32 ... 138 snapshots against k = 74 / 84 / 138 probe vectors).
 //
 // k_tsgemm_ss deals the 16 x 16 output tiles round-robin, so EVERY MFMA pair reads both of its fragments from LDS
-// (two ds_read_b128 per 128 matrix-pipe cycles per wave: about half of the LDS pipe).  Here the RT x CT
-// tile grid is cut into a 2 x 4 grid of rectangular blocks, one per wave, with compile-time block shapes: a wave with an
-// RB x CB block reads RB + CB fragments per k-step group and issues 2 RB CB MFMAs from them (5 x 3 block: 8 reads for 30
-// MFMAs instead of 30).  Waves w and w + 4 share a SIMD; the second row of blocks walks the column groups backwards so that
-// a wide block shares its SIMD with a narrow one.  Staging, LDS image and partial-tile output are those of k_tsgemm_ss.
-template <int RB, int CB, int NQ>
+// (two ds_read_b128 per 128 matrix-pipe cycles per wave: about half of the LDS pipe).  Here the first
+// 4 floor(CT / 4) tile columns are cut into a 2 x 4 grid of rectangular blocks with compile-time shapes, one per wave
+// (rows split ceil / floor, columns in four equal groups): a wave with an RB x CB block reads RB + CB fragments per 8
+// reduction indices and issues 2 RB CB MFMAs from them (5 x 2 block: 7 reads for 20 MFMAs instead of 20).  Waves w and
+// w + 4 share a SIMD and hold the upper and the lower block of one column group, so the four SIMDs carry equal main
+// loads; the tiles of the CT mod 4 left-over columns are dealt one at a time to the SIMDs (lower wave first), each
+// with its own pair of fragments -- 81 tiles end up as 21 / 20 / 20 / 20 per SIMD.  Staging, LDS image and
+// partial-tile output are those of k_tsgemm_ss.
+template <int RB, int CB, int EN, int NQ>
 __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* __restrict__ Lnext, const int la, const int la1,
-                                          const int (&toa)[RB], const int (&tob)[CB], d4 (&acc)[RB][CB], const d2 (&r)[NQ],
-                                          const int dst0) {
+                                          const int (&toa)[RB], const int (&tob)[CB], const int (&etoa)[EN > 0 ? EN : 1],
+                                          const int (&etob)[EN > 0 ? EN : 1], d4 (&acc)[RB][CB], d4 (&eacc)[EN > 0 ? EN : 1],
+                                          const d2 (&r)[NQ], const int dst0) {
   constexpr int CT = NQ * 32;
-  d2 fa[2][RB], fb[2][CB];
+  constexpr int EA = EN > 0 ? EN : 1;
+  d2 fa[2][RB], fb[2][CB], ea[2][EA], eb[2][EA];
 #pragma unroll
   for (int i = 0; i < RB; ++i) fa[0][i] = *reinterpret_cast<const d2*>(L + toa[i] + la);
 #pragma unroll
   for (int j = 0; j < CB; ++j) fb[0][j] = *reinterpret_cast<const d2*>(L + tob[j] + la);
 #pragma unroll
+  for (int e = 0; e < EN; ++e) {
+    ea[0][e] = *reinterpret_cast<const d2*>(L + etoa[e] + la);
+    eb[0][e] = *reinterpret_cast<const d2*>(L + etob[e] + la);
+  }
+#pragma unroll
   for (int it = 0; it < 4; ++it) {
     if (it + 1 < 4) {
-      const int lx = ((it + 1) & 1) ? la1 : la;
+      const int lx = (((it + 1) & 1) ? la1 : la) + (it + 1) * (8 * CT);
 #pragma unroll
-      for (int i = 0; i < RB; ++i) fa[(it + 1) & 1][i] = *reinterpret_cast<const d2*>(L + toa[i] + lx + (it + 1) * (8 * CT));
+      for (int i = 0; i < RB; ++i) fa[(it + 1) & 1][i] = *reinterpret_cast<const d2*>(L + toa[i] + lx);
 #pragma unroll
-      for (int j = 0; j < CB; ++j) fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(L + tob[j] + lx + (it + 1) * (8 * CT));
+      for (int j = 0; j < CB; ++j) fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(L + tob[j] + lx);
+#pragma unroll
+      for (int e = 0; e < EN; ++e) {
+        ea[(it + 1) & 1][e] = *reinterpret_cast<const d2*>(L + etoa[e] + lx);
+        eb[(it + 1) & 1][e] = *reinterpret_cast<const d2*>(L + etob[e] + lx);
+      }
     }
     if (it >= 2) {   // the next stage goes to the other LDS buffer under the MFMAs of the last two groups
       constexpr int H = (NQ + 1) / 2;
@@ -301,31 +316,48 @@ __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* 
 #pragma unroll
       for (int j = 0; j < CB; ++j) acc[i][j] = MFMA_F64(fa[it & 1][i].x, fb[it & 1][j].x, acc[i][j]);
 #pragma unroll
+    for (int e = 0; e < EN; ++e) eacc[e] = MFMA_F64(ea[it & 1][e].x, eb[it & 1][e].x, eacc[e]);
+#pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
       for (int j = 0; j < CB; ++j) acc[i][j] = MFMA_F64(fa[it & 1][i].y, fb[it & 1][j].y, acc[i][j]);
+#pragma unroll
+    for (int e = 0; e < EN; ++e) eacc[e] = MFMA_F64(ea[it & 1][e].y, eb[it & 1][e].y, eacc[e]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int RB, int CB, int NQ, int PF>
+// ext0 / ext_step: this wave's left-over tiles are the tile numbers ext0, ext0 + ext_step, ... (EN of them) of the
+// left-over columns, numbered down the columns: tile e = (row e % RT, column CM + e / RT).
+template <int RB, int CB, int EN, int NQ, int PF, int RT>
 __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* __restrict__ ptab, const int nstages, const int col0,
                                         const int off, const int dst0, const int la, const int la1, const int row_tile0,
                                         const int col_tile0, const int bcol0, double* __restrict__ P, const int kpad, const int r16,
-                                        const int kk) {
+                                        const int kk, const int ext0, const int ext_col0) {
   constexpr int BUF = NQ * 32 * SS_BK;
-  int toa[RB], tob[CB];
+  constexpr int EA = EN > 0 ? EN : 1;
+  int toa[RB], tob[CB], etoa[EA], etob[EA], er[EA], ec[EA];
 #pragma unroll
   for (int i = 0; i < RB; ++i) toa[i] = (row_tile0 + i) * 32;
 #pragma unroll
   for (int j = 0; j < CB; ++j) tob[j] = (bcol0 + (col_tile0 + j) * 16) * 2;
-  d4 acc[RB][CB];
+#pragma unroll
+  for (int e = 0; e < EA; ++e) {
+    const int id = ext0 + 8 * e;                  // the same wave is served again two rounds (8 tiles) later
+    er[e] = id % RT;
+    ec[e] = ext_col0 + id / RT;
+    etoa[e] = er[e] * 32;
+    etob[e] = (bcol0 + ec[e] * 16) * 2;
+  }
+  d4 acc[RB][CB], eacc[EA];
 #pragma unroll
   for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < CB; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  // two register sets: while stage s is consumed, stage s+1 (already fetched) is written to the other LDS buffer and
-  // stage s+2 is on its way -- one stage of MFMAs is shorter than the HBM latency for the small blocks
+#pragma unroll
+  for (int e = 0; e < EA; ++e) eacc[e] = d4{0.0, 0.0, 0.0, 0.0};
+  // two register sets where they fit: while stage s is consumed, stage s+1 (already fetched) is written to the other LDS
+  // buffer and stage s+2 is on its way -- one stage of MFMAs is shorter than the HBM latency for the small blocks
   d2 reg[PF][NQ];
   auto stage_load = [&](d2(&rr)[NQ], int s) {
     if (s > nstages - 1) s = nstages - 1;
@@ -343,12 +375,12 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     for (int s = 0; s < nstages; s += 2) {
       stage_load(reg[1], s + 2);
       __builtin_amdgcn_sched_barrier(0);
-      ssb_stage<RB, CB, NQ>(lds, lds + BUF, la, la1, toa, tob, acc, reg[0], dst0);
+      ssb_stage<RB, CB, EN, NQ>(lds, lds + BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0);
       __syncthreads();
       if (s + 1 < nstages) {
         stage_load(reg[0], s + 3);
         __builtin_amdgcn_sched_barrier(0);
-        ssb_stage<RB, CB, NQ>(lds + BUF, lds, la, la1, toa, tob, acc, reg[1], dst0);
+        ssb_stage<RB, CB, EN, NQ>(lds + BUF, lds, la, la1, toa, tob, etoa, etob, acc, eacc, reg[1], dst0);
         __syncthreads();
       }
     }
@@ -356,7 +388,7 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     for (int s = 0; s < nstages; ++s) {
       stage_load(reg[0], s + 1);
       __builtin_amdgcn_sched_barrier(0);
-      ssb_stage<RB, CB, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, acc, reg[0], dst0);
+      ssb_stage<RB, CB, EN, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0);
       __syncthreads();
     }
   }
@@ -367,6 +399,10 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         P[(int64_t)((row_tile0 + i) * 16 + kk + 4 * e) * kpad + (col_tile0 + j) * 16 + r16] = acc[i][j][e];
+#pragma unroll
+  for (int x = 0; x < EN; ++x)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) P[(int64_t)(er[x] * 16 + kk + 4 * e) * kpad + ec[x] * 16 + r16] = eacc[x][e];
 }
 
 template <int RT, int CTL, int NQ>
@@ -377,8 +413,12 @@ __global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __re
   constexpr int CT = NQ * 32;
   constexpr int BUF = CT * SS_BK;
   constexpr int RB0 = (RT + 1) / 2, RB1 = RT / 2;
-  constexpr int CBF = CTL / 4, NBIG = CTL % 4, CBC = CBF + (NBIG ? 1 : 0);
+  constexpr int CBF = CTL / 4, CM = 4 * CBF, NLEFT = (CTL - CM) * RT;     // main columns, left-over tiles
   static_assert(RB1 >= 1 && CBF >= 1, "blocked variant needs at least 2 x 4 tiles");
+  // left-over tile e goes to SIMD e % 4, rounds of four alternate between the lower wave (w >= 4, the smaller block)
+  // and the upper one: the lower wave of SIMD i gets e = i, i + 8, ..., the upper wave e = i + 4, i + 12, ...
+  constexpr int ENB_HI = (NLEFT + 7) / 8, ENB_LO = NLEFT / 8 + ((NLEFT % 8) > 3 ? 1 : 0);          // lower waves i < / >= NLEFT % 4 ...
+  constexpr int ENT_HI = (NLEFT + 3) / 8, ENT_LO = NLEFT > 4 ? (NLEFT - 4) / 8 + (((NLEFT - 4) % 8) > 3 ? 1 : 0) : 0;
   double* lds = reinterpret_cast<double*>(smem);
   gdptr* ptab = reinterpret_cast<gdptr*>(lds + 2 * BUF);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,21 +434,24 @@ __global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __re
   for (int v = tid; v < CT; v += SS_THREADS) ptab[v] = ss_colptr(v, ctot, acols, A, lda, m, B, ldb, k) + t_begin;
   __syncthreads();
   const int la = (kk * CT + (r16 ^ kk)) * 2, la1 = (kk * CT + (r16 ^ (kk + 4))) * 2;
-  const int rg = wave >> 2;
-  const int cg = rg ? 3 - (wave & 3) : (wave & 3);
+  const int rg = wave >> 2, cg = wave & 3;
   const int row_tile0 = rg ? RB0 : 0;
-  const int col_tile0 = cg * CBF + (cg < NBIG ? cg : NBIG);
-  const bool wide = cg < NBIG;
+  const int col_tile0 = cg * CBF;
+  const int ext0 = rg ? cg : cg + 4;               // first left-over tile of this wave
+  int en = 0;                                      // how many it has: ext0, ext0 + 8, ... < NLEFT
+  for (int id = ext0; id < NLEFT; id += 8) ++en;
   constexpr int kpad = CTL * 16;
   double* P = part + (int64_t)blockIdx.x * acols * kpad;
-  constexpr int PF = (RB0 * CBC <= 8 && NQ <= 6) ? 2 : 1;   // two register stages only where they do not cost a spill
-#define SSB_RUN(RBV, CBV) ssb_run<RBV, CBV, NQ, PF>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk)
+  // two register stages while a stage of MFMAs (tiles per SIMD x 512 cycles) is shorter than about 3.5 us of HBM latency under
+  // load; the larger blocks need the registers for their accumulators
+  constexpr int PF = (RT * CTL <= 56) ? 2 : 1;
+#define SSB_RUN(RBV, ENV) ssb_run<RBV, CBF, ENV, NQ, PF, RT>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk, ext0, CM)
   if (rg == 0) {
-    if (NBIG && wide) SSB_RUN(RB0, CBC);
-    else SSB_RUN(RB0, CBF);
+    if (ENT_HI != ENT_LO && en == ENT_LO) SSB_RUN(RB0, ENT_LO);
+    else SSB_RUN(RB0, ENT_HI);
   } else {
-    if (NBIG && wide) SSB_RUN(RB1, CBC);
-    else SSB_RUN(RB1, CBF);
+    if (ENB_HI != ENB_LO && en == ENB_LO) SSB_RUN(RB1, ENB_LO);
+    else SSB_RUN(RB1, ENB_HI);
   }
 #undef SSB_RUN
 }

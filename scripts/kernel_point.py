@@ -17,11 +17,15 @@ for n in (8, 16, 32, 48, 64, 96, 138, 512, 2048):
         L.call("hfmi_tuning_set", b"ss", ss)
         for orient in ("X^T W", "(W^T X)^T"):
             A, B = (X, W) if orient == "X^T W" else (W, X)
-            ms = C.c_double(0)
-            L.call("hfmi_bench_tsgemm_tn", A.handle, B.handle, 0, 10, None, C.byref(ms))
-            print("   n=%d ss=%d %s: %.4f ms" % (n, ss, orient, ms.value), flush=True)
-            if best is None or ms.value < best[1]:
-                best = (orient + (" [ss]" if ss and n <= 160 else " [tn]"), ms.value)
+            reps = []
+            for _ in range(5):           # median of five 10-launch averages (a single batch right after an idle gap reads 5-13 % slow)
+                ms = C.c_double(0)
+                L.call("hfmi_bench_tsgemm_tn", A.handle, B.handle, 0, 10, None, C.byref(ms))
+                reps.append(ms.value)
+            t_med = float(np.median(reps))
+            print("   n=%d ss=%d %s: %.4f ms" % (n, ss, orient, t_med), flush=True)
+            if best is None or t_med < best[1]:
+                best = (orient + (" [ss]" if ss and n <= 160 else " [tn]"), t_med)
     L.call("hfmi_tuning_set", b"ss", 1)
     t = best[1] * 1e-3
     by, fl = 8.0 * (N * n + N * k + n * k), 2.0 * N * n * k
