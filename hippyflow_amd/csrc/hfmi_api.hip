@@ -570,9 +570,14 @@ extern "C" int hfmi_op_low_rank(hfmi_ctx* ctx, const hfmi_block* U, const double
   op->X = *U;
   op->X.owner = false;
   op->scale = 1.0;
-  HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMalloc((void**)&op->weights, (size_t)U->nvec * sizeof(double)));
-  HIP_TRY(hipMemcpy(op->weights, host_d, (size_t)U->nvec * sizeof(double), hipMemcpyHostToDevice));
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc((void**)&op->weights, (size_t)U->nvec * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(op->weights, host_d, (size_t)U->nvec * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (op->weights) (void)hipFree(op->weights);
+    delete op;
+    HFMI_FAIL(HFMI_ERR_HIP, "op_low_rank: %s", hipGetErrorString(e));
+  }
   *out = op;
   return HFMI_OK;
 }
