@@ -43,7 +43,7 @@ constexpr int TN_BK = 32;   // reduction indices per LDS stage
 // read from LDS with the 4 columns of a group repeated for every block.
 template <int MT, int NT, bool TR, int WAVES, int R4>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) void k_tsgemm_tn(const double* __restrict__ A, int64_t lda, int m,
-                                                                    const double* __restrict__ B, int64_t ldb, int k,
+                                                                    const double* B /* not restrict: see the stage loop */, int64_t ldb, int k,
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ out, int64_t si, int64_t sj,
                                                                     int64_t sps, int direct, int probe) {
@@ -105,10 +105,23 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 
   d2 breg[NQ];
   auto stage_load = [&](int64_t ts) {
+#if defined(TN_EXP) && TN_EXP == 2     // experiment builds (scripts/build_variant.sh): LDS stores without the global loads
+    (void)ts;
+#elif defined(TN_EXP) && TN_EXP == 3   // loads that always hit the same lines
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + t_begin);
+#else
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + ts);
+#endif
   };
   auto stage_store = [&](double* L) {
+#if defined(TN_EXP) && TN_EXP == 1     // global loads without the LDS stores (the registers are kept alive)
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) asm volatile("" ::"v"(breg[qd]));
+    (void)L;
+    return;
+#endif
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
       const int c = tid + NTHR * qd;
@@ -189,7 +202,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
     for (int s = 0; s < nstages; ++s) {
       const int64_t ts = t_begin + (int64_t)s * BK;
       const bool has_next = s + 1 < nstages;
-      if (has_next && !(probe & 2)) stage_load(ts + BK);
+      // UNCONDITIONAL (the last stage re-reads its own slab): vmcnt retires loads in issue order, and these loads sit
+      // between the streamed operand's fragment fetched one iteration ago and the wait in front of its first MFMA.  Behind
+      // a branch (as it was until round 2) the compiler has to assume the path WITHOUT them at the join and emits
+      // vmcnt(6) instead of vmcnt(6 + NQ): every stage then began by waiting for these loads' L2 / HBM round trip --
+      // 10-12 % of the kernel (experiment builds TN_EXP = 1..3, scripts/build_variant.sh; profiles/r02o_tn_variants.txt).
+      stage_load(has_next ? ts + BK : ts);
+      asm volatile("" ::: "memory");   // keeps the loads HERE: left alone they are sunk to their ds_write and waited for with vmcnt(0)
       const double* L = lds + (s & 1) * BUFD;
 #pragma unroll
       for (int nt = 0; nt < NTF; ++nt) ldsb1(L, 0, nt);
