@@ -287,3 +287,53 @@ def test_low_rank_operator_with_a_general_diagonal(ctx):
     np.testing.assert_allclose(d, d_o, rtol=1e-9)
     Ud = U.to_dense()
     assert np.abs(Ud.T @ Bd @ Ud - np.eye(6)).max() < 1e-10
+
+
+# ------------------------------------------------------------------ error behaviour of the round-2 entry points
+def test_round2_entry_points_reject_bad_arguments(ctx):
+    import ctypes as C
+    L = hf._lib
+    # sym_eig beyond 4096
+    with pytest.raises(hf.HfmiError) as e:
+        hf.sym_eig_small(np.eye(4097))
+    assert "out of range" in str(e.value)
+    # host-callback slab size: negative, and on an operator that is not a host callback
+    cb = hf.HostCallbackOperator(lambda W: W, 64)
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_op_host_set_chunk", cb._op, -1)
+    csr = hf.CsrOperator(sp.identity(64, format="csr"))
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_op_host_set_chunk", csr._op, 4)
+    # a failing host callback surfaces as the original Python exception, also through the slab pipeline
+    class Boom:
+        def solve_block(self, X):
+            raise ValueError("boom in slab")
+    bad = hf.HostCallbackOperator(Boom(), 64, chunk_vectors=2)
+    X, Y = hf.MultiVector(64, 5), hf.MultiVector(64, 5)
+    with pytest.raises(ValueError, match="boom in slab"):
+        bad.matMvMult(X, Y)
+    # the slab pipeline gives the same block as one call (identity black box scaled by 3)
+    tri = hf.HostCallbackOperator(type("S", (), {"solve_block": staticmethod(lambda X: 3.0 * X)})(), 64, chunk_vectors=2)
+    hf.parRandom.normal(1.0, X)
+    tri.matMvMult(X, Y)
+    np.testing.assert_array_equal(Y.to_dense(), 3.0 * X.to_dense())
+    tri.matMvMult(X, Y, accumulate=True)
+    np.testing.assert_allclose(Y.to_dense(), 6.0 * X.to_dense(), rtol=1e-15)
+    # communicator: reductions other than sum / avg cannot be attached to an operator; blocks of another context are refused
+    coll = hf.NativeCollective.from_unique_id(hf.NativeCollective.unique_id(), 1, 0)
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_op_set_collective", csr._op, coll._comm, 2)
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_bcast", coll._comm, X.handle, 3)                 # root outside the communicator
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_allreduce", coll._comm, X.handle, 7)             # unknown reduction
+    coll.close()
+    # low-rank operator needs its diagonal
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_op_low_rank", ctx.handle, X.handle, None, C.byref(C.c_void_p()))
+    with pytest.raises(ZeroDivisionError):
+        hf.LowRankOperator(np.array([1.0, 0.0, 2.0, 1.0, 1.0]), X).inverse()
+    # Matern fill: grid too small for the block
+    Cb = hf.MultiVector(50, 50)
+    with pytest.raises(hf.HfmiError):
+        L.call("hfmi_block_fill_matern32", Cb.handle, 5, 5, 1.0, 0.1)
