@@ -42,6 +42,45 @@ extern "C" int hfmi_device_count(int* count) {
 }
 
 // ------------------------------------------------------------------ context
+// ------------------------------------------------------------------ device memory: pool of released block storage
+static void pool_flush(hfmi_ctx* ctx) {
+  if (ctx->pool.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->pool) (void)hipFree(e.p);
+  ctx->pool.clear();
+  ctx->pool_bytes = 0;
+}
+static hipError_t ctx_malloc(hfmi_ctx* ctx, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && !ctx->pool.empty()) {      // give the pooled storage back and try once more
+    (void)hipGetLastError();
+    pool_flush(ctx);
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+// storage of a destroyed block: kept for reuse (same stream order as every other use of it) or freed
+static void pool_release(hfmi_ctx* ctx, void* p, size_t bytes) {
+  constexpr size_t MAX_ENTRY = (size_t)2 << 30, MAX_TOTAL = (size_t)8 << 30;
+  if (bytes <= MAX_ENTRY && ctx->pool.size() < 16 && ctx->pool_bytes + bytes <= MAX_TOTAL) {
+    ctx->pool.push_back({p, bytes});
+    ctx->pool_bytes += bytes;
+    return;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(p);
+}
+static void* pool_take(hfmi_ctx* ctx, size_t bytes) {
+  for (size_t i = ctx->pool.size(); i-- > 0;)
+    if (ctx->pool[i].bytes == bytes) {
+      void* p = ctx->pool[i].p;
+      ctx->pool_bytes -= bytes;
+      ctx->pool.erase(ctx->pool.begin() + i);
+      return p;
+    }
+  return nullptr;
+}
+
 int ctx_ws(hfmi_ctx* ctx, int slot, size_t bytes, void** out) {
   if (bytes > ctx->ws_bytes[slot]) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -49,7 +88,7 @@ int ctx_ws(hfmi_ctx* ctx, int slot, size_t bytes, void** out) {
     ctx->ws[slot] = nullptr;
     ctx->ws_bytes[slot] = 0;
     size_t want = bytes + bytes / 4 + 4096;
-    HIP_TRY(hipMalloc(&ctx->ws[slot], want));
+    HIP_TRY(ctx_malloc(ctx, &ctx->ws[slot], want));
     ctx->ws_bytes[slot] = want;
   }
   *out = ctx->ws[slot];
@@ -92,6 +131,7 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   c->pinned_bytes = 0;
   c->pinned_cb = nullptr;
   c->pinned_cb_bytes = 0;
+  c->pool_bytes = 0;
   for (int i = 0; i < HFMI_PHASE_COUNT; ++i) c->phase_ms[i] = 0.0;
   c->profiling = false;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -119,6 +159,7 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
       if (b->owner && b->p) (void)hipFree(b->p);
       delete b;
     }
+  pool_flush(ctx);
   for (int i = 0; i < WS_NSLOTS; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -198,8 +239,8 @@ static int block_alloc(hfmi_ctx* ctx, int64_t N, int nvec, hfmi_block** out) {
   b->nvec = nvec;
   b->ld = round_up(N, 32);
   b->owner = true;
-  b->p = nullptr;
-  hipError_t e = hipMalloc((void**)&b->p, (size_t)b->ld * nvec * sizeof(double));
+  b->p = (double*)pool_take(ctx, (size_t)b->ld * nvec * sizeof(double));
+  hipError_t e = b->p ? hipSuccess : ctx_malloc(ctx, (void**)&b->p, (size_t)b->ld * nvec * sizeof(double));
   if (e != hipSuccess) {
     const double gb = (double)b->ld * nvec * 8 / 1e9;
     delete b;
@@ -259,8 +300,7 @@ extern "C" int hfmi_block_destroy(hfmi_block* b) {
   if (!b) return HFMI_OK;
   if (b->owner && b->p) {
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
-    (void)hipFree(b->p);
+    pool_release(b->ctx, b->p, (size_t)b->ld * b->nvec * sizeof(double));
   }
   delete b;
   return HFMI_OK;
@@ -1340,10 +1380,13 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_V), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
   }
   phase_end(ctx, ph);
-  hfmi_status_words st;
-  HFMI_TRY(read_status(ctx, &st));
+  // one synchronisation for both read-backs: the status words are copied asynchronously, the eigenvalue copy waits
+  HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
+  HFMI_TRY(read_back(ctx, (const double*)dv, r, host_d));
+  const hfmi_status_words st = *ctx->status_host;
+  print_status_dbg(&st);
   if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: Jacobi eigensolve did not converge (off-diagonal %.2e)", st.offdiag);
-  return read_back(ctx, (const double*)dv, r, host_d);
+  return HFMI_OK;
 }
 
 extern "C" int hfmi_double_pass(hfmi_op* A, const hfmi_block* Omega, int r, int s, int flags, double* host_d, hfmi_block* U) {

@@ -75,6 +75,12 @@ struct hfmi_ctx {
   void* pinned;                   // pinned host staging
   size_t pinned_bytes;
   std::vector<hfmi_block*> tmp_blocks;  // cached temporaries for the fused solves
+  // storage of destroyed blocks kept for the next hfmi_block_create of the same size (a solve per step returns a fresh
+  // U and the caller drops the previous one: without the pool every step pays a hipFree -- a device synchronisation --
+  // and a hipMalloc); entries <= 2 GB, at most 16 entries / 8 GB, flushed when an allocation fails
+  struct pool_entry { void* p; size_t bytes; };
+  std::vector<pool_entry> pool;
+  size_t pool_bytes;
   // optional per-launch event timing of the two MFMA kernel classes
   bool profiling;
   struct prof_rec { int kind; int64_t m, k, N; hipEvent_t e0, e1; double flops, bytes; };
