@@ -253,6 +253,15 @@ def test_pod_from_data_with_more_than_256_snapshots(ctx):
         np.testing.assert_allclose(phi * sg, phi_o, atol=1e-7)
         np.testing.assert_allclose(Mphi * sg, Mphi_o, atol=1e-7)
         assert np.abs(phi.T @ Mphi - np.eye(r)).max() < 1e-9
+    # the two Lanczos formulations of the reference (ghep :743-773, inverse_ghep :775-810) reduce to the same Gram problem
+    d_h, phi_h, _, _ = pod.construct_subspace(u_data.copy(), r, shifted=True, method="hep")
+    for method in ("ghep", "inverse_ghep"):
+        d_m, phi_m, Mphi_m, _ = pod.construct_subspace(u_data.copy(), r, shifted=True, method=method)
+        d_o, phi_o, _, _ = hf_o.pod_from_data(u_data.copy(), M, r, shifted=True, method=method)     # ARPACK on the host
+        np.testing.assert_allclose(d_m, d_o, rtol=1e-7)
+        np.testing.assert_array_equal(d_m, d_h)
+        sg = np.sign(np.sum(phi_m * (M @ phi_o), axis=0))
+        np.testing.assert_allclose(phi_m * sg, phi_o, atol=1e-6)
 
 
 def test_low_rank_operator_with_a_general_diagonal(ctx):
