@@ -1207,10 +1207,10 @@ extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, in
   HFMI_TRY(upload_small(ctx, host_T, k, k, sm_ptr(ctx, SM_T), SM_LD));
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
-  HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, sort_by_abs));
+  HFMI_TRY(launch_sym_eig(ctx, k, SM_T, SM_V, (double*)dv, sort_by_abs & 1, (sort_by_abs >> 1) & 1));
   hfmi_status_words st;
   HFMI_TRY(read_status(ctx, &st));
-  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig_small: Jacobi did not converge (off-diagonal %.2e)", st.offdiag);
+  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig_small: eigensolver did not converge (off-diagonal %.2e)", st.offdiag);
   HFMI_TRY(read_back(ctx, (const double*)dv, k, host_d));
   if (host_V) {
     std::vector<double> tmp((size_t)k * SM_LD);
@@ -1370,7 +1370,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
   ph = phase_begin(ctx, HFMI_PHASE_EIG);
-  HFMI_TRY(launch_jacobi_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1));
+  HFMI_TRY(launch_sym_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1, (flags >> 3) & 1));
   phase_end(ctx, ph);
   ph = phase_begin(ctx, HFMI_PHASE_BACK);
   if (deferred) {   // U = (Q R^-1) V = Q (R^-1 V)
@@ -1385,7 +1385,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   HFMI_TRY(read_back(ctx, (const double*)dv, r, host_d));
   const hfmi_status_words st = *ctx->status_host;
   print_status_dbg(&st);
-  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: Jacobi eigensolve did not converge (off-diagonal %.2e)", st.offdiag);
+  if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: small eigensolve did not converge (off-diagonal %.2e)", st.offdiag);
   return HFMI_OK;
 }
 

@@ -1,0 +1,1096 @@
+// Rayleigh-Ritz eigensolve of the double pass (np.linalg.eigh(T) inside hippylib's doublePass /
+// doublePassG, la.eigh of PODProjector.py:821) for k <= 256: Householder tridiagonalisation, Cuppen divide and conquer
+// on the tridiagonal matrix, back-transformation -- the algorithm family of LAPACK's dsyevd, which is what the
+// reference's numpy call runs, laid out for one CDNA4 compute unit instead of a CPU core.
+//
+//   k_tridiag<RI, CJ>   one workgroup, 16 waves.  The k x k matrix lives in REGISTERS (row r on wave r mod 16, column c
+//                       on lane c mod 64: RI x CJ doubles per thread), only the Householder vector, the 16 per-wave
+//                       partial products of A v and the vector p cross waves, through LDS: three barriers per column.
+//                       Finished rows / columns are skipped with wave-uniform tests, so the work per step shrinks with
+//                       the trailing block although the ownership map is static.
+//   k_dc                one workgroup.  Every coupling e_i is torn off up front (leaves are 1 x 1), the merges run level
+//                       by level: rank sort of the poles, deflation scan (dlaed2's rule), the secular equation in the
+//                       variable shifted to the nearer pole (G lanes per root), Gu-Eisenstat re-computation of the
+//                       rank-one vector, eigenvector update Q <- Q S on the fp64 MFMA.  Q, S live in L2-resident global
+//                       scratch (4 k^2 doubles), vectors in LDS.
+//   k_dc_back<EL>       many workgroups: the reflectors applied to the eigenvectors, 16 lanes per eigenvector (the dot
+//                       products are four DPP steps, no LDS, no barrier), result written to its sorted position.
+//
+// tests/helpers/dc_eig_twin.py is the numpy twin of these three kernels (same tree, same deflation rule, same secular
+// iteration); tests/test_dc_twin.py pins it against numpy.linalg.eigh on the CPU.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "hfmi_gemm_common.h"
+
+namespace {
+constexpr int DC_THREADS = 1024;
+constexpr int DC_WAVES = 16;
+constexpr int DC_MAXN = 256;
+constexpr double DC_EPS = 2.220446049250313e-16;
+
+// Cross-lane sums on DPP moves (two v_mov_b32_dpp per double and stage) instead of ds_bpermute round trips through the LDS
+// crossbar: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.  After a
+// stage both partners hold a + b and b + a, i.e. identical bits, so every lane of the group ends with the same value.
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int G>   // G = 1, 2, 4, 8, 16 consecutive lanes
+__device__ __forceinline__ double group_sum(double v) {
+  if (G >= 2) v += dpp_get<0xB1>(v);
+  if (G >= 4) v += dpp_get<0x4E>(v);
+  if (G >= 8) v += dpp_get<0x141>(v);
+  if (G >= 16) v += dpp_get<0x140>(v);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ double group_prod(double v) {
+  if (G >= 2) v *= dpp_get<0xB1>(v);
+  if (G >= 4) v *= dpp_get<0x4E>(v);
+  if (G >= 8) v *= dpp_get<0x141>(v);
+  if (G >= 16) v *= dpp_get<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double lane_get(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {   // all 64 lanes
+  v = group_sum<16>(v);
+  return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// 1 / sqrt(x) and 1 / x from the hardware estimates plus Newton steps: short dependent chains instead of the IEEE sequences
+// (the reflector needs tau and the scale to a few ulp, not correctly rounded)
+__device__ __forceinline__ double dc_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y0), y0, 1.0);
+  const double q = e * fma(0.375, e, 0.5);
+  return fma(y0, q, y0);
+}
+__device__ __forceinline__ double dc_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// ------------------------------------------------------------------------------------------------ tridiagonalisation
+// per-phase shader-clock counters of wave 0 (build with -DHFMI_DC_TICKS; every s_memtime read drains the LDS queue, so the
+// instrumented kernel is slower than the production one)
+#ifdef HFMI_DC_TICKS
+#define TRI_TICK_DECL long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tl = clock64()
+#define TRI_TICK(slot)              \
+  do {                              \
+    const long long _t = clock64(); \
+    slot += _t - tl;                \
+    tl = _t;                        \
+  } while (0)
+#define TRI_TICK_STORE \
+  if (tid == 0) {      \
+    ticks[12] = tk0;   \
+    ticks[13] = tk1;   \
+    ticks[14] = tk2;   \
+    ticks[15] = tk3;   \
+  }
+#else
+#define TRI_TICK_DECL
+#define TRI_TICK(slot)
+#define TRI_TICK_STORE
+#endif
+// T (row-major, ldt; the symmetric part is used) -> d[0..n), e[0..n-1) of H^T T H scaled by 2^-sexp, the reflectors
+// v_j (row j of Vh, v_j[c] = 0 for c <= j, v_j[j+1] = 1) and tau_j, H = H_0 ... H_{n-3}, H_j = I - tau_j v_j v_j^T.
+//
+// NW = 4 or 8 waves with the matrix in their registers: row r on wave r mod NW, column c on lane c mod 64 (RI x CJ doubles per
+// thread).  (16 waves of fewer elements each were measured first: issue-bound by the per-wave bookkeeping, 5000 cycles per column
+// at k = 74.)  Per column j:
+//   (b) every wave multiplies its rows into a slice of A v (A symmetric: column sums over the wave's rows)        | barrier |
+//   (d) every thread adds the NW slices of its own columns: p = tau A v, the dot product p . v is a wave-local sum, and the
+//       values v[r], w[r] a row needs are lane reads of those registers (no LDS); rank-two update of the trailing block.  The
+//       wave that owns row j + 1 updates the chunk holding that row first, forms reflector j + 1 from it and then finishes
+//       its other rows                                                                                             | barrier |
+// Rows are processed in chunks of four with ONE wave-uniform test per chunk (finished chunks are skipped, so the work per column
+// shrinks with the trailing block; a test per row costs two taken branches, more than the row's arithmetic).
+template <int RI, int CJ, int NW>
+__global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ T, int ldt, int n, double* __restrict__ dvec,
+                                                    double* __restrict__ evec, double* __restrict__ Vh, int ldv,
+                                                    double* __restrict__ tauv, int* __restrict__ sexp_out,
+                                                    long long* __restrict__ ticks) {
+  static_assert(RI % 4 == 0, "rows per wave come in chunks of four");
+  static_assert(RI * NW <= 64 * CJ, "row indices must fit the column groups");
+  constexpr int NCH = RI / 4;
+  __shared__ double s_v[DC_MAXN];
+  __shared__ double s_part[NW][DC_MAXN];
+  __shared__ double s_w[NW][DC_MAXN];
+  __shared__ double s_tau;
+  __shared__ double s_red[NW];
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler: scalar branches, scalar lane indices
+  double A[RI][CJ];
+  double amax = 0.0;
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int r = w + NW * i;
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) {
+      const int c = l + 64 * jj;
+      double a = 0.0;
+      if (r < n && c < n) a = 0.5 * (T[(size_t)r * ldt + c] + T[(size_t)c * ldt + r]);
+      A[i][jj] = a;
+      amax = fmax(amax, fabs(a));
+    }
+  }
+  // power-of-two scaling to max |entry| in [1, 2): norms cannot overflow / underflow, eigenvalues scale back exactly
+  amax = wave_max(amax);
+  if (l == 0) s_red[w] = amax;
+  __syncthreads();
+  amax = 0.0;
+  for (int ww = 0; ww < NW; ++ww) amax = fmax(amax, s_red[ww]);
+  int sexp = 0;
+  if (amax > 0.0 && isfinite(amax)) sexp = ilogb(amax);
+  const double sc = ldexp(1.0, -sexp);
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) A[i][jj] *= sc;
+  if (tid == 0) *sexp_out = sexp;
+
+  // reflector j from x = A[j][.] (the owner wave's copy of row j): -> s_v, s_tau now; Vh, tau, e[j], d[j] go to global memory
+  // after the next barrier (pend_*): a global store costs ~50 issue cycles and five of them sat on the critical path
+  double pend_v[CJ], pend_beta = 0.0, pend_tau = 0.0, pend_d = 0.0;
+  int pend_j = -1;
+  auto form_reflector = [&](int j, const double (&x)[CJ]) {
+    double xn2 = 0.0, alpha_l = 0.0, d_l = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) {
+      const int c = l + 64 * jj;
+      if (c == j) d_l = x[jj];
+      if (c == j + 1) alpha_l = x[jj];
+      if (c > j + 1 && c < n) xn2 = fma(x[jj], x[jj], xn2);
+    }
+    xn2 = wave_sum(xn2);
+    const double alpha = lane_get(alpha_l, (j + 1) & 63);   // only that lane's value is not zero, whichever column group
+    double tau = 0.0, beta = alpha, scl = 0.0;
+    if (xn2 > 1e-280) {     // entries are scaled to O(1): below this the column is zero to any precision that matters
+      const double s2 = fma(alpha, alpha, xn2);
+      const double rs = dc_rsqrt(s2);
+      const double nrm = s2 * rs;                         // sqrt(alpha^2 + |x|^2)
+      beta = -copysign(nrm, alpha);
+      tau = fma(fabs(alpha), rs, 1.0);                    // (beta - alpha) / beta
+      scl = copysign(dc_rcp(fabs(alpha) + nrm), alpha);   // 1 / (alpha - beta)
+    }
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) {
+      const int c = l + 64 * jj;
+      const double v = (c == j + 1) ? 1.0 : ((c > j + 1 && c < n) ? x[jj] * scl : 0.0);
+      s_v[c] = v;
+      pend_v[jj] = v;
+    }
+    if (l == 0) s_tau = tau;
+    pend_beta = beta;
+    pend_tau = tau;
+    pend_d = lane_get(d_l, j & 63);
+    pend_j = j;
+  };
+  auto flush_pending = [&]() {
+    if (pend_j >= 0) {
+      asm volatile("");
+#pragma unroll
+      for (int jj = 0; jj < CJ; ++jj) {
+        const int c = l + 64 * jj;
+        if (c < ldv) Vh[(size_t)pend_j * ldv + c] = pend_v[jj];
+      }
+      if (l == 0) {
+        dvec[pend_j] = pend_d;
+        evec[pend_j] = pend_beta;
+        tauv[pend_j] = pend_tau;
+      }
+      pend_j = -1;
+    }
+  };
+  // row rsel of this wave out of chunk ch
+  auto pick_row = [&](int ch, int rsel, double (&x)[CJ]) {
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) x[jj] = 0.0;
+#pragma unroll
+    for (int c4 = 0; c4 < NCH; ++c4) {
+      if (c4 == ch) {
+        asm volatile("");                      // keep this a branch: as selects it is 4 NCH CJ v_cndmask per column
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if ((w + NW * (4 * c4 + u)) == rsel) {
+            asm volatile("");                // (as selects the compiler keeps a copy of the rows in scratch and indexes it)
+#pragma unroll
+            for (int jj = 0; jj < CJ; ++jj) x[jj] = A[4 * c4 + u][jj];
+          }
+        }
+      }
+    }
+  };
+
+  if (n > 2 && w == 0) {
+    double x[CJ];
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) x[jj] = A[0][jj];
+    form_reflector(0, x);
+  }
+  __syncthreads();
+  TRI_TICK_DECL;
+  for (int j = 0; j + 2 < n; ++j) {
+    const double tau = s_tau;
+    const bool next_mine = (j + 3 < n) && (w == ((j + 1) & (NW - 1)));
+    const int chn = ((j + 1) / NW) >> 2;       // chunk of row j + 1 on its owner
+    double vc[CJ];
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) vc[jj] = s_v[l + 64 * jj];
+    if (tau != 0.0) {   // uniform over the workgroup
+      // (b) this wave's slice of A v.  v[r] of the wave's rows: wave-uniform LDS reads, all issued up front (a lane read of vc
+      // costs 40 cycles a row in dependent hazards); finished rows inside a live chunk multiply by v[r] = 0.
+      double vr[RI];
+#pragma unroll
+      for (int i = 0; i < RI; ++i) vr[i] = s_v[w + NW * i];
+      flush_pending();
+      {
+        double acc[CJ][2];
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) acc[jj][0] = acc[jj][1] = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          if (w + NW * (4 * ch + 3) > j) {
+            asm volatile("");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = 4 * ch + u;
+#pragma unroll
+              for (int jj = 0; jj < CJ; ++jj) acc[jj][u & 1] = fma(A[i][jj], vr[i], acc[jj][u & 1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) s_part[w][l + 64 * jj] = acc[jj][0] + acc[jj][1];
+      }
+      __syncthreads();
+      TRI_TICK(tk0);
+      // (d) p = tau A v on this thread's columns, w = p - (tau/2)(p . v) v, A <- A - v w^T - w v^T
+      double wc[CJ];
+      {
+        double pc[CJ], dl = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) {
+          const int c = l + 64 * jj;
+          double q[NW];
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) q[ww] = s_part[ww][c];
+#pragma unroll
+          for (int st = 1; st < NW; st *= 2)
+#pragma unroll
+            for (int ww = 0; ww + st < NW; ww += 2 * st) q[ww] += q[ww + st];
+          pc[jj] = (c > j && c < n) ? tau * q[0] : 0.0;
+          dl = fma(pc[jj], vc[jj], dl);
+        }
+        const double kk = 0.5 * tau * wave_sum(dl);
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) {
+          wc[jj] = fma(-kk, vc[jj], pc[jj]);
+          s_w[w][l + 64 * jj] = wc[jj];
+        }
+      }
+      double wr[RI];
+#pragma unroll
+      for (int i = 0; i < RI; ++i) wr[i] = s_w[w][w + NW * i];
+      TRI_TICK(tk1);
+      auto update_chunk = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 4 * ch + u;
+#pragma unroll
+          for (int jj = 0; jj < CJ; ++jj) A[i][jj] = fma(-wr[i], vc[jj], fma(-vr[i], wc[jj], A[i][jj]));
+        }
+      };
+      if (next_mine) {     // the chunk with row j + 1 first, then the next reflector, then the rest
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (ch == chn) {
+            asm volatile("");
+            update_chunk(ch);
+          }
+        double x[CJ];
+        pick_row(chn, j + 1, x);
+        form_reflector(j + 1, x);
+      }
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        if (w + NW * (4 * ch + 3) > j && !(next_mine && ch == chn)) {
+          asm volatile("");
+          update_chunk(ch);
+        }
+      }
+    } else {
+      flush_pending();
+      if (next_mine) {
+        double x[CJ];
+        pick_row(chn, j + 1, x);
+        form_reflector(j + 1, x);
+      }
+    }
+    TRI_TICK(tk2);
+    __syncthreads();
+    TRI_TICK(tk3);
+  }
+  flush_pending();
+  TRI_TICK_STORE;
+  // the last two rows hold d[n-2], e[n-2], d[n-1]
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int r = w + NW * i;
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) {
+      const int c = l + 64 * jj;
+      if (r < n && r + 2 >= n) {
+        if (c == r) dvec[r] = A[i][jj];
+        if (r + 2 == n && c == r + 1) evec[r] = A[i][jj];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ divide and conquer
+struct dc_args {
+  int n, levels, sort_by_abs;
+  const double* dvec;   // n
+  const double* evec;   // n - 1
+  const int* sexp;
+  double* Q;            // n x n column-major (ld = ldq): eigenvectors of the tridiagonal matrix, columns in place
+  double* Qt;           // scratch of the same shape
+  double* S;            // n x n row-major (ld = ldq): eigenvectors of the rank-one problems of a level
+  int ldq;
+  double* dvals;        // out: eigenvalues in output order (descending / by |.|), scaled back
+  int* perm;            // out: column of Q -> output position
+  hfmi_status_words* status;
+  long long* ticks;     // 16 counters: shader-clock time per phase, summed over the levels (HFMI_DC_TIMING=1 prints them)
+  int split_top;        // 1: the eigenvector update of the LAST merge (half of all the flops of the updates) is left to k_dc_top,
+  int* top_meta;        //    which spreads its tiles over the GPU; top_meta = {K, kept columns[n], live flag[n], column[n]}
+};
+
+// node i of level L covers columns [i n / 2^L, (i + 1) n / 2^L) (integer division); its children are nodes 2i and 2i + 1 of
+// level L + 1, i.e. the split point is (2i + 1) n / 2^(L+1)
+__device__ __forceinline__ void dc_node(int n, int L, int t, int& node, int& lo, int& mid, int& hi) {
+  node = (((t + 1) << L) - 1) / n;
+  lo = (node * n) >> L;
+  hi = ((node + 1) * n) >> L;
+  mid = ((2 * node + 1) * n) >> (L + 1);
+}
+
+template <int G>
+__device__ __forceinline__ void secular_eval(const double* __restrict__ dl, const double* __restrict__ wv, int K, int sub,
+                                             double dorg, double tau, double rho, int i0, double& f, double& dpsi, double& dphi,
+                                             double& err) {
+  double psi = 0.0, phi = 0.0, dps = 0.0, dph = 0.0;
+  int j = sub;
+  for (; j <= i0; j += G) {                  // poles to the left of the root, then those to the right: no selects
+    const double dj = (dl[j] - dorg) - tau;
+    const double inv = dc_rcp(dj);           // a couple of ulp: inside the 8 eps (|psi| + |phi|) the stopping test allows
+    const double z = wv[j];
+    const double t = z * z * inv;
+    psi += t;
+    dps = fma(t, inv, dps);
+  }
+  for (; j < K; j += G) {
+    const double dj = (dl[j] - dorg) - tau;
+    const double inv = dc_rcp(dj);
+    const double z = wv[j];
+    const double t = z * z * inv;
+    phi += t;
+    dph = fma(t, inv, dph);
+  }
+  psi = rho * group_sum<G>(psi);
+  phi = rho * group_sum<G>(phi);
+  dpsi = rho * group_sum<G>(dps);
+  dphi = rho * group_sum<G>(dph);
+  f = 1.0 + psi + phi;
+  err = 8.0 * (fabs(psi) + fabs(phi)) + 1.0 + fabs(tau) * (dpsi + dphi);
+}
+
+// root i of 1 + rho sum_j w_j^2 / (dl_j - lam) = 0: returns the origin pole and tau = lam - dl[origin].
+// One round = one evaluation + the "middle way" step; the step is written without data-dependent branches (the lanes of a wave
+// work on different roots: a branch taken by one root is paid by all), with the hardware reciprocal / rsqrt estimates plus
+// Newton steps instead of the IEEE sequences.  A round is a dependent chain of ~100 fp64 operations either way: that chain
+// times the rounds a root needs (4 on average, 8 at most) times the levels is the floor of this kernel.
+template <int G>
+__device__ __forceinline__ bool secular_root(const double* __restrict__ dl, const double* __restrict__ wv, int K, int i, int sub,
+                                             double rho, int& org_out, double& tau_out, int& evals) {
+  evals = 0;
+  if (K == 1) {
+    org_out = 0;
+    tau_out = rho * wv[0] * wv[0];
+    return true;
+  }
+  const bool last = (i == K - 1);
+  const int i0 = last ? K - 2 : i, i1 = i0 + 1;
+  int org;
+  double lo, hi, f, dpsi, dphi, err;
+  double tau;
+  bool have_eval = false;
+  if (last) {
+    org = K - 1;
+    double s2 = 0.0;
+    for (int j = sub; j < K; j += G) s2 = fma(wv[j], wv[j], s2);
+    lo = 0.0;
+    hi = rho * group_sum<G>(s2);
+    tau = 0.5 * hi;
+  } else {
+    const double gap = dl[i + 1] - dl[i];
+    tau = 0.5 * gap;
+    secular_eval<G>(dl, wv, K, sub, dl[i], tau, rho, i0, f, dpsi, dphi, err);
+    have_eval = true;        // the same point in either shifted variable: value and slopes carry over
+    if (f >= 0.0) {          // root in the lower half: origin = left pole
+      org = i;
+      lo = 0.0;
+      hi = tau;
+    } else {                 // origin = right pole, tau = -gap / 2 there
+      org = i + 1;
+      lo = -tau;
+      hi = 0.0;
+      tau = -tau;
+    }
+  }
+  const double dorg = dl[org];
+  const double d0 = dl[i0] - dorg, d1 = dl[i1] - dorg;
+  bool converged = false;
+  for (int it = 0; it < 100; ++it) {
+    if (!have_eval) secular_eval<G>(dl, wv, K, sub, dorg, tau, rho, i0, f, dpsi, dphi, err);
+    have_eval = false;
+    ++evals;
+    if (fabs(f) <= DC_EPS * err) {
+      converged = true;
+      break;
+    }
+    lo = (f < 0.0) ? tau : lo;
+    hi = (f < 0.0) ? hi : tau;
+    if (hi - lo <= 2.0 * DC_EPS * fmax(fabs(lo), fabs(hi))) {
+      tau = 0.5 * (lo + hi);
+      converged = true;
+      break;
+    }
+    // "middle way": the two neighbouring poles kept exact, the rest matched in value and slope; c eta^2 - a eta + b = 0
+    const double D0 = d0 - tau, D1 = d1 - tau;
+    const double dw = dpsi + dphi;
+    const double dd = D0 * D1;
+    const double a = fma(D0 + D1, f, -dd * dw);
+    const double b = dd * f;
+    const double c = f - fma(D0, dpsi, D1 * dphi);
+    const double disc = fma(a, a, -4.0 * b * c);
+    const bool dok = disc > 0.0 && disc < 1e300;
+    const double dsafe = dok ? disc : 1.0;
+    const double sq = dsafe * dc_rsqrt(dsafe);
+    const double q = 0.5 * (a + copysign(sq, a));
+    const double x1 = fma(q, dc_rcp(c), tau);             // q / c
+    const double x2 = fma(b, dc_rcp(q), tau);             // b / q
+    const double xn = fma(-f, dc_rcp(dw), tau);           // Newton: f is increasing, the step always points at the root
+    const bool ok1 = dok && x1 > lo && x1 < hi;           // (comparisons are false for NaN / inf)
+    const bool ok2 = dok && x2 > lo && x2 < hi;
+    const bool okn = xn > lo && xn < hi;
+    const bool take2 = ok2 && (!ok1 || fabs(x2 - tau) < fabs(x1 - tau));
+    double next = take2 ? x2 : x1;
+    const bool found = ok1 || ok2;
+    next = found ? next : xn;
+    if (!(found || okn)) {                     // bisection, geometric where the bracket spans decades (rare)
+      if (lo > 0.0 && hi > 4.0 * lo) next = sqrt(lo * hi);
+      else if (hi < 0.0 && lo < 4.0 * hi) next = -sqrt(lo * hi);
+      else if (lo == 0.0) next = hi * 0.0625;
+      else if (hi == 0.0) next = lo * 0.0625;
+      else next = 0.5 * (lo + hi);
+    }
+    tau = next;
+  }
+  org_out = org;
+  tau_out = tau;
+  return converged;
+}
+
+template <int G>
+__global__ __launch_bounds__(DC_THREADS) void k_dc(dc_args p) {
+  __shared__ double sD[DC_MAXN], sZ[DC_MAXN], sDs[DC_MAXN], sZs[DC_MAXN], sDl[DC_MAXN], sW[DC_MAXN], sTau[DC_MAXN], sZh[DC_MAXN];
+  __shared__ double sRc[DC_MAXN], sRs[DC_MAXN];
+  __shared__ int sCol[DC_MAXN], sKs[DC_MAXN], sKc[DC_MAXN], sOrg[DC_MAXN], sRa[DC_MAXN], sRb[DC_MAXN];
+  __shared__ double nRho[DC_MAXN / 2], nTol[DC_MAXN / 2];
+  __shared__ int nK[DC_MAXN / 2], nRot[DC_MAXN / 2], nClose[DC_MAXN / 2];
+  __shared__ unsigned long long nDmax[DC_MAXN / 2], nZmax[DC_MAXN / 2];
+  __shared__ int sLive[DC_MAXN];
+  __shared__ int s_fail, s_anyclose;
+#ifdef HFMI_DC_TICKS
+  __shared__ int s_evals, s_evmax, s_roots;
+  if (threadIdx.x == 0) s_evals = s_evmax = s_roots = 0;
+#endif
+  const int n = p.n, tid = threadIdx.x, ldq = p.ldq;
+  double* __restrict__ Q = p.Q;
+  double* __restrict__ S = p.S;
+  if (tid == 0) s_fail = 0;
+  long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#ifdef HFMI_DC_TICKS
+#define DC_TICK(slot)                  \
+  do {                                 \
+    const long long _t = clock64();    \
+    tk[slot] += _t - tlast;            \
+    tlast = _t;                        \
+  } while (0)
+#else
+#define DC_TICK(slot)
+#endif
+  // tearing: every coupling is the split point of exactly one node
+  if (tid < n) {
+    double d = p.dvec[tid];
+    if (tid > 0) d -= fabs(p.evec[tid - 1]);
+    if (tid + 1 < n) d -= fabs(p.evec[tid]);
+    sD[tid] = d;
+  }
+  for (int idx = tid; idx < n * n; idx += DC_THREADS) {
+    const int c = idx / n, r = idx - c * n;
+    Q[(size_t)c * ldq + r] = (r == c) ? 1.0 : 0.0;
+    p.Qt[(size_t)c * ldq + r] = 0.0;     // a level writes the rows of its nodes only: the other rows of a column must be zero in BOTH buffers
+  }
+  __syncthreads();
+  DC_TICK(0);
+
+  double* __restrict__ Qin = p.Q;
+  double* __restrict__ Qout = p.Qt;
+  for (int L = p.levels - 1; L >= 0; --L) {
+    int node = 0, lo = 0, mid = 0, hi = 0;
+    bool active = false;
+    if (tid < n) {
+      dc_node(n, L, tid, node, lo, mid, hi);
+      active = hi - lo >= 2;
+    }
+    if (tid < DC_MAXN / 2) {
+      nDmax[tid] = 0ull;
+      nZmax[tid] = 0ull;
+      nClose[tid] = 0;
+    }
+    if (tid == 0) s_anyclose = 0;
+    __syncthreads();
+    // P1: the rank-one vector: last row of the left child's Q, first row of the right child's; node-wide max |d|, max |z|
+    // (non-negative doubles order like their bit patterns)
+    double zt = 0.0, dt = 0.0, rho = 0.0;
+    if (active) {
+      const double beta = p.evec[mid - 1];
+      rho = 2.0 * fabs(beta);
+      const double q = (tid < mid) ? Qin[(size_t)tid * ldq + (mid - 1)] : (beta >= 0.0 ? 1.0 : -1.0) * Qin[(size_t)tid * ldq + mid];
+      zt = q * 0.70710678118654752440;
+      dt = sD[tid];
+      sZ[tid] = zt;
+      atomicMax(&nDmax[node], (unsigned long long)__double_as_longlong(fabs(dt)));
+      atomicMax(&nZmax[node], (unsigned long long)__double_as_longlong(fabs(zt)));
+    }
+    __syncthreads();
+    DC_TICK(1);
+    // P2: ascending rank inside the node; components below the tolerance drop out (dlaed2's first test); position among the
+    // survivors.  If no two neighbouring survivors turn out to be close (P3) this IS the deflation: nothing is sequential.
+    double tol = 0.0;
+    bool small_t = false;
+    if (active) {
+      const double dmax = __longlong_as_double((long long)nDmax[node]), zmax = __longlong_as_double((long long)nZmax[node]);
+      tol = 8.0 * DC_EPS * fmax(dmax, zmax);
+      const bool skip = rho * zmax <= tol;
+      const double thr = skip ? INFINITY : tol;            // nothing couples: every component counts as small
+      small_t = rho * fabs(zt) <= thr;
+      int rank = 0, pre = 0, cnt = 0;
+      for (int u = lo; u < hi; ++u) {
+        const double du = sD[u], zu = sZ[u];
+        const bool before = du < dt || (du == dt && u < tid);
+        const bool live = !(rho * fabs(zu) <= thr);
+        rank += before ? 1 : 0;
+        pre += (before && live) ? 1 : 0;
+        cnt += live ? 1 : 0;
+      }
+      sDs[lo + rank] = dt;
+      sZs[lo + rank] = zt;
+      sCol[lo + rank] = tid;
+      sLive[lo + rank] = small_t ? 0 : 1;
+      if (!small_t) sKs[lo + pre] = lo + rank;
+      if (tid == lo) {
+        nRho[node] = rho;
+        nTol[node] = tol;
+        nK[node] = cnt;
+        nRot[node] = 0;
+      }
+    }
+    __syncthreads();
+    DC_TICK(2);
+    // P3: dlaed2's second test on every pair of neighbouring survivors, in parallel
+    if (active) {
+      const int s = tid;                                    // sorted position
+      if (sLive[s]) {
+        int pv = s - 1;
+        while (pv >= lo && !sLive[pv]) --pv;
+        if (pv >= lo) {
+          const double zs = sZs[s], zp = sZs[pv];
+          const double t = sDs[s] - sDs[pv];
+          // |t c s| with c = zs / tau, s = -zp / tau, tau^2 = zs^2 + zp^2
+          if (fabs(t * zs * zp) <= tol * fma(zs, zs, zp * zp)) {
+            nClose[node] = 1;
+            s_anyclose = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (s_anyclose) {     // uniform: some node has close poles -> that node's leader redoes the scan sequentially, with rotations
+      if (active && tid == lo && nClose[node]) {
+        int K = 0, nrot = 0, pj = -1;
+        double zp = 0.0, dp = 0.0;
+        for (int s = lo; s < hi; ++s) {
+          const double zs = sZs[s];
+          const bool live = sLive[s] != 0;
+          sLive[s] = 0;
+          if (!live) continue;
+          const double ds = sDs[s];
+          if (pj < 0) {
+            pj = s;
+            zp = zs;
+            dp = ds;
+            continue;
+          }
+          const double tau = sqrt(fma(zs, zs, zp * zp));     // |z| <= 1: no overflow to guard
+          const double c = zs / tau, sn = -zp / tau;
+          const double t = ds - dp;
+          if (fabs(t * c * sn) <= tol) {
+            sZs[pj] = 0.0;
+            sRa[lo + nrot] = pj;
+            sRb[lo + nrot] = s;
+            sRc[lo + nrot] = c;
+            sRs[lo + nrot] = sn;
+            ++nrot;
+            sDs[pj] = dp * c * c + ds * sn * sn;
+            const double dnew = dp * sn * sn + ds * c * c;
+            sDs[s] = dnew;
+            sZs[s] = tau;
+            pj = s;
+            zp = tau;
+            dp = dnew;
+          } else {
+            sLive[pj] = 1;
+            sKs[lo + K++] = pj;
+            pj = s;
+            zp = zs;
+            dp = ds;
+          }
+        }
+        if (pj >= 0) {
+          sLive[pj] = 1;
+          sKs[lo + K++] = pj;
+        }
+        nK[node] = K;
+        nRot[node] = nrot;
+      }
+      __syncthreads();
+    }
+    DC_TICK(3);
+    // P4: the rotations on the columns of Q (this thread's row), kept poles gathered, eigenvalues of all columns refreshed
+    if (active) {
+      const int nrot = nRot[node];
+      for (int q = 0; q < nrot; ++q) {
+        const int ca = sCol[sRa[lo + q]], cb = sCol[sRb[lo + q]];
+        const double c = sRc[lo + q], sn = sRs[lo + q];
+        const double qa = Qin[(size_t)ca * ldq + tid], qb = Qin[(size_t)cb * ldq + tid];
+        Qin[(size_t)ca * ldq + tid] = c * qa + sn * qb;
+        Qin[(size_t)cb * ldq + tid] = c * qb - sn * qa;
+      }
+      const int i = tid - lo;
+      if (i < nK[node]) {
+        const int pos = sKs[tid];
+        sDl[tid] = sDs[pos];
+        sW[tid] = sZs[pos];
+        sKc[tid] = sCol[pos];
+      }
+      sD[sCol[tid]] = sDs[tid];
+    }
+    __syncthreads();
+    DC_TICK(4);
+    // P5-P7 with GL lanes per root, GL chosen per level: the lanes of a group all execute the ~150 instructions of a round, so
+    // small nodes (few poles per root) get few lanes -- at k = 74 the seven levels then keep 2, 2, 3, 3, 5, 10, 10 waves busy
+    // instead of 10 each, and a round costs its own issue time instead of three waves' worth per SIMD
+    auto secular_phases = [&](auto gtag) {
+      constexpr int GL = decltype(gtag)::value;
+      const int slot = tid / GL, sub = tid % GL;
+      int nd = 0, l2 = 0, m2 = 0, h2 = 0, K = 0;
+      if (slot < n) {
+        dc_node(n, L, slot, nd, l2, m2, h2);
+        K = (h2 - l2 >= 2) ? nK[nd] : 0;
+      }
+      const int i = slot - l2;
+      const bool mine = slot < n && i < K;
+      // P5: secular equation
+      if (mine) {
+        int org;
+        double tau;
+        int evals;
+        const bool ok = secular_root<GL>(sDl + l2, sW + l2, K, i, sub, nRho[nd], org, tau, evals);
+        if (sub == 0) {
+          sTau[slot] = tau;
+          sOrg[slot] = org;
+          if (!ok) s_fail = 1;
+#ifdef HFMI_DC_TICKS
+          atomicAdd(&s_evals, evals);
+          atomicMax(&s_evmax, evals);
+          atomicAdd(&s_roots, 1);
+#endif
+        }
+      }
+      __syncthreads();
+      DC_TICK(5);
+      // P6: Gu-Eisenstat: the rank-one vector for which the COMPUTED roots are exact
+      if (mine) {
+        const double* dl = sDl + l2;
+        const double di = dl[i];
+        double prod = 1.0;
+        for (int j = sub; j < K; j += GL) {
+          const double num = (dl[sOrg[l2 + j]] - di) + sTau[l2 + j];     // lam_j - dl_i
+          prod *= (j == i) ? num : num * dc_rcp(dl[j] - di);
+        }
+        prod = group_prod<GL>(prod);
+        if (sub == 0) sZh[slot] = copysign(sqrt(fabs(prod)), sW[slot]);
+      }
+      __syncthreads();
+      DC_TICK(6);
+      // P7: eigenvectors of the rank-one problem, normalised, and the new eigenvalues
+      if (mine) {
+        const double* dl = sDl + l2;
+        const double dorg = dl[sOrg[slot]], tau = sTau[slot];
+        double nrm = 0.0;
+        for (int q = sub; q < K; q += GL) {
+          const double sv = sZh[l2 + q] * dc_rcp((dl[q] - dorg) - tau);
+          nrm = fma(sv, sv, nrm);
+        }
+        nrm = group_sum<GL>(nrm);
+        const double inv = dc_rsqrt(nrm);
+        for (int q = sub; q < K; q += GL) {
+          const double sv = sZh[l2 + q] * dc_rcp((dl[q] - dorg) - tau);
+          S[(size_t)(l2 + q) * ldq + (l2 + i)] = sv * inv;
+        }
+        if (sub == 0) sD[sKc[slot]] = dorg + tau;
+      }
+      __syncthreads();
+      DC_TICK(7);
+    };
+    {
+      const int nnmax = (n + (1 << L) - 1) >> L;
+      if (nnmax <= 4) secular_phases(std::integral_constant<int, 1>());
+      else if (nnmax <= 12 || G < 4) secular_phases(std::integral_constant<int, 2>());
+      else if (nnmax <= 40 || G < 8) secular_phases(std::integral_constant<int, 4>());
+      else secular_phases(std::integral_constant<int, 8>());
+    }
+    // P8: Qout[:, kept] = Qin[:, kept] S on the fp64 MFMA (rows of the node only: Q is block diagonal by construction); every
+    // other column moves over unchanged
+    if (L == 0 && p.split_top) {
+      if (tid == 0) p.top_meta[0] = nK[0];
+      if (tid < n) {
+        p.top_meta[1 + tid] = sKc[tid];
+        p.top_meta[1 + DC_MAXN + tid] = sLive[tid];
+        p.top_meta[1 + 2 * DC_MAXN + tid] = sCol[tid];
+      }
+    } else {
+      const int nnmax = (n + (1 << L) - 1) >> L;
+      const int tpn = (nnmax + 15) >> 4, tiles = (1 << L) * tpn * tpn;
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, li = l & 15, lk = l >> 4;
+      for (int tile = wv; tile < tiles; tile += DC_WAVES) {
+        const int nd = tile / (tpn * tpn), rem = tile - nd * tpn * tpn;
+        const int tr = rem / tpn, tc = rem - tr * tpn;
+        const int l2 = (nd * n) >> L, h2 = ((nd + 1) * n) >> L;
+        if (h2 - l2 < 2) continue;
+        const int K = nK[nd];
+        const int r0 = l2 + tr * 16, j0 = tc * 16;
+        if (j0 >= K || r0 >= h2) continue;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool colok = j0 + li < K, rowok = r0 + li < h2;
+        for (int k0 = 0; k0 < K; k0 += 32) {     // eight k-steps of loads in flight before the first MFMA needs one
+          double a[8], b[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int ki = k0 + 4 * u + lk;
+            a[u] = 0.0;
+            b[u] = 0.0;
+            if (ki < K) {
+              if (colok) a[u] = S[(size_t)(l2 + ki) * ldq + (l2 + j0 + li)];
+              if (rowok) b[u] = Qin[(size_t)sKc[l2 + ki] * ldq + (r0 + li)];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = MFMA_F64(a[u], b[u], acc);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int jc = j0 + lk + 4 * reg;
+          if (jc < K && rowok) Qout[(size_t)sKc[l2 + jc] * ldq + (r0 + li)] = acc[reg];
+        }
+      }
+      const int total = n * nnmax;           // (sorted position, row offset)
+      for (int idx = tid; idx < total; idx += DC_THREADS) {
+        const int sp = idx / nnmax, ro = idx - sp * nnmax;
+        int nd, l2, m2, h2;
+        dc_node(n, L, sp, nd, l2, m2, h2);
+        if (l2 + ro >= h2) continue;
+        const bool act = h2 - l2 >= 2;
+        if (act && sLive[sp]) continue;        // a kept column: written by the product above
+        const size_t off = (size_t)(act ? sCol[sp] : sp) * ldq + (l2 + ro);
+        Qout[off] = Qin[off];
+      }
+    }
+    __syncthreads();
+    DC_TICK(8);
+    {
+      double* const t = Qin;
+      Qin = Qout;
+      Qout = t;
+    }
+  }
+  // output order: descending (by magnitude on request), ties by column
+  if (tid < n) {
+    const double dt = sD[tid];
+    const double key = p.sort_by_abs ? fabs(dt) : dt;
+    int rank = 0;
+    for (int u = 0; u < n; ++u) {
+      const double du = p.sort_by_abs ? fabs(sD[u]) : sD[u];
+      rank += (du > key || (du == key && u < tid)) ? 1 : 0;
+    }
+    p.perm[tid] = rank;
+    p.dvals[rank] = ldexp(dt, *p.sexp);
+  }
+  DC_TICK(10);
+  if (tid == 0) {
+#ifdef HFMI_DC_TICKS
+    tk[11] = ((long long)s_evmax << 40) | ((long long)s_roots << 20) | (long long)s_evals;
+#endif
+    for (int q = 0; q < 12; ++q) p.ticks[q] = tk[q];
+    p.status->failed = s_fail;
+    p.status->sweeps = p.levels;
+    p.status->offdiag = 0.0;
+    p.status->tick[4] = 2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ last merge, all CUs
+// Qout[:, kept] = Qin[:, kept] S for the root node (rows 0 .. n): one wave per 16 x 16 tile, the other columns copied by the
+// remaining workgroups.  Inside k_dc the same product is 81 tiles on one CU with every operand an L2 round trip away (k = 138:
+// 107 us); here each tile is one latency chain on its own CU.
+__global__ __launch_bounds__(64) void k_dc_top(const double* __restrict__ Qin, double* __restrict__ Qout, const double* __restrict__ S,
+                                               int ldq, int n, const int* __restrict__ meta) {
+  const int K = meta[0];
+  const int* __restrict__ kc = meta + 1;
+  const int* __restrict__ live = meta + 1 + DC_MAXN;
+  const int* __restrict__ colof = meta + 1 + 2 * DC_MAXN;
+  const int T = (n + 15) >> 4, l = threadIdx.x, li = l & 15, lk = l >> 4;
+  const int b = blockIdx.x;
+  if (b < T * T) {
+    const int tr = b / T, tc = b - tr * T;
+    const int r0 = tr * 16, j0 = tc * 16;
+    if (j0 >= K) return;
+    const bool colok = j0 + li < K, rowok = r0 + li < n;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 64) {       // sixteen k-steps of loads in flight
+      double a[16], bb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int ki = k0 + 4 * u + lk;
+        a[u] = 0.0;
+        bb[u] = 0.0;
+        if (ki < K) {
+          if (colok) a[u] = S[(size_t)ki * ldq + (j0 + li)];
+          if (rowok) bb[u] = Qin[(size_t)kc[ki] * ldq + (r0 + li)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = MFMA_F64(a[u], bb[u], acc);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int jc = j0 + lk + 4 * reg;
+      if (jc < K && rowok) Qout[(size_t)kc[jc] * ldq + (r0 + li)] = acc[reg];
+    }
+  } else {
+    // copy duty: sorted positions sp = b - T*T, b - T*T + (copy blocks), ...
+    const int nb = gridDim.x - T * T;
+    for (int sp = b - T * T; sp < n; sp += nb) {
+      if (live[sp]) continue;
+      const int c = colof[sp];
+      for (int r = l; r < n; r += 64) Qout[(size_t)c * ldq + r] = Qin[(size_t)c * ldq + r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ back-transformation
+// V_out[:, perm[c]] = H_0 H_1 ... H_{n-3} Q[:, c].  A wave carries four eigenvectors, 16 lanes each: lane m of a group holds
+// rows m, m + 16, ...; the reflector rows are shared by the four groups.
+template <int EL>
+__global__ __launch_bounds__(64) void k_dc_back(const double* __restrict__ Q, int ldq, int n, const double* __restrict__ Vh, int ldv,
+                                                const double* __restrict__ tauv, const int* __restrict__ perm,
+                                                double* __restrict__ Vout, int ldo) {
+  const int l = threadIdx.x, g = l >> 4, m = l & 15;
+  const int col = blockIdx.x * 4 + g;
+  const bool live = col < n;
+  double z[EL], v[EL], vn[EL];
+#pragma unroll
+  for (int e = 0; e < EL; ++e) {
+    const int r = m + 16 * e;
+    z[e] = (live && r < n) ? Q[(size_t)col * ldq + r] : 0.0;
+  }
+  int j = n - 3;
+  if (j >= 0) {
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const int r = m + 16 * e;
+      vn[e] = (r < ldv) ? Vh[(size_t)j * ldv + r] : 0.0;
+    }
+  }
+  for (; j >= 0; --j) {
+#pragma unroll
+    for (int e = 0; e < EL; ++e) v[e] = vn[e];
+    if (j > 0) {
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        const int r = m + 16 * e;
+        vn[e] = (r < ldv) ? Vh[(size_t)(j - 1) * ldv + r] : 0.0;
+      }
+    }
+    const double tau = tauv[j];
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) dot = fma(v[e], z[e], dot);
+    dot = group_sum<16>(dot);
+    const double f = -tau * dot;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) z[e] = fma(f, v[e], z[e]);
+  }
+  if (live) {
+    const int pc = perm[col];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const int r = m + 16 * e;
+      if (r < n) Vout[(size_t)r * ldo + pc] = z[e];
+    }
+  }
+}
+}  // namespace
+
+// T (k x k, SM slot, row-major) -> eigenvalues (descending, or by magnitude) into dvals (device, k), eigenvectors into the
+// columns of slot_v.  Same contract as launch_jacobi_eig.
+int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs) {
+  if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "dc_eig: k=%d out of range", k);
+  const int ldq = (int)round_up(k, 16);
+  const size_t mat = (size_t)ldq * ldq;
+  // scratch: d, e, tau (3 x 256), reflectors (256 x ldq), Q, Qt, S, perm + scale exponent
+  const size_t doubles = 3 * DC_MAXN + (size_t)DC_MAXN * ldq + 3 * mat;
+  void* wv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_MISC, doubles * sizeof(double) + (DC_MAXN + 16) * sizeof(int) + 16 * sizeof(long long) + (3 * DC_MAXN + 16) * sizeof(int), &wv));
+  double* dvec = (double*)wv;
+  double* evec = dvec + DC_MAXN;
+  double* tauv = evec + DC_MAXN;
+  double* Vh = tauv + DC_MAXN;
+  double* Qm = Vh + (size_t)DC_MAXN * ldq;
+  double* Qt = Qm + mat;
+  double* Sm = Qt + mat;
+  int* perm = (int*)(Sm + mat);
+  int* sexp = perm + DC_MAXN;
+  long long* ticks = (long long*)(sexp + 16);
+  int* top_meta = (int*)(ticks + 16);
+  const double* T = sm_ptr(ctx, slot_t);
+  static int tri_waves = 0;     // HFMI_TRI_WAVES = 4 | 8: A/B of the workgroup shape
+  if (!tri_waves) {
+    const char* e = getenv("HFMI_TRI_WAVES");
+    tri_waves = (e && atoi(e) == 4) ? 4 : 8;
+  }
+#define TRI(RIV, CJV, NWV)                                                                                                        \
+  hipLaunchKernelGGL((k_tridiag<RIV, CJV, NWV>), dim3(1), dim3(64 * NWV), 0, ctx->stream, T, SM_LD, k, dvec, evec, Vh, ldq, tauv, \
+                     sexp, ticks)
+  if (tri_waves == 4) {
+    if (k <= 32) TRI(8, 1, 4);
+    else if (k <= 64) TRI(16, 1, 4);
+    else if (k <= 80) TRI(20, 2, 4);
+    else if (k <= 96) TRI(24, 2, 4);
+    else if (k <= 128) TRI(32, 2, 4);
+    else if (k <= 144) TRI(36, 3, 4);
+    else if (k <= 160) TRI(40, 3, 4);
+    else if (k <= 192) TRI(48, 3, 4);
+    else TRI(64, 4, 4);
+  } else {
+    if (k <= 32) TRI(4, 1, 8);
+    else if (k <= 64) TRI(8, 1, 8);
+    else if (k <= 96) TRI(12, 2, 8);
+    else if (k <= 128) TRI(16, 2, 8);
+    else if (k <= 160) TRI(20, 3, 8);
+    else if (k <= 192) TRI(24, 3, 8);
+    else TRI(32, 4, 8);
+  }
+#undef TRI
+  HIP_TRY(hipGetLastError());
+  dc_args a;
+  a.n = k;
+  a.levels = 0;
+  while ((1 << a.levels) < k) ++a.levels;
+  a.sort_by_abs = sort_by_abs ? 1 : 0;
+  a.dvec = dvec;
+  a.evec = evec;
+  a.sexp = sexp;
+  a.Q = Qm;
+  a.Qt = Qt;
+  a.S = Sm;
+  a.ldq = ldq;
+  a.dvals = dvals;
+  a.perm = perm;
+  a.status = ctx->status_dev;
+  a.ticks = ticks;
+  static int split_top = -1;    // HFMI_DC_SPLIT_TOP=0: the last merge's product inside k_dc (A/B)
+  if (split_top < 0) {
+    const char* e = getenv("HFMI_DC_SPLIT_TOP");
+    split_top = e ? atoi(e) : 1;
+  }
+  a.split_top = (split_top && k >= 32) ? 1 : 0;
+  a.top_meta = top_meta;
+  if (k <= 128) hipLaunchKernelGGL((k_dc<8>), dim3(1), dim3(DC_THREADS), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_dc<4>), dim3(1), dim3(DC_THREADS), 0, ctx->stream, a);
+  HIP_TRY(hipGetLastError());
+  if (a.split_top) {
+    // level 0 is the last of `levels` merges: its input is the buffer after levels - 1 swaps
+    const double* Qin0 = ((a.levels - 1) & 1) ? Qt : Qm;
+    double* Qout0 = ((a.levels - 1) & 1) ? Qm : Qt;
+    const int T = (k + 15) / 16;
+    hipLaunchKernelGGL(k_dc_top, dim3(T * T + 16), dim3(64), 0, ctx->stream, Qin0, Qout0, Sm, ldq, k, top_meta);
+    HIP_TRY(hipGetLastError());
+  }
+  double* Vout = sm_ptr(ctx, slot_v);
+  const int blocks = (k + 3) / 4;
+  const double* Qfin = (a.levels & 1) ? Qt : Qm;     // the merges ping-pong between the two buffers, one swap per level
+#define BACK(ELV) \
+  hipLaunchKernelGGL((k_dc_back<ELV>), dim3(blocks), dim3(64), 0, ctx->stream, Qfin, ldq, k, Vh, ldq, tauv, perm, Vout, SM_LD)
+  if (k <= 80) BACK(5);
+  else if (k <= 96) BACK(6);
+  else if (k <= 128) BACK(8);
+  else if (k <= 144) BACK(9);
+  else if (k <= 192) BACK(12);
+  else BACK(16);
+#undef BACK
+  HIP_TRY(hipGetLastError());
+  static const bool timing = getenv("HFMI_DC_TIMING") != nullptr;
+  if (timing) {
+    long long h[16];
+    HIP_TRY(hipMemcpyAsync(h, ticks, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    fprintf(stderr, "[hfmi dc k=%d] ticks: init %lld | z %lld | rank %lld | pair test (+ scan) %lld | rot+gather %lld | secular %lld | loewner %lld | S %lld | gemm + copy %lld | - %lld | sort %lld\n",
+            k, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+    fprintf(stderr, "[hfmi dc k=%d] secular: %lld roots, %lld evaluations, at most %lld for one root\n", k, (h[11] >> 20) & 0xfffff, h[11] & 0xfffff, h[11] >> 40);
+    fprintf(stderr, "[hfmi tridiag k=%d] wave-0 ticks: (b) slices + barrier %lld | p, dot %lld | update (+ next reflector every 4th step) %lld | waiting for the owner %lld\n",
+            k, h[12], h[13], h[14], h[15]);
+  }
+  return HFMI_OK;
+}

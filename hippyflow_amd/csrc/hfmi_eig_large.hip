@@ -34,20 +34,30 @@ __global__ void __launch_bounds__(EL_THREADS) k_jacobi_large_cols(double* __rest
   }
   double* tp = T + (int64_t)p * ld;
   double* tq = T + (int64_t)q * ld;
-  const double app = tp[p], aqq = tq[q], apq = tq[p];
-  const double eps = 2.220446049250313e-16;
-  const bool rotate = fabs(apq) > eps * sqrt(fabs(app * aqq)) && fabs(apq) > abs_floor;
-  if (!rotate) {
-    if (threadIdx.x == 0) cs[blockIdx.x] = make_double2(1.0, 0.0);
-    return;
-  }
-  const double tau = (aqq - app) / (2.0 * apq);
-  const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-  const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+  // ONE thread reads the pivot entries and decides: the loop below overwrites exactly those entries (rows p and q of the
+  // two columns), so a wavefront that started late must not derive its own (c, s) from half-rotated values
+  __shared__ double sh_c, sh_s;
+  __shared__ int sh_rotate;
   if (threadIdx.x == 0) {
+    const double app = tp[p], aqq = tq[q], apq = tq[p];
+    const double eps = 2.220446049250313e-16;
+    const bool rot = fabs(apq) > eps * sqrt(fabs(app * aqq)) && fabs(apq) > abs_floor;
+    double c = 1.0, s = 0.0;
+    if (rot) {
+      const double tau = (aqq - app) / (2.0 * apq);
+      const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+      c = 1.0 / sqrt(1.0 + t * t);
+      s = t * c;
+      atomicAdd(nrot, 1u);
+    }
     cs[blockIdx.x] = make_double2(c, s);
-    atomicAdd(nrot, 1u);
+    sh_c = c;
+    sh_s = s;
+    sh_rotate = rot ? 1 : 0;
   }
+  __syncthreads();
+  if (!sh_rotate) return;            // uniform: every thread reads the same flag after the barrier
+  const double c = sh_c, s = sh_s;
   double* vp = V + (int64_t)p * ld;
   double* vq = V + (int64_t)q * ld;
   for (int r = threadIdx.x; r < n; r += EL_THREADS) {

@@ -218,6 +218,12 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
                     int full_r, double shift_rel, double pivot_tol);
 // T (k x k) -> eigenvalues (sorted descending) into dvals (device, k), eigenvectors into slot_v (columns).
 int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs);
+// the same contract by Householder tridiagonalisation + divide and conquer (hfmi_eig_dc.hip): LAPACK dsyevd's algorithm
+// family, i.e. what the reference's np.linalg.eigh runs; absolute accuracy eps ||T||
+int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs);
+// dispatcher: method 0 = default (divide and conquer unless tuning "eig" = 1), 1 = Jacobi (high relative accuracy)
+int launch_sym_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs, int method);
+int eig_tuning_set(const char* key, int value);   // 1 = key handled
 int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);
 // slot_c (k x r, zero padded to 16 columns) = slot_a (k x k) * slot_b[:, :r]
 int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int slot_c);

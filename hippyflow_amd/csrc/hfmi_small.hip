@@ -9,6 +9,7 @@
 #include "hfmi_internal.h"
 
 #include <stdlib.h>
+#include <string.h>
 #define SMALL_THREADS 1024
 #define EPS_D 2.220446049250313e-16
 // workgroup size of the one-workgroup kernels (tuning knob for experiments: HFMI_SMALL_THREADS)
@@ -1638,4 +1639,24 @@ int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dval
                        sm_ptr(ctx, slot_v), SM_LD);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
+}
+
+// Rayleigh-Ritz eigensolver selection.  Default: divide and conquer (hfmi_eig_dc.hip; k = 74: 0.68 -> about 0.15 ms).  The
+// Jacobi kernels above stay for callers that want the high RELATIVE accuracy of small eigenvalues of graded positive
+// definite matrices (hfmi_sym_eig_small flag bit 1, hfmi_double_pass flag bit 3) and for A/B runs (tuning "eig" = 1).
+static int g_eig_default = -1;
+int eig_tuning_set(const char* key, int value) {
+  if (key && !strcmp(key, "eig") && (value == 0 || value == 1)) {
+    g_eig_default = value;
+    return 1;
+  }
+  return 0;
+}
+int launch_sym_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs, int method) {
+  if (g_eig_default < 0) {
+    const char* e = getenv("HFMI_EIG");
+    g_eig_default = (e && !strcmp(e, "jacobi")) ? 1 : 0;
+  }
+  if (method == 1 || g_eig_default == 1) return launch_jacobi_eig(ctx, k, slot_t, slot_v, dvals, sort_by_abs);
+  return launch_dc_eig(ctx, k, slot_t, slot_v, dvals, sort_by_abs);
 }

@@ -138,18 +138,24 @@ def _save(directory, name, array):
 def _draw_omega(N, nvec, collective, ctx, stored=None):
     """Probe block.  The reference draws on rank 0 and broadcasts k vectors of length N
     (activeSubspaceProjector.py:433-443,536-551).  Here rank 0's generator state (seed, stream) -- 16 bytes -- is
-    what is broadcast; every rank then regenerates the same counter-based Philox block in its own HBM, whatever
-    its own generator had been used for before (per-rank sample draws, perturbations ...).  A stored Omega
-    (unit-test path) is broadcast from rank 0 as a block."""
+    what is broadcast; every rank then regenerates the same counter-based Philox block in its own HBM from a
+    TEMPORARY generator holding that state.  The process-wide ``parRandom`` of the other ranks is left alone, as in
+    the reference (hp.parRandom is rank-split and only Omega travels): per-rank sample draws that follow -- the noise
+    of the serialized-sampling Jacobian operator, ``normal_perturb`` -- stay distinct when the ranks were seeded
+    differently.  Rank 0's generator advances by the one stream the draw consumed.  A stored Omega (unit-test path)
+    is broadcast from rank 0 as a block."""
     if stored is not None:
         Omega = MultiVector(stored)
         collective.bcast(Omega, root=0)
         return Omega
     state = np.array([parRandom.seed & (2 ** 64 - 1), parRandom.stream & 0xFFFFFFFF], dtype=np.uint64)
     state = collective.bcast(state, root=0)
-    parRandom.reseed(int(state[0]), int(state[1]))
+    draw = type(parRandom)(int(state[0]))
+    draw.stream = int(state[1])
     Omega = MultiVector(int(N), int(nvec), ctx=ctx)
-    parRandom.normal(1., Omega)
+    draw.normal(1., Omega)
+    if _is_root(collective):
+        parRandom.stream += 1
     return Omega
 
 

@@ -51,12 +51,17 @@ class _ParRandom:
 parRandom = _ParRandom()
 
 
-def sym_eig_small(T, sort_by_abs=False, ctx=None):
-    """np.linalg.eigh(T) + descending sort, on the device (one-workgroup Jacobi)."""
+def sym_eig_small(T, sort_by_abs=False, ctx=None, method="dc"):
+    """np.linalg.eigh(T) + descending sort, on the device.  ``method="dc"``: Householder tridiagonalisation + divide
+    and conquer (the algorithm family of the LAPACK routine behind np.linalg.eigh); ``"jacobi"``: one-workgroup
+    cyclic Jacobi (high relative accuracy of small eigenvalues of graded positive definite matrices)."""
+    if method not in ("dc", "jacobi"):
+        raise ValueError("sym_eig_small: method must be 'dc' or 'jacobi'")
     T = L.as_f64(T)
     k = T.shape[0]
     d, V = np.empty(k), np.empty((k, k))
-    L.call("hfmi_sym_eig_small", (ctx or L.Context.default()).handle, L.ptr(T), k, 1 if sort_by_abs else 0, L.ptr(d), L.ptr(V))
+    flags = (1 if sort_by_abs else 0) | (2 if method == "jacobi" else 0)
+    L.call("hfmi_sym_eig_small", (ctx or L.Context.default()).handle, L.ptr(T), k, flags, L.ptr(d), L.ptr(V))
     return d, V
 
 

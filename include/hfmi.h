@@ -208,11 +208,16 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
 
 /* ---------------------------------------------------------------- Rayleigh-Ritz (a8)
  * np.linalg.eigh(T) + descending sort: symmetric k x k (host, row-major; the
- * symmetric part is used), eigenvalues descending (by |d| if sort_by_abs),
- * eigenvectors in the columns of V (row-major k x k).  k <= 256: one-workgroup parallel
- * cyclic Jacobi in LDS (the Rayleigh-Ritz step of the double pass).  256 < k <= 4096: two-sided
- * Jacobi over the whole GPU, one workgroup per index pair of a round (the n x n Gram problem of the
- * deterministic POD, la.eigh at PODProjector.py:821). */
+ * symmetric part is used), eigenvalues descending, eigenvectors in the columns of V
+ * (row-major k x k).  sort_by_abs is a flag word: bit 0 = order by |d|; bit 1 = HFMI_EIG_JACOBI.
+ * k <= 256, default: Householder tridiagonalisation + divide and conquer on one compute unit
+ * (hfmi_eig_dc.hip) -- the algorithm family of the LAPACK routine behind np.linalg.eigh, absolute
+ * accuracy eps ||T||.  HFMI_EIG_JACOBI: one-workgroup parallel cyclic Jacobi in LDS (slower; small
+ * eigenvalues of graded positive definite matrices to high RELATIVE accuracy).
+ * 256 < k <= 4096: two-sided Jacobi over the whole GPU, one workgroup per index pair of a round
+ * (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821). */
+#define HFMI_EIG_SORT_ABS 1
+#define HFMI_EIG_JACOBI 2
 int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,
                        double* host_V);
 
@@ -226,7 +231,8 @@ int hfmi_svd_small(hfmi_ctx* ctx, const double* host_R, int k, double* host_sigm
  * Omega has k >= r vectors and is not modified; on return host_d[r] holds the
  * eigenvalues (descending) and U (r vectors) the (B-)orthonormal eigenvectors.
  * Everything stays on the device between the first apply and the final U.
- * flags: bit 0 = sort by |d|;  bit 1 = use HFMI_QR_MGS;  bit 2 = form T = (A Q)^T Q literally (by default, for
+ * flags: bit 0 = sort by |d|;  bit 1 = use HFMI_QR_MGS;  bit 3 = Jacobi instead of divide and conquer for the
+ * k x k Rayleigh-Ritz problem;  bit 2 = form T = (A Q)^T Q literally (by default, for
  * operators of Gram form A = scale X^T Gamma X the same matrix is formed as scale (X Q)^T Gamma (X Q), which skips
  * the second N x k block product and shrinks the rank average of that pass to k x k). */
 int hfmi_double_pass(hfmi_op* A, const hfmi_block* Omega, int r, int s, int flags, double* host_d,
@@ -255,7 +261,8 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * barriers; results are garbage -- scripts/tn_probe.py); ("nn_waves", 0|4|8) and ("nn_tt", 0..3)
  * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("nn_res", 1|0) small matrix resident in LDS with persistent
  * workgroups when it fits (short reductions: Q R^-1, U = Q V); ("ss", 0|1) route skinny x skinny contractions to
- * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized. */
+ * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized; ("eig", 0|1) Rayleigh-Ritz
+ * eigensolver of every call: divide and conquer | Jacobi. */
 int hfmi_tuning_set(const char* key, int value);
 /* phases of hfmi_double_pass[_g], accumulated between hfmi_profile_begin and hfmi_profile_end (milliseconds, summed
  * over the solves in the region; device phases by HIP events on the context's stream, the HOST_* legs by the host's

@@ -326,32 +326,95 @@ def test_Borthogonalize(ctx, method):
 
 
 # ------------------------------------------------------------------ small eigensolve (a8)
-@pytest.mark.parametrize("k", [1, 2, 5, 30, 31, 74, 84, 137, 138, 200, 256])
-def test_sym_eig_small_matches_eigh(ctx, k):
+@pytest.mark.parametrize("method", ["dc", "jacobi"])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 16, 17, 30, 31, 64, 65, 74, 80, 81, 84, 96, 97, 128, 129, 137, 138, 144, 145, 148, 192, 193, 200, 256])
+def test_sym_eig_small_matches_eigh(ctx, k, method):
     rng = np.random.default_rng(k)
     Qm = np.linalg.qr(rng.standard_normal((k, k)))[0]
     lam = np.exp(-0.25 * np.arange(k)) * np.where(np.arange(k) % 7 == 3, -1.0, 1.0)   # decaying, some negative
     T = (Qm * lam) @ Qm.T
     T = 0.5 * (T + T.T)
-    d, V = hf.sym_eig_small(T)
+    d, V = hf.sym_eig_small(T, method=method)
     w = np.linalg.eigvalsh(T)[::-1]
     assert np.max(np.abs(d - w)) < 1e-14 * k * np.abs(w).max()
     assert np.all(np.diff(d) <= 0)
     assert np.linalg.norm(V.T @ V - np.eye(k)) < 1e-13 * k
     assert np.linalg.norm(T @ V - V * d) < 1e-13 * k * np.abs(w).max()
-    d_abs, _ = hf.sym_eig_small(T, sort_by_abs=True)
+    d_abs, _ = hf.sym_eig_small(T, sort_by_abs=True, method=method)
     assert np.all(np.diff(np.abs(d_abs)) <= 0)
 
 
+def _hard_spectra():
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((74, 74))
+    yield "random", A + A.T
+    X = rng.standard_normal((60, 20))
+    yield "rank-deficient", X @ X.T
+    yield "identity", np.eye(50)
+    yield "zero", np.zeros((20, 20))
+    Q = np.linalg.qr(rng.standard_normal((100, 100)))[0]
+    lam = np.concatenate([np.ones(40), np.ones(30) * (1 + 1e-10), np.linspace(0, 1, 30)])
+    T = (Q * lam) @ Q.T
+    yield "clusters", 0.5 * (T + T.T)
+    n = 41
+    yield "wilkinson", np.diag(np.abs(np.arange(n) - 20.0)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    n = 128
+    yield "laplace", 2 * np.eye(n) - np.diag(np.ones(n - 1), 1) - np.diag(np.ones(n - 1), -1)
+    J = rng.standard_normal((6400, 74))
+    yield "wishart", J.T @ J
+    J = rng.standard_normal((2048, 138)) * np.exp(-0.05 * np.arange(138))
+    yield "decay138", J.T @ J
+    yield "huge", 1e150 * (A + A.T)
+    yield "tiny", 1e-150 * (A + A.T)
+    yield "diagonal", np.diag(np.arange(70.0) - 30.0)
+    B = rng.standard_normal((250, 250))
+    yield "random250", B + B.T
+
+
+@pytest.mark.parametrize("name,T", list(_hard_spectra()), ids=[n for n, _ in _hard_spectra()])
+def test_sym_eig_small_divide_and_conquer_hard_spectra(ctx, name, T):
+    """The cases tests/test_dc_twin.py runs through the numpy twin, through the kernels: deflation by small components
+    and by close poles, all-deflated merges, clusters, exact zeros, scaling."""
+    k = T.shape[0]
+    d, V = hf.sym_eig_small(T, method="dc")
+    w = np.linalg.eigvalsh(T)[::-1]
+    nrm = max(np.abs(w).max(), 1e-300)
+    assert np.all(np.diff(d) <= 0)
+    assert np.max(np.abs(d - w)) < 1e-14 * k * nrm
+    assert np.linalg.norm(V.T @ V - np.eye(k)) < 1e-13 * k
+    assert np.linalg.norm(T @ V - V * d) < 1e-13 * k * nrm
+
+
+def test_sym_eig_small_dc_equals_numpy_twin(ctx):
+    """Same tree, same deflation rule, same secular iteration: kernel and twin agree far below the error of either."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import dc_eig_twin as tw
+    rng = np.random.default_rng(11)
+    J = rng.standard_normal((500, 74))
+    T = J.T @ J
+    d, V = hf.sym_eig_small(T, method="dc")
+    dt, Vt = tw.eigh_dc(T)
+    assert np.max(np.abs(d - dt)) < 5e-15 * np.abs(dt).max()
+    sgn = np.sign(np.sum(V * Vt, axis=0))
+    assert np.abs(V * sgn - Vt).max() < 1e-11
+
+
 def test_sym_eig_small_graded_relative_accuracy(ctx):
-    """Jacobi resolves tiny eigenvalues of a graded PSD matrix to high relative accuracy."""
+    """Jacobi (method="jacobi") resolves tiny eigenvalues of a graded PSD matrix to high relative accuracy; divide and
+    conquer, like the LAPACK routine behind the reference's np.linalg.eigh, to eps ||T|| absolutely."""
     rng = np.random.default_rng(3)
     k = 40
     G = rng.standard_normal((200, k)) @ np.diag(np.logspace(0, -6, k))
     T = G.T @ G
-    d, _ = hf.sym_eig_small(T)
     w = np.linalg.svd(G, compute_uv=False) ** 2
+    d, _ = hf.sym_eig_small(T, method="jacobi")
     assert np.max(np.abs(d - w) / w) < 1e-9
+    d, _ = hf.sym_eig_small(T, method="dc")
+    assert np.max(np.abs(d - w)) < 1e-14 * k * w[0]
+    ref = np.linalg.eigvalsh(T)[::-1]
+    assert np.max(np.abs(d - w)) < 20 * max(np.max(np.abs(ref - w)), 1e-16 * w[0])    # no worse than LAPACK's eigh in kind
 
 
 @pytest.mark.parametrize("k", [1, 2, 7, 30, 75, 138, 200])
