@@ -76,6 +76,9 @@ SIGNATURES = {
     "hfmi_comm_init_rank": [_P, _P, C.c_int, C.c_int, _PP],
     "hfmi_comm_init_from_file": [_P, C.c_char_p, C.c_int, C.c_int, _PP],
     "hfmi_comm_info": [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "hfmi_comm_describe": [_P, C.c_char_p, C.c_int],
+    "hfmi_comm_decide_transport": [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.c_int,
+                                   C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "hfmi_comm_barrier": [_P],
     "hfmi_allreduce": [_P, _P, C.c_int],
     "hfmi_bcast": [_P, _P, C.c_int],

@@ -237,6 +237,13 @@ class NativeCollective(_Collective):
     def barrier(self):
         L.call("hfmi_comm_barrier", self._comm)
 
+    def describe(self):
+        """What the ranks agreed on and why (transport, fallback reason, RCCL library, every rank's PCI bus id)."""
+        import json
+        buf = C.create_string_buffer(4096)
+        L.call("hfmi_comm_describe", self._comm, buf, len(buf))
+        return json.loads(buf.value.decode())
+
     def allReduceMax(self, value):
         """Largest value over the ranks (bench.py's max-over-ranks timing; not part of the reference's protocol)."""
         box = np.array([value], dtype=np.float64)

@@ -14,6 +14,13 @@
 //            pattern xGMI's point-to-point links favour).  Ranks meet at barriers in a POSIX shared-memory segment.
 // Host payloads (the reference's scalar / numpy all-reduces, collective.py:85-93) go through the same segment.
 // A communicator made WITHOUT a context is host-only (CPU tests of the launcher / id exchange / barrier logic).
+//
+// First contact (round 3): the transport is AGREED, never assumed.  Every rank publishes in the segment whether librccl
+// loaded, whether ncclCommInitRank succeeded and whether a first all-reduce gave the right sum within a time-out; all ranks
+// read the same table and fall back to P2P together if any entry is bad (hfmi_comm_describe reports what happened and why).
+// P2P itself is stream-ordered since round 3: arrival / completion counters in the host segment (mapped into every
+// rank's GPU with hipHostRegister) are written and polled by tiny kernels on the context's stream, so a collective costs
+// no host synchronisation; the polls give up after the communicator's time-out instead of hanging the GPU.
 #include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
@@ -28,6 +35,7 @@
 #include <algorithm>
 #include <atomic>
 #include <new>
+#include <vector>
 
 #include "hfmi_internal.h"
 
@@ -42,6 +50,7 @@ struct rccl_api {
   int (*GetUniqueId)(rccl_unique_id*);
   int (*CommInitRank)(rccl_comm_t*, int, rccl_unique_id, int);
   int (*CommDestroy)(rccl_comm_t);
+  int (*CommAbort)(rccl_comm_t);      // optional
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t);
   int (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t);
   const char* (*GetErrorString)(int);
@@ -54,7 +63,11 @@ bool rccl_load() {
   if (g_rccl.handle) return true;
   if (g_rccl_tried) return false;
   g_rccl_tried = true;
-  const char* cands[3] = {getenv("HFMI_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  // HFMI_RCCL_LIB names THE library: if it is set and does not load there is no RCCL (the ranks then agree on p2p)
+  const char* named = getenv("HFMI_RCCL_LIB");
+  const bool only_named = named && *named;
+  const char* cands[3] = {only_named ? named : nullptr, only_named ? nullptr : "librccl.so.1",
+                          only_named ? nullptr : "/opt/rocm/lib/librccl.so.1"};
   for (const char* c : cands) {
     if (!c || !*c) continue;
     void* h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
@@ -62,6 +75,7 @@ bool rccl_load() {
     g_rccl.GetUniqueId = (int (*)(rccl_unique_id*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_unique_id, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommAbort = (int (*)(rccl_comm_t))dlsym(h, "ncclCommAbort");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclBroadcast");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
@@ -89,7 +103,13 @@ struct comm_slot {
   int64_t bytes;
   char device_id[64];         // PCI bus id; equal strings = ranks sharing a GPU
   int32_t has_device;
-  int32_t rccl_ok;
+  int32_t rccl_ok;            // librccl loaded and the id carries an RCCL id
+  int32_t rccl_init;          // 0 = not tried, 1 = ncclCommInitRank succeeded, 2 = failed
+  int32_t rccl_first;         // 0 = not tried, 1 = the first all-reduce gave the right sum, 2 = wrong / error / time-out
+};
+struct alignas(64) comm_flag {
+  unsigned long long v;       // written by ONE rank's GPU (system-scope store), polled by the others' GPUs
+  char pad[56];
 };
 struct comm_shared {
   std::atomic<uint32_t> arrived;
@@ -97,6 +117,8 @@ struct comm_shared {
   std::atomic<uint32_t> abort_flag;
   uint32_t pad;
   comm_slot slot[COMM_MAX_RANKS];
+  comm_flag arrive[COMM_MAX_RANKS];   // sequence number of the last collective whose contribution rank p has staged
+  comm_flag done[COMM_MAX_RANKS];     // ... whose slice rank p has reduced and scattered
   double host_area[COMM_MAX_RANKS][HOST_AREA_DOUBLES];
 };
 struct id_layout {            // HFMI_UNIQUE_ID_BYTES = 256
@@ -130,7 +152,14 @@ struct hfmi_comm {
   // P2P staging
   double* stage;             // own buffer
   size_t stage_bytes;
+  bool stage_fine;           // allocated fine-grained (peer kernels' writes are visible without a kernel boundary)
   double* peer[COMM_MAX_RANKS];   // mapped staging buffers (peer[rank] == stage)
+  comm_shared* sh_dev;       // the segment as the GPU sees it (hipHostRegister), null = host-synchronised P2P
+  bool sh_registered;
+  unsigned long long seq;    // collectives issued on the stream-ordered path (identical on every rank)
+  int* dev_err;              // device word: a poll gave up (time-out)
+  bool distinct_devices;
+  char why[256];             // how the transport was chosen (hfmi_comm_describe)
   // device scratch for host payloads on the RCCL-only route
   double* scratch;
   size_t scratch_bytes;
@@ -185,9 +214,17 @@ extern "C" int hfmi_comm_unique_id(void* id_out) {
   return HFMI_OK;
 }
 
-// rank 0 makes the id and publishes it in `path` (write + rename: readers never see a partial file); the other
-// ranks wait for the file.  The reference's counterpart is mpi4py's own bootstrap; a host that has MPI can instead
-// broadcast the bytes of hfmi_comm_unique_id itself and call hfmi_comm_init_rank.
+// rank 0 makes the id and publishes it in `path` (O_EXCL temporary + rename: readers never see a partial file and nobody
+// else's file is followed or overwritten); the other ranks wait for the file and accept it only if it is a regular file of
+// this user with mode 0600 whose token they have not joined before (a stale file of an earlier communicator of the same
+// launch is skipped, not joined).  Rank 0 removes the file as soon as every rank has it (first barrier of init) and no rank
+// returns before that (last barrier), so two communicators made back to back cannot meet in the wrong segment.
+// The reference's counterpart is mpi4py's own bootstrap; a host that has MPI can instead broadcast the bytes of
+// hfmi_comm_unique_id itself and call hfmi_comm_init_rank.
+static unsigned char g_last_token[32];
+static bool g_have_last_token = false;
+static int comm_init_impl(hfmi_ctx* ctx, const void* id_bytes, int nranks, int rank, const char* unlink_path, hfmi_comm** out);
+
 extern "C" int hfmi_comm_init_from_file(hfmi_ctx* ctx, const char* path, int nranks, int rank, hfmi_comm** out) {
   if (!path || !out) HFMI_FAIL(HFMI_ERR_INVALID, "comm_init_from_file: null argument");
   unsigned char id[HFMI_UNIQUE_ID_BYTES];
@@ -195,28 +232,37 @@ extern "C" int hfmi_comm_init_from_file(hfmi_ctx* ctx, const char* path, int nra
     HFMI_TRY(hfmi_comm_unique_id(id));
     char tmp[1024];
     snprintf(tmp, sizeof(tmp), "%s.tmp.%d", path, (int)getpid());
-    FILE* f = fopen(tmp, "wb");
-    if (!f) HFMI_FAIL(HFMI_ERR_COMM, "comm_init_from_file: cannot create %s: %s", tmp, strerror(errno));
-    const size_t w = fwrite(id, 1, sizeof(id), f);
-    fclose(f);
-    if (w != sizeof(id) || rename(tmp, path) != 0) HFMI_FAIL(HFMI_ERR_COMM, "comm_init_from_file: cannot publish %s", path);
+    (void)unlink(tmp);
+    const int fd = open(tmp, O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY | O_CLOEXEC, 0600);
+    if (fd < 0) HFMI_FAIL(HFMI_ERR_COMM, "comm_init_from_file: cannot create %s: %s", tmp, strerror(errno));
+    const ssize_t w = write(fd, id, sizeof(id));
+    close(fd);
+    if (w != (ssize_t)sizeof(id) || rename(tmp, path) != 0) {
+      (void)unlink(tmp);
+      HFMI_FAIL(HFMI_ERR_COMM, "comm_init_from_file: cannot publish %s: %s", path, strerror(errno));
+    }
   } else {
     const double t0 = now_s(), limit = comm_timeout_s();
     for (;;) {
-      FILE* f = fopen(path, "rb");
-      if (f) {
-        const size_t r = fread(id, 1, sizeof(id), f);
-        fclose(f);
-        if (r == sizeof(id)) break;
+      const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+      if (fd >= 0) {
+        struct stat st;
+        bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 077) == 0 &&
+                  st.st_size == (off_t)sizeof(id);
+        if (ok) ok = read(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+        close(fd);
+        if (ok) {
+          id_layout probe;
+          memcpy(&probe, id, sizeof(probe));
+          if (!(g_have_last_token && memcmp(probe.token, g_last_token, sizeof(g_last_token)) == 0)) break;
+        }
       }
-      if (now_s() - t0 > limit) HFMI_FAIL(HFMI_ERR_COMM, "rank %d: no communicator id in %s after %.0f s", rank, path, limit);
+      if (now_s() - t0 > limit) HFMI_FAIL(HFMI_ERR_COMM, "rank %d: no (fresh, own, mode 0600) communicator id in %s after %.0f s", rank, path, limit);
       timespec ts = {0, 2000000};
       nanosleep(&ts, nullptr);
     }
   }
-  HFMI_TRY(hfmi_comm_init_rank(ctx, id, nranks, rank, out));
-  if (rank == 0) (void)unlink(path);      // every rank has read it: init_rank ends with a barrier
-  return HFMI_OK;
+  return comm_init_impl(ctx, id, nranks, rank, rank == 0 ? path : nullptr, out);
 }
 
 // ------------------------------------------------------------------ P2P staging buffers
@@ -225,6 +271,27 @@ static int p2p_close_peers(hfmi_comm* c) {
     if (p != c->rank && c->peer[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
     c->peer[p] = nullptr;
   }
+  return HFMI_OK;
+}
+// the staging buffer: fine-grained device memory when the runtime grants it AND exports it (peer GPUs' kernel writes are then
+// visible to this GPU without relying on a kernel boundary flushing a remote L2), else ordinary device memory
+static int p2p_alloc_stage(hfmi_comm* c, size_t want) {
+  static const bool coarse = getenv("HFMI_P2P_COARSE") != nullptr;
+  c->stage_fine = false;
+  if (!coarse) {
+    void* q = nullptr;
+    if (hipExtMallocWithFlags(&q, want, hipDeviceMallocFinegrained) == hipSuccess) {
+      hipIpcMemHandle_t h;
+      if (hipIpcGetMemHandle(&h, q) == hipSuccess) {
+        c->stage = (double*)q;
+        c->stage_fine = true;
+        return HFMI_OK;
+      }
+      (void)hipFree(q);
+    }
+    (void)hipGetLastError();
+  }
+  HIP_TRY(hipMalloc((void**)&c->stage, want));
   return HFMI_OK;
 }
 // Collective: every rank calls it with the same `bytes`.
@@ -238,7 +305,7 @@ static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
   c->stage = nullptr;
   c->stage_bytes = 0;
   const size_t want = round_up((int64_t)(bytes + bytes / 8), 1 << 20);
-  HIP_TRY(hipMalloc((void**)&c->stage, want));
+  HFMI_TRY(p2p_alloc_stage(c, want));
   c->stage_bytes = want;
   comm_slot& me = c->sh->slot[c->rank];
   HIP_TRY(hipIpcGetMemHandle(&me.handle, c->stage));
@@ -264,7 +331,9 @@ struct p2p_ptrs {
 };
 // rank r owns the d2 elements [lo, hi): sum over ranks in rank order (every rank ends up with identical bits),
 // scale, and store into the same slice of every rank's buffer.
-__global__ void __launch_bounds__(256) k_p2p_reduce(p2p_ptrs bufs, int nranks, int64_t lo, int64_t hi, double scale, int op) {
+__global__ void __launch_bounds__(256) k_p2p_reduce(p2p_ptrs bufs, int nranks, int64_t lo, int64_t hi, double scale, int op,
+                                                    const int* __restrict__ dev_err) {
+  if (dev_err && *dev_err) return;      // a poll gave up: the peers' data may be missing, leave the buffers alone
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
@@ -282,31 +351,73 @@ __global__ void __launch_bounds__(256) k_p2p_reduce(p2p_ptrs bufs, int nranks, i
     for (int p = 0; p < nranks; ++p) reinterpret_cast<d2*>(bufs.p[p])[i] = acc;
   }
 }
+// stream-ordered hand-shake through the host segment: one thread publishes this rank's sequence number ...
+__global__ void k_p2p_signal(comm_flag* flag, unsigned long long seq) {
+  __threadfence_system();
+  __hip_atomic_store(&flag->v, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and one wave waits until every rank has published at least `seq` (lane p polls rank p).  wall_clock64 runs at a
+// constant 100 MHz: the poll gives up after `ticks` and raises dev_err instead of occupying the GPU for ever.
+__global__ void k_p2p_wait(const comm_flag* flags, int nranks, unsigned long long seq, long long ticks, int* dev_err) {
+  const int p = threadIdx.x;
+  if (p >= nranks) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(&flags[p].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    if (wall_clock64() - t0 > ticks || *(volatile int*)dev_err) {
+      atomicExch(dev_err, 1);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
 
-static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op) {
+static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, hipStream_t stream) {
   hfmi_ctx* ctx = c->ctx;
   const int64_t padded = round_up(count, 2);
   const size_t bytes = (size_t)padded * sizeof(double);
   HFMI_TRY(p2p_ensure_stage(c, bytes));
-  if (padded != count) HIP_TRY(hipMemsetAsync(c->stage + count, 0, sizeof(double), ctx->stream));
-  HIP_TRY(hipMemcpyAsync(c->stage, data, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HFMI_TRY(shm_barrier(c));                       // every rank's contribution is in its staging buffer
+  if (padded != count) HIP_TRY(hipMemsetAsync(c->stage + count, 0, sizeof(double), stream));
+  HIP_TRY(hipMemcpyAsync(c->stage, data, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
   const int64_t n2 = padded / 2;
   const int64_t lo = n2 * c->rank / c->nranks, hi = n2 * (c->rank + 1) / c->nranks;
+  p2p_ptrs bufs;
+  for (int p = 0; p < COMM_MAX_RANKS; ++p) bufs.p[p] = p < c->nranks ? c->peer[p] : nullptr;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((hi - lo + 255) / 256, (int64_t)ctx->num_cus * 8));
+  const double scale = (op == HFMI_REDUCE_AVG) ? 1.0 / c->nranks : 1.0;
+  if (c->sh_dev) {
+    // stream-ordered: no host synchronisation, no host barrier
+    const unsigned long long seq = ++c->seq;
+    const long long ticks = (long long)(comm_timeout_s() * 1e8);
+    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->arrive[c->rank], seq);
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, stream, c->sh_dev->arrive, c->nranks, seq, ticks, c->dev_err);
+    if (hi > lo) hipLaunchKernelGGL(k_p2p_reduce, dim3(blocks), dim3(256), 0, stream, bufs, c->nranks, lo, hi, scale, op, c->dev_err);
+    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->done[c->rank], seq);
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, stream, c->sh_dev->done, c->nranks, seq, ticks, c->dev_err);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(data, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    // the next collective's copy-in is ordered behind this copy-out on the stream, and no peer touches this rank's buffer
+    // before this rank has published the next sequence number
+    return HFMI_OK;
+  }
+  HIP_TRY(hipStreamSynchronize(stream));
+  HFMI_TRY(shm_barrier(c));                       // every rank's contribution is in its staging buffer
   if (hi > lo) {
-    p2p_ptrs bufs;
-    for (int p = 0; p < COMM_MAX_RANKS; ++p) bufs.p[p] = p < c->nranks ? c->peer[p] : nullptr;
-    const int blocks = (int)std::min<int64_t>((hi - lo + 255) / 256, (int64_t)ctx->num_cus * 8);
-    const double scale = (op == HFMI_REDUCE_AVG) ? 1.0 / c->nranks : 1.0;
-    hipLaunchKernelGGL(k_p2p_reduce, dim3(blocks), dim3(256), 0, ctx->stream, bufs, c->nranks, lo, hi, scale, op);
+    hipLaunchKernelGGL(k_p2p_reduce, dim3(blocks), dim3(256), 0, stream, bufs, c->nranks, lo, hi, scale, op, (const int*)nullptr);
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipStreamSynchronize(stream));
   HFMI_TRY(shm_barrier(c));                       // every slice of every buffer is final
-  HIP_TRY(hipMemcpyAsync(data, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(data, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
   // the staging buffer may be overwritten by the next collective only after this copy: the next collective
   // starts with a stream synchronise of its own copy-in, which is ordered behind this copy on the same stream
+  return HFMI_OK;
+}
+// a poll that gave up leaves a flag on the device; the entry points that synchronise anyway look at it
+static int p2p_check_err(hfmi_comm* c) {
+  if (!c->dev_err) return HFMI_OK;
+  int e = 0;
+  HIP_TRY(hipMemcpy(&e, c->dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) HFMI_FAIL(HFMI_ERR_COMM, "rank %d: a peer rank did not reach a collective within %.0f s (stream-ordered p2p transport)", c->rank, comm_timeout_s());
   return HFMI_OK;
 }
 
@@ -325,8 +436,126 @@ static int p2p_bcast_dev(hfmi_comm* c, void* data, size_t bytes, int root) {
   return shm_barrier(c);                          // the root may reuse its staging buffer
 }
 
+// ------------------------------------------------------------------ transport decision
+// One pure function of the table every rank reads from the segment, so that all ranks decide alike.
+// force: 0 = auto, 2 = p2p requested.  reason (>= 160 bytes) says why in words.
+static int decide_transport(int nranks, const comm_slot* slot, int force, char* reason) {
+  bool all_dev = true, any_dev = false, all_rccl = true, distinct = true;
+  int first_no_rccl = -1;
+  for (int p = 0; p < nranks; ++p) {
+    all_dev = all_dev && slot[p].has_device;
+    any_dev = any_dev || slot[p].has_device;
+    if (!slot[p].rccl_ok) {
+      all_rccl = false;
+      if (first_no_rccl < 0) first_no_rccl = p;
+    }
+    for (int q = 0; q < p; ++q)
+      if (slot[p].has_device && slot[q].has_device && strcmp(slot[p].device_id, slot[q].device_id) == 0) distinct = false;
+  }
+  if (!all_dev) {
+    if (any_dev) {
+      snprintf(reason, 160, "some ranks passed a device context and some did not");
+      return -1;
+    }
+    snprintf(reason, 160, "no rank has a device context: host payloads only");
+    return TRANSPORT_HOST;
+  }
+  if (force == 2) {
+    snprintf(reason, 160, "p2p requested (HFMI_COMM_TRANSPORT=p2p)");
+    return TRANSPORT_P2P;
+  }
+  if (!distinct) {
+    snprintf(reason, 160, "ranks share a GPU (RCCL refuses duplicate devices)");
+    return TRANSPORT_P2P;
+  }
+  if (!all_rccl) {
+    snprintf(reason, 160, "librccl not usable on rank %d (HFMI_RCCL_LIB / librccl.so.1 did not load, or the id carries no RCCL id)", first_no_rccl);
+    return TRANSPORT_P2P;
+  }
+  snprintf(reason, 160, "every rank has its own GPU and librccl");
+  return TRANSPORT_RCCL;
+}
+// test hook (CPU suite): the decision for a hand-made table.  has_device / rccl_ok: nranks ints; device_ids: nranks strings.
+extern "C" int hfmi_comm_decide_transport(int nranks, const int* has_device, const int* rccl_ok, const char* const* device_ids,
+                                          int force_p2p, int* transport, char* reason, int reason_len) {
+  if (nranks < 1 || nranks > COMM_MAX_RANKS || !has_device || !rccl_ok || !device_ids || !transport)
+    HFMI_FAIL(HFMI_ERR_INVALID, "comm_decide_transport: bad argument");
+  comm_slot slot[COMM_MAX_RANKS];
+  memset(slot, 0, sizeof(slot));
+  for (int p = 0; p < nranks; ++p) {
+    slot[p].has_device = has_device[p];
+    slot[p].rccl_ok = rccl_ok[p];
+    snprintf(slot[p].device_id, sizeof(slot[p].device_id), "%s", device_ids[p] ? device_ids[p] : "");
+  }
+  char why[160];
+  *transport = decide_transport(nranks, slot, force_p2p ? 2 : 0, why);
+  if (reason && reason_len > 0) snprintf(reason, (size_t)reason_len, "%s", why);
+  return HFMI_OK;
+}
+
 // ------------------------------------------------------------------ init / destroy
+static void comm_free(hfmi_comm* c) {
+  if (!c) return;
+  if (c->sh_registered) (void)hipHostUnregister(c->sh);
+  if (c->dev_err) (void)hipFree(c->dev_err);
+  if (c->sh) munmap(c->sh, sizeof(comm_shared));
+  delete c;
+}
+// stream-ordered P2P needs the segment mapped into the GPU's address space and a device error word
+static int p2p_enable_stream_order(hfmi_comm* c) {
+  static const char* mode = getenv("HFMI_P2P_SYNC");      // "host" | "stream" | unset = stream when the GPUs are distinct
+  const bool want = mode ? strcmp(mode, "stream") == 0 : c->distinct_devices;
+  if (!want || c->nranks == 1) return HFMI_OK;
+  if (hipHostRegister(c->sh, sizeof(comm_shared), hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return HFMI_OK;                                         // stays host-synchronised
+  }
+  c->sh_registered = true;
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, c->sh, 0) != hipSuccess || hipMalloc((void**)&c->dev_err, sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    return HFMI_OK;
+  }
+  HIP_TRY(hipMemset(c->dev_err, 0, sizeof(int)));
+  c->sh_dev = (comm_shared*)dp;
+  return HFMI_OK;
+}
+// the first all-reduce on a fresh RCCL communicator, with a time-out: 1 = right sum, 2 = anything else
+static int rccl_first_contact(hfmi_comm* c) {
+  const int n = 1024;
+  double* buf = nullptr;
+  if (hipMalloc((void**)&buf, n * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    return 2;
+  }
+  std::vector<double> h(n, (double)(c->rank + 1));
+  int verdict = 2;
+  hipStream_t st = c->ctx->stream;
+  if (hipMemcpyAsync(buf, h.data(), n * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+      hipStreamSynchronize(st) == hipSuccess &&
+      g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_DOUBLE, RCCL_SUM, c->nccl, st) == 0) {
+    const double t0 = now_s(), limit = std::min(comm_timeout_s(), 120.0);
+    hipError_t q;
+    while ((q = hipStreamQuery(st)) == hipErrorNotReady && now_s() - t0 < limit) {
+      timespec ts = {0, 200000};
+      nanosleep(&ts, nullptr);
+    }
+    if (q == hipSuccess && hipMemcpy(h.data(), buf, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+      const double want = 0.5 * c->nranks * (c->nranks + 1.0);
+      verdict = 1;
+      for (int i = 0; i < n; ++i)
+        if (h[i] != want) verdict = 2;
+    }
+  }
+  (void)hipGetLastError();
+  if (verdict == 1) (void)hipFree(buf);   // after a time-out the buffer may still be in use by a stuck kernel: leak it
+  return verdict;
+}
+
 extern "C" int hfmi_comm_init_rank(hfmi_ctx* ctx, const void* id_bytes, int nranks, int rank, hfmi_comm** out) {
+  return comm_init_impl(ctx, id_bytes, nranks, rank, nullptr, out);
+}
+static int comm_init_impl(hfmi_ctx* ctx, const void* id_bytes, int nranks, int rank, const char* unlink_path, hfmi_comm** out) {
   if (!id_bytes || !out) HFMI_FAIL(HFMI_ERR_INVALID, "comm_init_rank: null argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) HFMI_FAIL(HFMI_ERR_INVALID, "comm_init_rank: rank %d of %d", rank, nranks);
   id_layout id;
@@ -346,7 +575,12 @@ extern "C" int hfmi_comm_init_rank(hfmi_ctx* ctx, const void* id_bytes, int nran
   c->rank = rank;
   c->nranks = nranks;
   c->transport = TRANSPORT_HOST;
-  if (ctx) HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx && hipSetDevice(ctx->device) != hipSuccess) {
+    comm_free(c);
+    HFMI_FAIL(HFMI_ERR_HIP, "comm_init_rank: hipSetDevice(%d) failed", ctx->device);
+  }
+  memcpy(g_last_token, id.token, sizeof(g_last_token));
+  g_have_last_token = true;
 
   if (!force_rccl) {
     // node-local control segment named by the id's token; a fresh segment is zero-filled = initial barrier state
@@ -354,18 +588,18 @@ extern "C" int hfmi_comm_init_rank(hfmi_ctx* ctx, const void* id_bytes, int nran
     for (int i = 0; i < 16; ++i) snprintf(name + 6 + 2 * i, 3, "%02x", id.token[i]);
     const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
     if (fd < 0) {
-      delete c;
+      comm_free(c);
       HFMI_FAIL(HFMI_ERR_COMM, "comm_init_rank: shm_open(%s) failed: %s", name, strerror(errno));
     }
     if (ftruncate(fd, sizeof(comm_shared)) != 0) {
       close(fd);
-      delete c;
+      comm_free(c);
       HFMI_FAIL(HFMI_ERR_COMM, "comm_init_rank: ftruncate failed: %s", strerror(errno));
     }
     void* m = mmap(nullptr, sizeof(comm_shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) {
-      delete c;
+      comm_free(c);
       HFMI_FAIL(HFMI_ERR_COMM, "comm_init_rank: mmap failed: %s", strerror(errno));
     }
     c->sh = (comm_shared*)m;
@@ -380,59 +614,113 @@ extern "C" int hfmi_comm_init_rank(hfmi_ctx* ctx, const void* id_bytes, int nran
       me.rccl_ok = (id.rccl_valid && rccl_load()) ? 1 : 0;
     }
     int s = shm_barrier(c);
-    if (s == HFMI_OK && rank == 0) (void)shm_unlink(name);    // every rank has it mapped: nothing is left in /dev/shm
+    // every rank has the segment mapped and (file bootstrap) has read the id file: nothing is left behind in /dev/shm or in
+    // the temp directory, and a later communicator cannot pick this one's file up (its ranks leave only after the last barrier)
+    if (rank == 0) {
+      (void)shm_unlink(name);
+      if (unlink_path) (void)unlink(unlink_path);
+    }
     if (s != HFMI_OK) {
-      if (rank == 0) (void)shm_unlink(name);
-      munmap(c->sh, sizeof(comm_shared));
-      delete c;
+      comm_free(c);
       return s;
     }
     // the same decision on every rank, from the same table
-    bool all_dev = true, all_rccl = true, distinct = true;
-    for (int p = 0; p < nranks; ++p) {
-      all_dev = all_dev && c->sh->slot[p].has_device;
-      all_rccl = all_rccl && c->sh->slot[p].rccl_ok;
+    c->distinct_devices = true;
+    for (int p = 0; p < nranks; ++p)
       for (int q = 0; q < p; ++q)
-        if (strcmp(c->sh->slot[p].device_id, c->sh->slot[q].device_id) == 0) distinct = false;
+        if (strcmp(c->sh->slot[p].device_id, c->sh->slot[q].device_id) == 0) c->distinct_devices = false;
+    const int t = decide_transport(nranks, c->sh->slot, force_p2p ? 2 : 0, c->why);
+    if (t < 0) {
+      char msg[200];
+      snprintf(msg, sizeof(msg), "%s", c->why);
+      comm_free(c);
+      HFMI_FAIL(HFMI_ERR_INVALID, "comm_init_rank: %s", msg);
     }
-    if (!all_dev) {
-      bool any = false;
-      for (int p = 0; p < nranks; ++p) any = any || c->sh->slot[p].has_device;
-      if (any) {
-        munmap(c->sh, sizeof(comm_shared));
-        delete c;
-        HFMI_FAIL(HFMI_ERR_INVALID, "comm_init_rank: some ranks passed a context and some did not");
-      }
-      c->transport = TRANSPORT_HOST;
-    } else if (force_p2p || !distinct || !all_rccl) {
-      c->transport = TRANSPORT_P2P;
-    } else {
-      c->transport = TRANSPORT_RCCL;
-    }
+    c->transport = t;
   } else {
     if (!ctx) {
-      delete c;
+      comm_free(c);
       HFMI_FAIL(HFMI_ERR_INVALID, "HFMI_COMM_TRANSPORT=rccl needs a device context");
     }
     c->transport = TRANSPORT_RCCL;
+    snprintf(c->why, sizeof(c->why), "rccl requested (HFMI_COMM_TRANSPORT=rccl): no node segment, no fallback");
+    if (unlink_path) (void)unlink(unlink_path);   // peers that have not read it yet would time out: rccl-only launches should ship the id themselves
   }
 
   if (c->transport == TRANSPORT_RCCL) {
     if (!id.rccl_valid || !rccl_load()) {
-      if (c->sh) munmap(c->sh, sizeof(comm_shared));
-      delete c;
+      comm_free(c);
       HFMI_FAIL(HFMI_ERR_COMM, "comm_init_rank: librccl is not available (HFMI_RCCL_LIB / librccl.so.1)");
     }
-    const int r = g_rccl.CommInitRank(&c->nccl, nranks, id.rccl, rank);
-    if (r != 0) {
-      if (c->sh) munmap(c->sh, sizeof(comm_shared));
-      delete c;
-      HFMI_FAIL(HFMI_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+    static const char* inject = getenv("HFMI_COMM_INJECT");     // test hook: "init" / "first" make THIS path fail on every rank
+    int r = (inject && !strcmp(inject, "init")) ? -1 : g_rccl.CommInitRank(&c->nccl, nranks, id.rccl, rank);
+    if (!c->sh) {
+      if (r != 0) {
+        comm_free(c);
+        HFMI_FAIL(HFMI_ERR_COMM, "ncclCommInitRank failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "injected failure");
+      }
+    } else {
+      // agree on the outcome: one rank's failure sends EVERY rank to the p2p transport
+      comm_slot& me = c->sh->slot[rank];
+      me.rccl_init = (r == 0) ? 1 : 2;
+      int s = shm_barrier(c);
+      bool all_ok = s == HFMI_OK;
+      int bad = -1;
+      for (int p = 0; p < nranks && s == HFMI_OK; ++p)
+        if (c->sh->slot[p].rccl_init != 1) {
+          all_ok = false;
+          if (bad < 0) bad = p;
+        }
+      const char* stage = "ncclCommInitRank";
+      if (all_ok) {
+        me.rccl_first = (inject && !strcmp(inject, "first")) ? 2 : rccl_first_contact(c);
+        s = shm_barrier(c);
+        all_ok = s == HFMI_OK;
+        for (int p = 0; p < nranks && s == HFMI_OK; ++p)
+          if (c->sh->slot[p].rccl_first != 1) {
+            all_ok = false;
+            if (bad < 0) bad = p;
+          }
+        stage = "the first ncclAllReduce";
+      }
+      if (s != HFMI_OK) {
+        comm_free(c);
+        return s;
+      }
+      if (!all_ok) {
+        if (c->nccl) {
+          // a communicator that failed its first collective may hang in destroy: abort it if the library can, else leak it
+          if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->nccl);
+          else if (me.rccl_first != 2) (void)g_rccl.CommDestroy(c->nccl);
+          c->nccl = nullptr;
+        }
+        c->transport = TRANSPORT_P2P;
+        snprintf(c->why, sizeof(c->why), "fell back from rccl: %s failed on rank %d; all ranks agreed on p2p", stage, bad);
+      }
     }
   }
-  *out = c;
+  if (c->transport == TRANSPORT_P2P) {
+    const int s = p2p_enable_stream_order(c);
+    if (s != HFMI_OK) {
+      comm_free(c);
+      return s;
+    }
+    // every rank must take the same path: stream-ordered only if all of them could map the segment
+    c->sh->slot[rank].rccl_first = c->sh_dev ? 11 : 12;
+    int s2 = shm_barrier(c);
+    if (s2 != HFMI_OK) {
+      comm_free(c);
+      return s2;
+    }
+    for (int p = 0; p < nranks; ++p)
+      if (c->sh->slot[p].rccl_first != 11) c->sh_dev = nullptr;
+  }
   const int s = shm_barrier(c);
-  if (s != HFMI_OK) return s;
+  if (s != HFMI_OK) {
+    comm_free(c);
+    return s;
+  }
+  *out = c;
   return HFMI_OK;
 }
 
@@ -451,11 +739,27 @@ extern "C" int hfmi_comm_destroy(hfmi_comm* c) {
   }
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   if (c->scratch) (void)hipFree(c->scratch);
-  if (c->sh) munmap(c->sh, sizeof(comm_shared));
-  delete c;
+  comm_free(c);
   return HFMI_OK;
 }
 
+// what was chosen and why, as one line of JSON (bench.py puts it into its record): transport, library, the PCI bus id of
+// every rank, whether the p2p path is stream-ordered
+extern "C" int hfmi_comm_describe(const hfmi_comm* c, char* buf, int len) {
+  if (!c || !buf || len < 2) HFMI_FAIL(HFMI_ERR_INVALID, "comm_describe: bad argument");
+  static const char* names[3] = {"host", "rccl", "p2p"};
+  int o = snprintf(buf, (size_t)len, "{\"transport\": \"%s\", \"nranks\": %d, \"rank\": %d, \"why\": \"%s\", \"rccl_library\": \"%s\", "
+                   "\"p2p_sync\": \"%s\", \"p2p_stage\": \"%s\", \"devices\": [",
+                   names[c->transport], c->nranks, c->rank, c->why, g_rccl.handle ? g_rccl.path : "",
+                   c->transport != TRANSPORT_P2P ? "" : (c->sh_dev ? "stream" : "host"),
+                   c->transport != TRANSPORT_P2P || !c->stage ? "" : (c->stage_fine ? "fine-grained" : "coarse-grained"));
+  for (int p = 0; p < c->nranks && o > 0 && o < len; ++p)
+    o += snprintf(buf + o, (size_t)(len - o), "%s\"%s\"", p ? ", " : "", c->sh ? c->sh->slot[p].device_id : "");
+  if (o > 0 && o < len) snprintf(buf + o, (size_t)(len - o), "]}");
+  return HFMI_OK;
+}
+
+int comm_transport(const hfmi_comm* c) { return c ? c->transport : 0; }
 extern "C" int hfmi_comm_info(const hfmi_comm* c, int* nranks, int* rank, int* transport) {
   if (!c) HFMI_FAIL(HFMI_ERR_INVALID, "null communicator");
   if (nranks) *nranks = c->nranks;
@@ -466,17 +770,23 @@ extern "C" int hfmi_comm_info(const hfmi_comm* c, int* nranks, int* rank, int* t
 
 // ------------------------------------------------------------------ collectives on device memory
 int comm_allreduce_device(hfmi_comm* c, double* data, int64_t count, int op) {
+  return comm_allreduce_device_on(c, data, count, op, nullptr);
+}
+// the same on another stream of the context (the row panels of an operator application are reduced on the auxiliary stream
+// while the next panel is being computed, hfmi_api.hip)
+int comm_allreduce_device_on(hfmi_comm* c, double* data, int64_t count, int op, void* hip_stream) {
   if (!c || !data) HFMI_FAIL(HFMI_ERR_INVALID, "allreduce: null argument");
   if (op != HFMI_REDUCE_SUM && op != HFMI_REDUCE_AVG && op != HFMI_REDUCE_MAX) HFMI_FAIL(HFMI_ERR_INVALID, "allreduce: unknown operation %d", op);
   if (!c->ctx) HFMI_FAIL(HFMI_ERR_INVALID, "allreduce: a host-only communicator cannot reduce device memory");
   HIP_TRY(hipSetDevice(c->ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->ctx->stream;
   if (c->transport == TRANSPORT_RCCL) {
     const int rop = op == HFMI_REDUCE_SUM ? RCCL_SUM : op == HFMI_REDUCE_AVG ? RCCL_AVG : RCCL_MAX;
-    RCCL_TRY(g_rccl.AllReduce(data, data, (size_t)count, RCCL_DOUBLE, rop, c->nccl, c->ctx->stream));
+    RCCL_TRY(g_rccl.AllReduce(data, data, (size_t)count, RCCL_DOUBLE, rop, c->nccl, st));
     return HFMI_OK;
   }
   if (c->nranks == 1) return HFMI_OK;
-  return p2p_allreduce_dev(c, data, count, op);
+  return p2p_allreduce_dev(c, data, count, op, st);
 }
 static int comm_bcast_device(hfmi_comm* c, void* data, size_t bytes, int root) {
   if (!c->ctx) HFMI_FAIL(HFMI_ERR_INVALID, "bcast: a host-only communicator cannot broadcast device memory");
@@ -579,6 +889,7 @@ extern "C" int hfmi_comm_barrier(hfmi_comm* c) {
   if (c->ctx) {
     HIP_TRY(hipSetDevice(c->ctx->device));
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    HFMI_TRY(p2p_check_err(c));
   }
   if (c->sh) return shm_barrier(c);
   double one = 1.0;

@@ -145,6 +145,8 @@ struct hfmi_op {
 };
 // in-place all-reduce of `count` doubles of device memory on the communicator's context stream (hfmi_comm.hip)
 int comm_allreduce_device(hfmi_comm* c, double* data, int64_t count, int op);
+int comm_allreduce_device_on(hfmi_comm* c, double* data, int64_t count, int op, void* hip_stream /* null = the context's */);
+int comm_transport(const hfmi_comm* c);   // 0 host, 1 rccl, 2 p2p
 
 // ------------------------------------------------------------------ kernel launchers (hfmi_gemm.hip)
 // C (m x k) = scale * A^T B (+ beta * C); A: N x m, B: N x k column-major blocks.

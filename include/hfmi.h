@@ -178,7 +178,11 @@ int hfmi_op_destroy(hfmi_op* op);
  * GPU), 2 = direct peer access through HIP IPC staging buffers (ranks sharing a GPU, or HFMI_COMM_TRANSPORT=p2p),
  * 0 = host-only (ctx NULL on every rank: host payloads and barriers only).  Ranks of one communicator live on one
  * node unless HFMI_COMM_TRANSPORT=rccl.  A peer that never arrives fails the call after HFMI_COMM_TIMEOUT_S
- * (300 s) with HFMI_ERR_COMM instead of hanging. */
+ * (300 s) with HFMI_ERR_COMM instead of hanging.  The transport is agreed among the ranks: if librccl does not load,
+ * ncclCommInitRank fails or the first all-reduce does not give the right sum on ANY rank, ALL ranks use the p2p
+ * transport (which works across GPUs through HIP IPC and is stream-ordered: counters in the node segment, written and
+ * polled from the GPUs; HFMI_P2P_SYNC=host|stream overrides the choice).  The id file of hfmi_comm_init_from_file is
+ * created 0600 with O_EXCL, read only if it is this user's, and removed before any rank returns. */
 #define HFMI_UNIQUE_ID_BYTES 256
 #define HFMI_REDUCE_SUM 0
 #define HFMI_REDUCE_AVG 1
@@ -187,6 +191,13 @@ int hfmi_comm_unique_id(void* id_out);
 int hfmi_comm_init_rank(hfmi_ctx* ctx_or_null, const void* id, int nranks, int rank, hfmi_comm** out);
 int hfmi_comm_init_from_file(hfmi_ctx* ctx_or_null, const char* path, int nranks, int rank, hfmi_comm** out);
 int hfmi_comm_info(const hfmi_comm* comm, int* nranks, int* rank, int* transport);
+/* one line of JSON: the transport, WHY it was chosen (e.g. "fell back from rccl: the first ncclAllReduce failed on rank 3;
+ * all ranks agreed on p2p"), the RCCL library in use, every rank's PCI bus id, how the p2p path synchronises */
+int hfmi_comm_describe(const hfmi_comm* comm, char* buf, int len);
+/* the transport decision as a pure function of the table the ranks publish (test hook for the CPU suite): has_device[p],
+ * rccl_ok[p], device_ids[p] for p < nranks; *transport = 0 host / 1 rccl / 2 p2p, or -1 for an inconsistent table */
+int hfmi_comm_decide_transport(int nranks, const int* has_device, const int* rccl_ok, const char* const* device_ids,
+                               int force_p2p, int* transport, char* reason, int reason_len);
 int hfmi_comm_barrier(hfmi_comm* comm);               /* drains the context's stream, then meets the other ranks */
 int hfmi_allreduce(hfmi_comm* comm, hfmi_block* Y, int reduce_op);           /* in place, stream-ordered */
 int hfmi_bcast(hfmi_comm* comm, hfmi_block* Y, int root);

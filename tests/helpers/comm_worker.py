@@ -16,6 +16,16 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if mode == "missing_peer" and rank == world - 1:
         return 0                                     # this rank never joins: the others must time out, not hang
+    if mode == "back_to_back":
+        # communicators made one after the other through the SAME id file must never meet in a stale segment
+        sums = []
+        for it in range(6):
+            c = NativeCollective.from_env(host_only=True)
+            sums.append(c.allReduce(float(rank + 1 + it), "sum"))
+            if it % 2 == 0:
+                c.close()               # some are closed at once, some stay open while the next one is made
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), sums=np.array(sums), why=c.describe()["why"])
+        return 0
     coll = NativeCollective.from_env(host_only=True)
     res = {"size": coll.size(), "rank": coll.rank(), "transport": coll.transport}
     if mode == "missing_peer":

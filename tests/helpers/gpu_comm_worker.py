@@ -19,7 +19,7 @@ def main():
     from hippyflow_amd.randomized import _ParRandom
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     coll = hf.NativeCollective.from_env()
-    res = {"size": coll.size(), "rank": coll.rank(), "transport": coll.transport}
+    res = {"size": coll.size(), "rank": coll.rank(), "transport": coll.transport, "p2p_sync": coll.describe()["p2p_sync"]}
     ctx = hf.Context.default()
 
     N, k = 5003, 7

@@ -43,15 +43,44 @@ def test_one_rank_rccl_communicator_is_bit_transparent():
     coll.close()
 
 
+def test_rccl_first_contact_failure_falls_back_to_p2p_by_agreement():
+    """First-contact hardening: a failing ncclCommInitRank / a first all-reduce that does not deliver sends the ranks to
+    the p2p transport TOGETHER, and the communicator says why (injected failures: a one-GPU box cannot produce a real one)."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import json, hippyflow_amd as hf, numpy as np\n"
+            "c = hf.NativeCollective.from_unique_id(hf.NativeCollective.unique_id(), 1, 0)\n"
+            "X = hf.MultiVector(1000, 3); hf.parRandom.normal(1.0, X); ref = X.to_dense(); c.allReduce(X, 'avg')\n"
+            "assert np.array_equal(ref, X.to_dense())\n"
+            "print(json.dumps(c.describe()))\n" % ROOT)
+    for inject, stage in (("init", "ncclCommInitRank"), ("first", "the first ncclAllReduce")):
+        env = dict(os.environ, HFMI_COMM_INJECT=inject, HFMI_COMM_TIMEOUT_S="60")
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])     # (RCCL prints its banner to stdout too)
+        assert d["transport"] == "p2p" and "fell back from rccl" in d["why"] and stage in d["why"]
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HFMI_RCCL_LIB="/nonexistent/librccl.so"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])     # (RCCL prints its banner to stdout too)
+    assert d["transport"] == "p2p" and "librccl not usable" in d["why"] and len(d["devices"]) == 1 and d["devices"][0]
+
+
+@pytest.mark.parametrize("sync", ["host", "stream"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_ranks_sharing_the_gpu_p2p_transport(tmp_path, world):
+def test_ranks_sharing_the_gpu_p2p_transport(tmp_path, world, sync):
+    """sync = "stream": the stream-ordered p2p path (arrival / completion counters in the node segment, written and polled
+    by kernels: no host synchronisation inside a collective) -- what an 8-GPU run falls back to if RCCL misbehaves."""
     from hippyflow_amd.launch import spawn_ranks
-    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="120")
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="60", HFMI_P2P_SYNC=sync)
     assert spawn_ranks([WORKER, str(tmp_path)], world, env=env, timeout=600) == 0
     rs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for rank, r in enumerate(rs):
         assert int(r["size"]) == world and int(r["rank"]) == rank
         assert str(r["transport"]) in ("p2p", "rccl")                 # rccl only where every rank has its own GPU
+        if str(r["transport"]) == "p2p":
+            assert str(r["p2p_sync"]) == sync
         assert float(r["sum_err"]) == 0.0                             # same summation order as the expectation
         assert float(r["avg_err"]) < 1e-15 and float(r["bcast_err"]) == 0.0 and float(r["vector_err"]) < 1e-14
         assert float(r["big_err"]) < 1e-15

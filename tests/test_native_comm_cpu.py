@@ -70,3 +70,79 @@ def test_unique_id_and_explicit_init_single_rank():
         hf.NativeCollective.from_unique_id(b"short", 1, 0, host_only=True)
     with pytest.raises(hf.HfmiError):
         hf.NativeCollective.from_unique_id(bytes(256), 1, 0, host_only=True)       # not made by hfmi_comm_unique_id
+
+
+def test_back_to_back_communicators_never_join_a_stale_segment(tmp_path):
+    """Round-2 advice: the id file is removed before any rank returns, and a rank rejects an id whose token it has
+    already joined -- six communicators in a row through one file (some still open) all reduce correctly."""
+    from hippyflow_amd.launch import spawn_ranks
+    world = 3
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="30")
+    t0 = time.time()
+    assert spawn_ranks([WORKER, str(tmp_path), "back_to_back"], world, env=env, timeout=120) == 0
+    assert time.time() - t0 < 60
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        np.testing.assert_array_equal(got["sums"], [world * (world + 1) / 2 + world * it for it in range(6)])
+        assert "host payloads only" in str(got["why"])
+
+
+def test_id_file_is_private_and_foreign_files_are_not_joined(tmp_path):
+    """The id file is created 0600 with O_EXCL|O_NOFOLLOW; a reader skips files that are not regular / not 0600."""
+    import ctypes as C
+    import stat
+    import hippyflow_amd as hf
+    from hippyflow_amd import _lib as L
+    path = str(tmp_path / "comm.id")
+    # a world-readable file with plausible size is ignored by a non-zero rank: it times out instead of joining it
+    open(path, "wb").write(hf.NativeCollective.unique_id())
+    os.chmod(path, 0o644)
+    os.environ["HFMI_COMM_TIMEOUT_S"] = "1"
+    try:
+        h = C.c_void_p()
+        with pytest.raises(hf.HfmiError, match="communicator id"):
+            L.call("hfmi_comm_init_from_file", None, path.encode(), 2, 1, C.byref(h))
+        os.unlink(path)
+        # a symlink where the temporary file would go is not followed (O_EXCL | O_NOFOLLOW): rank 0 replaces it
+        victim = tmp_path / "victim"
+        victim.write_text("precious")
+        os.symlink(str(victim), path + ".tmp.%d" % os.getpid())
+        h = C.c_void_p()
+        L.call("hfmi_comm_init_from_file", None, path.encode(), 1, 0, C.byref(h))       # one rank: publishes, joins, removes
+        assert victim.read_text() == "precious" and not os.path.exists(path)
+        L.load().hfmi_comm_destroy(h)
+    finally:
+        os.environ.pop("HFMI_COMM_TIMEOUT_S", None)
+
+
+def test_transport_decision_is_one_function_of_the_published_table():
+    """First-contact hardening: every rank evaluates the same pure function of the same table, so a missing librccl
+    (HFMI_RCCL_LIB=/nonexistent on ANY rank) sends ALL ranks to the p2p transport."""
+    import ctypes as C
+    from hippyflow_amd import _lib as L
+
+    def decide(has_dev, rccl_ok, ids, force=0):
+        n = len(ids)
+        t = C.c_int(-9)
+        why = C.create_string_buffer(200)
+        arr = (C.c_char_p * n)(*[i.encode() for i in ids])
+        L.call("hfmi_comm_decide_transport", n, (C.c_int * n)(*has_dev), (C.c_int * n)(*rccl_ok), arr, force, C.byref(t), why, 200)
+        return t.value, why.value.decode()
+
+    gpus = ["0000:%02x:00.0" % (5 + 8 * i) for i in range(8)]
+    assert decide([1] * 8, [1] * 8, gpus)[0] == 1                                   # rccl
+    t, why = decide([1] * 8, [1, 1, 1, 0, 1, 1, 1, 1], gpus)
+    assert t == 2 and "rank 3" in why                                               # one rank without librccl -> everybody p2p
+    t, why = decide([1, 1], [1, 1], [gpus[0], gpus[0]])
+    assert t == 2 and "share a GPU" in why
+    assert decide([1] * 4, [1] * 4, gpus[:4], force=1)[0] == 2
+    assert decide([0, 0, 0], [0, 0, 0], ["", "", ""])[0] == 0                       # host only
+    assert decide([1, 0], [1, 0], [gpus[0], ""])[0] == -1                           # inconsistent
+
+
+def test_missing_librccl_is_reported_not_fatal(tmp_path):
+    """HFMI_RCCL_LIB=/nonexistent: the id carries no RCCL id, nothing fails, the table says so (on a GPU box the same
+    launch picks p2p on every rank -- tests/test_gpu_comm.py)."""
+    env = dict(os.environ, HFMI_RCCL_LIB="/nonexistent/librccl.so", HFMI_COMM_TIMEOUT_S="30")
+    from hippyflow_amd.launch import spawn_ranks
+    assert spawn_ranks([WORKER, str(tmp_path), "payloads"], 2, env=env, timeout=120) == 0
