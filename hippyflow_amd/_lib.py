@@ -238,7 +238,7 @@ class Context:
                  "launches": int(n[g]), "flops_per_launch": fl[g], "bytes_per_launch": by[g]} for g in range(ng.value)]
 
     PHASES = ("apply_A", "apply_Binv", "orthogonalize", "rayleigh_quotient", "small_eig", "back_transform", "allreduce",
-              "host_d2h_wait", "host_function", "host_h2d")
+              "host_d2h_wait", "host_function", "host_h2d", "allreduce_overlapped")
 
     def profile_phases(self):
         """Milliseconds per phase of the fused solves between profile_begin and profile_end (call after profile_end).

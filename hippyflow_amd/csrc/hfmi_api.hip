@@ -140,6 +140,12 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_status, hipEventDisableTiming));
   for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_cb[i], hipEventDisableTiming));
+  for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  c->nn_hook = nullptr;
+  c->nn_hook_user = nullptr;
+  c->nn_hook_panels = 0;
+  c->nn_hook_called = false;
   HIP_TRY(hipMalloc((void**)&c->small, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->small, 0, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double), c->stream));
   HIP_TRY(hipMalloc((void**)&c->status_dev, sizeof(hfmi_status_words)));
@@ -165,6 +171,8 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_cb) (void)hipHostFree(ctx->pinned_cb);
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_cb[i]);
+  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_panel[i]);
+  (void)hipEventDestroy(ctx->ev_join);
   (void)hipFree(ctx->small);
   (void)hipFree(ctx->status_dev);
   (void)hipHostFree(ctx->status_host);
@@ -888,6 +896,49 @@ static int host_apply_pipelined(hfmi_op* op, const hfmi_block* W, hfmi_block* Y)
 }
 
 static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double beta);
+static int phase_begin_on(hfmi_ctx* ctx, int phase, hipStream_t st);
+static void phase_end_on(hfmi_ctx* ctx, int idx, hipStream_t st);
+
+// Overlapped rank reduction of an operator application (collectiveOperator.py:73-80, collective.py:98-111): the
+// last contraction of a Gram-form apply (Y = X^T G) is issued in row panels of whole rounds of tiles (hfmi_gemm_nn.hip), and
+// as soon as a panel's rows are final they are packed into a contiguous buffer, all-reduced and unpacked on the AUXILIARY
+// stream while the next panel is computed on the main one.  Only the last panel's reduction is exposed.  Same arithmetic per
+// element as the one-launch product followed by one all-reduce of the block: bit-identical results (tests/test_gpu_comm.py).
+struct panel_reduce {
+  hfmi_op* op;
+  int npanels;
+  int64_t stage_off;     // doubles used in WS_COMM so far
+  double* stage;
+  int status;
+};
+static int panel_reduce_hook(void* user, double* Y, int64_t ldy, int r, int64_t row0, int64_t rows) {
+  panel_reduce* pr = (panel_reduce*)user;
+  hfmi_ctx* ctx = pr->op->ctx;
+  if (pr->npanels >= 8) HFMI_FAIL(HFMI_ERR_INVALID, "panel_reduce: more than 8 row panels");
+  hipEvent_t ev = ctx->ev_panel[pr->npanels++];
+  HIP_TRY(hipEventRecord(ev, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev, 0));
+  double* st = pr->stage + pr->stage_off;
+  const int64_t rld = round_up(rows, 2);
+  pr->stage_off += rld * r;
+  const int ph = phase_begin_on(ctx, HFMI_PHASE_ALLREDUCE_AUX, ctx->aux_stream);
+  if (rld != rows) HIP_TRY(hipMemsetAsync(st, 0, (size_t)rld * r * sizeof(double), ctx->aux_stream));
+  HIP_TRY(hipMemcpy2DAsync(st, (size_t)rld * sizeof(double), Y + row0, (size_t)ldy * sizeof(double), (size_t)rows * sizeof(double),
+                           (size_t)r, hipMemcpyDeviceToDevice, ctx->aux_stream));
+  HFMI_TRY(comm_allreduce_device_on(pr->op->comm, st, rld * r, pr->op->comm_op, ctx->aux_stream));
+  HIP_TRY(hipMemcpy2DAsync(Y + row0, (size_t)ldy * sizeof(double), st, (size_t)rld * sizeof(double), (size_t)rows * sizeof(double),
+                           (size_t)r, hipMemcpyDeviceToDevice, ctx->aux_stream));
+  phase_end_on(ctx, ph, ctx->aux_stream);
+  return HFMI_OK;
+}
+static int g_comm_panels = -1;    // HFMI_COMM_PANELS: 0 = one all-reduce after the product, n = at most n row panels (default 4)
+int api_tuning_set(const char* key, int value) {
+  if (key && !strcmp(key, "comm_panels") && value >= 0 && value <= 8) {
+    g_comm_panels = value;
+    return 1;
+  }
+  return 0;
+}
 
 static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double beta) {
   hfmi_ctx* ctx = op->ctx;
@@ -906,6 +957,32 @@ static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double 
       if (op->kind == OP_JTJ && op->gamma_inv)
         HFMI_TRY(launch_gamma_apply(ctx, (double*)G, ldg, op->ndata, op->q, k, op->gamma_inv, (int)round_up(op->q, 16)));
       if (op->weights) HFMI_TRY(launch_row_scale(ctx, (double*)G, ldg, m, k, op->weights));
+      if (g_comm_panels < 0) {
+        const char* e = getenv("HFMI_COMM_PANELS");
+        g_comm_panels = e ? atoi(e) : 4;
+        if (g_comm_panels < 0 || g_comm_panels > 8) g_comm_panels = 4;
+      }
+      if (op->comm && g_comm_panels > 1 && beta == 0.0 && comm_transport(op->comm) != 0 && k <= 256) {
+        void* sv = nullptr;
+        HFMI_TRY(ctx_ws(ctx, WS_COMM, ((size_t)Y->ld + 16) * k * sizeof(double), &sv));
+        panel_reduce pr = {op, 0, 0, (double*)sv, HFMI_OK};
+        ctx->nn_hook = panel_reduce_hook;
+        ctx->nn_hook_user = &pr;
+        ctx->nn_hook_panels = g_comm_panels;
+        ctx->nn_hook_called = false;
+        const int s = launch_tsgemm_nn(ctx, X.p, X.ld, m, (const double*)G, ldg, k, 1.0, beta, Y->p, Y->ld, X.N);
+        ctx->nn_hook = nullptr;
+        if (s != HFMI_OK) return s;
+        if (ctx->nn_hook_called) {
+          // join: the main stream continues when the last panel is back
+          const int ph = phase_begin(ctx, HFMI_PHASE_ALLREDUCE);
+          HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+          HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+          phase_end(ctx, ph);
+          op->reduced_by_panels = true;
+        }
+        return HFMI_OK;
+      }
       HFMI_TRY(launch_tsgemm_nn(ctx, X.p, X.ld, m, (const double*)G, ldg, k, 1.0, beta, Y->p, Y->ld, X.N));
       return HFMI_OK;
     }
@@ -992,8 +1069,9 @@ extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, in
   if (W->p == Y->p) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: input and output blocks must not alias");
   HIP_TRY(hipSetDevice(op->ctx->device));
   if (accumulate && (op->post_fn || op->comm)) HFMI_FAIL(HFMI_ERR_INVALID, "op_apply: accumulate with a rank reduction attached is ambiguous");
+  op->reduced_by_panels = false;
   HFMI_TRY(op_apply_raw(op, W, Y, accumulate ? 1.0 : 0.0));
-  if (op->comm) {
+  if (op->comm && !op->reduced_by_panels) {
     const int ph = phase_begin(op->ctx, HFMI_PHASE_ALLREDUCE);
     HFMI_TRY(comm_allreduce_device(op->comm, Y->p, Y->ld * (int64_t)Y->nvec, op->comm_op));
     phase_end(op->ctx, ph);
@@ -1418,18 +1496,20 @@ int prof_stop(hfmi_ctx* ctx, int idx) {
   if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream);
   return HFMI_OK;
 }
-int phase_begin(hfmi_ctx* ctx, int phase) {
+static int phase_begin_on(hfmi_ctx* ctx, int phase, hipStream_t st) {
   if (!ctx->profiling) return -1;
   hfmi_ctx::phase_rec r;
   r.phase = phase;
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
-  (void)hipEventRecord(r.e0, ctx->stream);
+  (void)hipEventRecord(r.e0, st);
   ctx->phase_events.push_back(r);
   return (int)ctx->phase_events.size() - 1;
 }
-void phase_end(hfmi_ctx* ctx, int idx) {
-  if (idx >= 0) (void)hipEventRecord(ctx->phase_events[idx].e1, ctx->stream);
+static void phase_end_on(hfmi_ctx* ctx, int idx, hipStream_t st) {
+  if (idx >= 0) (void)hipEventRecord(ctx->phase_events[idx].e1, st);
 }
+int phase_begin(hfmi_ctx* ctx, int phase) { return phase_begin_on(ctx, phase, ctx->stream); }
+void phase_end(hfmi_ctx* ctx, int idx) { phase_end_on(ctx, idx, ctx->stream); }
 extern "C" int hfmi_profile_phases(hfmi_ctx* ctx, double* ms_out) {
   if (!ctx || !ms_out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   for (int i = 0; i < HFMI_PHASE_COUNT; ++i) ms_out[i] = ctx->phase_ms[i];

@@ -36,9 +36,9 @@ template <int TT, int NT, int WAVES, int R4>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const double* __restrict__ A, int64_t lda, int m,
                                                                     const double* __restrict__ S, int lds_, int r,
                                                                     double* __restrict__ Y, int64_t ldy, int64_t N,
-                                                                    int ntiles, int msplit, int mchunk, int64_t pstride,
+                                                                    int tail_tiles, int msplit, int mchunk, int64_t pstride,
                                                                     int full_tiles, double* __restrict__ Yfull,
-                                                                    int64_t ldfull) {
+                                                                    int64_t ldfull, int full_base, int tail_base) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2][NN_KC][SLD]
   constexpr int COLS = NT * 16;
@@ -57,14 +57,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   // Row tiles [0, full_tiles) are whole rounds of the CUs: one workgroup each over the full reduction range, written
   // straight to the result.  The remaining (fewer than one round of) tiles are split msplit-ways over the reduction
   // axis so that they, too, occupy every CU for 1/msplit of a tile's time; only those rows go through partials.
-  const int tail_tiles = ntiles - full_tiles;
+  // A launch covers the whole tiles [full_base, full_base + full_tiles) and the tail tiles [tail_base, tail_base + tail_tiles):
+  // the complete product is one launch (full_base = 0, tail_base = full_tiles) or, when the rank all-reduce of the first row
+  // panels is to overlap the rest of the product, a few launches over consecutive tile ranges (same arithmetic per element).
   // whole tiles and tail pieces are remapped over the XCDs separately: one contiguous logical range per XCD would
   // put all the short tail pieces on the last XCDs and leave the whole tiles to the others (full_tiles % 8 == 0)
   const bool whole = (int)blockIdx.x < full_tiles;
-  const int logical = whole ? xcd_remap(blockIdx.x, full_tiles)
-                            : full_tiles + xcd_remap((int)blockIdx.x - full_tiles, tail_tiles * msplit);
-  const int split = whole ? 0 : (logical - full_tiles) / tail_tiles;
-  const int tile = whole ? logical : full_tiles + (logical - full_tiles) % tail_tiles;
+  const int logical = whole ? xcd_remap(blockIdx.x, full_tiles) : xcd_remap((int)blockIdx.x - full_tiles, tail_tiles * msplit);
+  const int split = whole ? 0 : logical / tail_tiles;
+  const int tile = whole ? full_base + logical : tail_base + logical % tail_tiles;
   const int64_t t0 = (int64_t)tile * (16 * TT * WAVES) + wave * (16 * TT);
   const int i_begin = whole ? 0 : split * mchunk;
   int i_end = whole ? m : i_begin + mchunk;
@@ -546,11 +547,8 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
     full_tiles = 0;
   }
   const int tail_tiles = ntiles - full_tiles;
-  dim3 grid((unsigned)(full_tiles + tail_tiles * msplit)), block(WAVES * 64);
-  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, ntiles, msplit, mchunk, pstride,
-                     full_tiles, Y, ldy);
-  HIP_TRY(hipGetLastError());
-  if (msplit > 1) {
+  dim3 block(WAVES * 64);
+  auto reduce_tail = [&]() -> int {
     const int64_t row0 = (int64_t)full_tiles * tile_rows;   // multiple of 64
     int64_t gx = ((N - row0 + 1) / 2 + 255) / 256;
     if (gx > 2048) gx = 2048;
@@ -558,7 +556,43 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
     hipLaunchKernelGGL(k_reduce_nn, dim3((unsigned)gx, (unsigned)r), dim3(256), 0, ctx->stream, (const double*)out, msplit,
                        pstride, ldo, Y, ldy, row0, N, r);
     HIP_TRY(hipGetLastError());
+    return HFMI_OK;
+  };
+  // Row panels for an overlapped rank reduction (ctx->nn_hook, set by hfmi_op_apply): whole rounds of tiles per launch, the
+  // hook is told which rows are final after each.  Tiles keep the plan of the single launch, so the results are the same bits.
+  if (ctx->nn_hook) {
+    const int whole_cnt = msplit > 1 ? full_tiles : ntiles;          // tiles computed in one piece
+    const int rounds = whole_cnt / cus;
+    if (rounds >= 2) {
+      int panels = rounds < ctx->nn_hook_panels ? rounds : ctx->nn_hook_panels;
+      if (panels < 1) panels = 1;
+      int base = 0;
+      for (int p = 0; p < panels; ++p) {
+        const bool last = p == panels - 1;
+        const int cnt = last ? whole_cnt - base : (rounds / panels + (p < rounds % panels ? 1 : 0)) * cus;
+        const int tl = (last && msplit > 1) ? tail_tiles : 0;
+        if (msplit > 1)
+          hipLaunchKernelGGL(kern, dim3((unsigned)(cnt + tl * msplit)), block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N,
+                             tl > 0 ? tl : 1, msplit, mchunk, pstride, cnt, Y, ldy, base, full_tiles);
+        else
+          hipLaunchKernelGGL(kern, dim3((unsigned)cnt), block, shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, 1, 1, mchunk,
+                             (int64_t)0, cnt, Y, ldy, base, 0);
+        HIP_TRY(hipGetLastError());
+        if (last && msplit > 1) HFMI_TRY(reduce_tail());
+        const int64_t row0 = (int64_t)base * tile_rows;
+        const int64_t row1 = last ? N : (int64_t)(base + cnt) * tile_rows;
+        HFMI_TRY(ctx->nn_hook(ctx->nn_hook_user, Y, ldy, r, row0, row1 - row0));
+        base += cnt;
+      }
+      ctx->nn_hook_called = true;
+      return HFMI_OK;
+    }
   }
+  dim3 grid((unsigned)(full_tiles + tail_tiles * msplit));
+  hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, tail_tiles, msplit, mchunk, pstride,
+                     full_tiles, Y, ldy, 0, full_tiles);
+  HIP_TRY(hipGetLastError());
+  if (msplit > 1) HFMI_TRY(reduce_tail());
   return HFMI_OK;
 }
 

@@ -32,7 +32,7 @@ void hfmi_set_error(const char* fmt, ...);
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------ objects
-enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_MGS, WS_NSLOTS };
+enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_MGS, WS_COMM, WS_NSLOTS };
 
 struct hfmi_block {
   hfmi_ctx* ctx;
@@ -91,6 +91,14 @@ struct hfmi_ctx {
   std::vector<phase_rec> phase_events;
   double phase_ms[HFMI_PHASE_COUNT];
   // second pinned staging area (host-callback operators: double-buffered W and Y slabs)
+  // row-panel hook of tsgemm_nn (hfmi_gemm_nn.hip): when set, a large product is issued as a few launches over consecutive
+  // row ranges and the hook is called after each with the rows that are final -- hfmi_op_apply reduces those rows over the
+  // ranks on the auxiliary stream while the next panel is computed
+  int (*nn_hook)(void* user, double* Y, int64_t ldy, int r, int64_t row0, int64_t rows);
+  void* nn_hook_user;
+  int nn_hook_panels;
+  bool nn_hook_called;
+  hipEvent_t ev_panel[8], ev_join;
   void* pinned_cb;
   size_t pinned_cb_bytes;
   hipEvent_t ev_cb[4];            // D2H done x2, H2D done x2
@@ -142,6 +150,7 @@ struct hfmi_op {
   void* post_user;
   hfmi_comm* comm;       // rank average / sum of the result block (hfmi_op_set_collective), null = none
   int comm_op;
+  bool reduced_by_panels; // the last apply already reduced its result over the ranks, panel by panel (hfmi_api.hip)
 };
 // in-place all-reduce of `count` doubles of device memory on the communicator's context stream (hfmi_comm.hip)
 int comm_allreduce_device(hfmi_comm* c, double* data, int64_t count, int op);
@@ -226,6 +235,7 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
 // dispatcher: method 0 = default (divide and conquer unless tuning "eig" = 1), 1 = Jacobi (high relative accuracy)
 int launch_sym_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs, int method);
 int eig_tuning_set(const char* key, int value);   // 1 = key handled
+int api_tuning_set(const char* key, int value);   // 1 = key handled ("comm_panels")
 int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);
 // slot_c (k x r, zero padded to 16 columns) = slot_a (k x k) * slot_b[:, :r]
 int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int slot_c);

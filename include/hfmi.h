@@ -273,7 +273,8 @@ int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tfl
  * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("nn_res", 1|0) small matrix resident in LDS with persistent
  * workgroups when it fits (short reductions: Q R^-1, U = Q V); ("ss", 0|1) route skinny x skinny contractions to
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized; ("eig", 0|1) Rayleigh-Ritz
- * eigensolver of every call: divide and conquer | Jacobi. */
+ * eigensolver of every call: divide and conquer | Jacobi; ("comm_panels", 0..8) row panels of an operator application whose
+ * rank reduction overlaps the rest of the product (0 / 1 = one all-reduce after the product; default 4). */
 int hfmi_tuning_set(const char* key, int value);
 /* phases of hfmi_double_pass[_g], accumulated between hfmi_profile_begin and hfmi_profile_end (milliseconds, summed
  * over the solves in the region; device phases by HIP events on the context's stream, the HOST_* legs by the host's
@@ -288,7 +289,9 @@ int hfmi_tuning_set(const char* key, int value);
 #define HFMI_PHASE_HOST_D2H 7     /* host callback: waiting for device -> pinned host copies */
 #define HFMI_PHASE_HOST_FN 8      /* host callback: inside the host function */
 #define HFMI_PHASE_HOST_H2D 9     /* host callback: issuing / draining pinned host -> device copies */
-#define HFMI_PHASE_COUNT 10
+#define HFMI_PHASE_ALLREDUCE_AUX 10 /* rank reductions of row panels on the auxiliary stream, overlapped with the product that
+                                     * makes the next panel; HFMI_PHASE_ALLREDUCE then holds only what the main stream waited */
+#define HFMI_PHASE_COUNT 11
 int hfmi_profile_phases(hfmi_ctx* ctx, double* ms_out /* HFMI_PHASE_COUNT */);   /* after hfmi_profile_end */
 int hfmi_profile_begin(hfmi_ctx* ctx);
 int hfmi_profile_end(hfmi_ctx* ctx, int max_groups, int* ngroups, int* kind, int64_t* shape, double* ms,
