@@ -42,7 +42,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="as", choices=["as", "pod", "kle", "dipnet"],
                     help="as / pod / kle: BASELINE configs 4 / 3 / 2 of the projector path; dipnet: config 5, the projected-network "
                          "surrogate (PyTorch-ROCm bf16) fed by device AS x POD solves -- a separate JSON line with its own metric")
@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--noise", type=float, default=0.01, help="config 4: J_i = A_i P^T + noise * E_i (SURVEY 8d: 0.01; 0 = exactly rank 100)")
     ap.add_argument("--quick", action="store_true", help="1/8-size problem (smoke / profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ingest", action="store_true", help="report host -> HBM ingest rates instead of the solve (never part of `value`)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal-T steps after the timed region")
     ap.add_argument("--samples-total", type=int, default=512,
@@ -339,10 +340,121 @@ def dipnet_line(args):
     print(json.dumps(out), flush=True)
 
 
+def gpu_sysfs_snapshot(pci_bus_id=None):
+    """Shader clock / power the driver exposes through sysfs (plain file reads; no child process, no GPU call): the big
+    contractions are power-limited, so the clock they were given is part of the record.  Best effort: {} where the files
+    are not there."""
+    import glob
+    snap = {}
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        try:
+            if pci_bus_id and pci_bus_id.lower() not in os.path.realpath(dev).lower():
+                continue
+            rec = {}
+            try:
+                for line in open(os.path.join(dev, "pp_dpm_sclk")).read().splitlines():
+                    if line.strip().endswith("*"):
+                        rec["sclk"] = line.split(":", 1)[1].replace("*", "").strip()
+            except OSError:
+                pass
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6),
+                                         ("freq1_input", "sclk_hz", 1.0), ("temp1_input", "temp_c", 1e-3)):
+                    try:
+                        rec.setdefault(key, float(open(os.path.join(hw, name)).read().strip()) * scale)
+                    except (OSError, ValueError):
+                        pass
+            if rec:
+                snap[os.path.basename(os.path.dirname(dev))] = rec
+        except OSError:
+            continue
+    return snap
+
+
+def ingest_line(args):
+    """--ingest: host -> HBM rate of the sample-by-sample filling of a Jacobian block (the reference's sampling loop,
+    activeSubspaceProjector.py:178-221 / PODProjector.py:343-357).  Never part of `value`: the solve is timed
+    with its operator data resident.  Three legs on config-4-shaped samples (q x N doubles each): the synchronous upload
+    from pageable memory (hfmi_block_upload), the asynchronous one from pinned double buffers (hfmi_block_upload_async)
+    with the GPU idle, and the same while a mean-J^T J application of resident samples runs on the compute stream."""
+    import hippyflow_amd as hf
+    from hippyflow_amd import _lib as L
+    ctx = hf.Context.default()
+    q, N = 100, 200000 // (8 if args.quick else 1)
+    ns = 24
+    sample_bytes = q * N * 8
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((q, N))
+    blk = hf.MultiVector(N, ns * q)
+    # (a) pageable, synchronous
+    t0 = time.perf_counter()
+    for i in range(ns):
+        v = blk.view(i * q, q)                    # (kept alive across the call: the handle dies with the view object)
+        L.call("hfmi_block_upload", v.handle, L.ptr(src), L.LAYOUT_VECTORS)
+    ctx.synchronize()
+    t_pageable = time.perf_counter() - t0
+    # (b) pinned, asynchronous, producer = a copy into the pinned buffer (a stand-in for the host PDE solve's output)
+    def stream():
+        for _ in range(ns):
+            yield src
+    t0 = time.perf_counter()
+    blk2 = hf.ingest_stream(stream(), ns, q, N)
+    ctx.synchronize()
+    t_pinned = time.perf_counter() - t0
+    np.testing.assert_array_equal(blk2.view(0, q).to_vectors(), src)
+    # (b') the DMA alone: the producer writes in place into the pinned buffers (no host copy in the loop)
+    pins = [hf.pinned_empty((q, N)) for _ in range(2)]
+    for pb in pins:
+        pb[...] = src
+    t0 = time.perf_counter()
+    tk = [None, None]
+    for i in range(ns):
+        if tk[i & 1] is not None:
+            ctx.ingest_wait(tk[i & 1])
+        tk[i & 1] = blk2.view(i * q, q).upload_async(pins[i & 1])
+    ctx.ingest_fence()
+    ctx.synchronize()
+    t_dma = time.perf_counter() - t0
+    # (c) the same with the compute stream busy
+    resident = hf.MultiVector(N, 32 * q)
+    hf.parRandom.normal(1.0, resident)
+    op = hf.MeanJTJfromDataOperator.from_block(resident, 32, q)
+    W, Y = hf.MultiVector(N, 74), hf.MultiVector(N, 74)
+    hf.parRandom.normal(1.0, W)
+    hf.MatMvMult(op, W, Y)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    hf.MatMvMult(op, W, Y)
+    ctx.synchronize()
+    t_apply_alone = time.perf_counter() - t0
+    reps = max(1, int(t_pinned / max(t_apply_alone, 1e-4)) + 1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        hf.MatMvMult(op, W, Y)                      # enqueued; the host goes on to produce samples
+    blk3 = hf.ingest_stream(stream(), ns, q, N)
+    t_ingest_busy = time.perf_counter() - t0
+    ctx.synchronize()
+    t_both = time.perf_counter() - t0
+    out = {"metric": "host -> HBM ingest rate of sample-by-sample block filling (GB/s)", "unit": "GB/s",
+           "value": ns * sample_bytes / t_pinned / 1e9, "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "config-4-shaped Jacobian samples, %d x (%d x %d) doubles = %.2f GB" % (ns, q, N, ns * sample_bytes / 1e9)},
+           "pageable_synchronous_gbs": ns * sample_bytes / t_pageable / 1e9,
+           "pinned_async_gbs": ns * sample_bytes / t_pinned / 1e9,
+           "pinned_async_in_place_producer_gbs": ns * sample_bytes / t_dma / 1e9,
+           "pinned_async_gbs_while_computing": ns * sample_bytes / t_ingest_busy / 1e9,
+           "compute_alone_ms": t_apply_alone * 1e3, "compute_reps_alongside": reps,
+           "compute_plus_ingest_ms": t_both * 1e3, "serial_sum_ms": (reps * t_apply_alone + t_pinned) * 1e3,
+           "note": "never part of the solve's `value`; the producer here is a host memcpy into the pinned buffer"}
+    del blk3
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
     if args.workload == "dipnet":
         return dipnet_line(args)
+    if args.ingest:
+        return ingest_line(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this parent touches no GPU; it starts N fresh child interpreters (one per
         # device, nothing is re-exec'ed) and rank 0's JSON line arrives on the inherited stdout
@@ -392,16 +504,24 @@ def main():
     for _ in range(args.warmup):
         d, U = step()
     barrier()
+    pci = ctx.pci_bus_id()
+    sysfs_before = gpu_sysfs_snapshot(pci) if rank == 0 else {}
     ctx.profile_begin()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        d, U = step()
+        ts = time.perf_counter()
+        d, U = step()                                # returns when the eigenvalues are on the host: a complete solve
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
+    sysfs_after = gpu_sysfs_snapshot(pci) if rank == 0 else {}
     prof = ctx.profile_end()
     phases = ctx.profile_phases()
+    median_ms = float(np.median(step_ms))
     if use_dist:
         elapsed = collective.allReduceMax(elapsed)   # the slowest rank's clock
+        median_ms = collective.allReduceMax(median_ms)
     # the same solve with T = (A Q)^T Q formed literally, as the reference does (4 long contractions instead of 3):
     # reported next to the headline number, never part of it
     literal_ms = None
@@ -418,6 +538,9 @@ def main():
             literal_ms = collective.allReduceMax(literal_ms)
     comm_info = {"ranks": collective.size(), "transport": getattr(collective, "transport", "none"),
                  "launcher": os.environ.get("HFMI_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none")}
+    if hasattr(collective, "describe"):
+        comm_info.update(collective.describe())      # why this transport (RCCL first-contact fallback), PCI bus id of every rank
+        comm_info["row_panels_overlapped"] = int(os.environ.get("HFMI_COMM_PANELS", "4"))
     if use_dist:
         collective.close()                           # collective: every rank leaves the communicator here;
     if rank != 0:                                    # rank 0 goes on alone with the oracle legs
@@ -430,6 +553,13 @@ def main():
            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic (seeded, generated in HBM: SURVEY.md section 8d recipes)",
            "config": desc, "communicator": comm_info, "build_tag": hf.build_tag()}
+    # SURVEY 8d defines the metric on the MEDIAN solve; `value` keeps the driver's contract (K steps between two barriers,
+    # slowest rank), the median of the per-step clocks is reported beside it (a complete solve ends with its eigenvalues on
+    # the host, so each step is bracketed by a synchronisation of its own)
+    out["median_ms_per_step"] = median_ms
+    out["value_from_median"] = N * r / (median_ms * 1e-3) / 1e9
+    out["step_ms_min_max"] = [float(min(step_ms)), float(max(step_ms))]
+    out["gpu_sysfs"] = {"pci_bus_id": pci, "before_timed_region": sysfs_before, "after_timed_region": sysfs_after}
     if literal_ms is not None:
         out["literal_T_ms_per_step"] = literal_ms
     out["phases_ms_per_step"] = {name: ms / args.steps for name, ms in phases.items()}
@@ -487,8 +617,13 @@ def main():
             out["roofline"]["frac_of_in_job_measured_peak"] = (out["roofline"]["fp64_mfma_frac"] * FP64_MFMA_PEAK_TFLOPS / pm["mfma_f64_tflops"]
                                                                if out["roofline"]["bound"] == "mfma" else
                                                                out["roofline"]["algorithmic_gbs"] / pm["hbm_copy_gbs"])
+        # ... and against the MFMA rate the box sustains while HBM is being streamed (the regime the contractions run in)
+        out["device_peaks_measured"].update(ctx.bench_loaded_peak())
+        if "roofline" in out and out["roofline"]["bound"] == "mfma":
+            out["roofline"]["frac_of_in_job_loaded_peak"] = (out["roofline"]["achieved"] /
+                                                             out["device_peaks_measured"]["mfma_f64_tflops_while_streaming"])
     except Exception as exc:   # the micro-benchmark is informative only
-        out["device_peaks_measured"] = {"error": str(exc)}
+        out.setdefault("device_peaks_measured", {})["error"] = str(exc)
 
     from oracle import hippyflow_restated as hf_o
     from oracle import hippylib_restated as hp_o
@@ -507,7 +642,9 @@ def main():
                          "oracle_seconds": time.perf_counter() - t0,
                          "note": "oracle = CPU restatement of the reference path (oracle/) on the same Omega and the same operator data, "
                                  "streamed from HBM to the host and applied densely there"}
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
+        # rank 0 alone (the other ranks have left the communicator): at N > 1 `wl` is rank 0's shard, the bounded sample is
+        # drawn from it and scaled to the whole job exactly as at N = 1
         out["cpu_baseline"] = cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)

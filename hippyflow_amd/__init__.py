@@ -5,10 +5,10 @@ Host code is Python over a C ABI (include/hfmi.h, hippyflow_amd/libhfmi.so: hand
 There is no CPU fallback: importing the package is cheap and GPU-free, but any compute call
 raises if libhfmi.so or a GPU is missing.
 """
-from ._lib import Context, HfmiError, build_tag, device_count, load
+from ._lib import Context, HfmiError, build_tag, device_count, load, pinned_empty
 from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, MultipleSamePartitioningPDEsCollective,
                           MultipleSerialPDEsCollective, NativeCollective, NullCollective, TorchCollective)
-from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector
+from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector, ingest_stream
 from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobianOperator, DeviceOperator, HostCallbackOperator,
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
                         JJT, JTJ, MeanJJTfromDataOperator, MeanJTJfromDataOperator, PriorPreconditionedProjector,

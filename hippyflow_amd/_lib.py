@@ -38,6 +38,7 @@ SIGNATURES = {
     "hfmi_ctx_get_stream": [_P, _PP],
     "hfmi_ctx_synchronize": [_P],
     "hfmi_ctx_device_info": [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "hfmi_ctx_pci_bus_id": [_P, C.c_char_p, C.c_int],
     "hfmi_timer_start": [_P],
     "hfmi_timer_stop": [_P, _D],
     "hfmi_block_create": [_P, C.c_int64, C.c_int, _PP],
@@ -47,6 +48,11 @@ SIGNATURES = {
     "hfmi_block_info": [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64), _PP],
     "hfmi_block_upload": [_P, _P, C.c_int],
     "hfmi_block_download": [_P, _P, C.c_int],
+    "hfmi_host_alloc_pinned": [C.c_size_t, C.POINTER(C.c_void_p)],
+    "hfmi_host_free_pinned": [C.c_void_p],
+    "hfmi_block_upload_async": [_P, _P, C.c_int, C.POINTER(C.c_int64)],
+    "hfmi_ingest_wait": [_P, C.c_int64],
+    "hfmi_ingest_fence": [_P],
     "hfmi_block_zero": [_P],
     "hfmi_block_copy": [_P, _P],
     "hfmi_block_scale": [_P, C.c_double],
@@ -94,6 +100,7 @@ SIGNATURES = {
     "hfmi_bench_tsgemm_tn": [_P, _P, C.c_int, C.c_int, _P, _D],
     "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
     "hfmi_bench_peaks": [_P, _D, _D, _D],
+    "hfmi_bench_loaded_peak": [_P, _D, _D],
     "hfmi_profile_begin": [_P],
     "hfmi_profile_phases": [_P, _D],
     "hfmi_tuning_set": [C.c_char_p, C.c_int],
@@ -174,6 +181,40 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _PinnedOwner:
+    def __init__(self, p):
+        self.p = p
+
+    def __del__(self):
+        try:
+            load().hfmi_host_free_pinned(self.p)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array over page-locked host memory (hfmi_host_alloc_pinned): the source of ``MultiVector.upload_async``."""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    call("hfmi_host_alloc_pinned", C.c_size_t(max(nbytes, 8)), C.byref(p))
+    owner = _PinnedOwner(p)
+    buf = (C.c_char * max(nbytes, 8)).from_address(p.value)
+    arr_owner = np.ndarray.__new__(_PinnedArray, shape, dtype, buffer=buf)
+    arr_owner._owner = owner
+    return arr_owner
+
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray that keeps its pinned allocation alive (views share ``base``)."""
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self._owner = getattr(obj, "_owner", None)
+
+
 class Context:
     """One per GPU (hfmi_ctx).  `Context.default()` gives the process-wide context of
     cuda:LOCAL_RANK (one process per GPU)."""
@@ -221,6 +262,25 @@ class Context:
         a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
         call("hfmi_bench_peaks", self.handle, C.byref(a), C.byref(b), C.byref(c))
         return {"mfma_f64_tflops": a.value, "fma_f64_tflops": b.value, "hbm_copy_gbs": c.value}
+
+    def ingest_wait(self, ticket):
+        """Host wait until the upload with this ticket has left its pinned buffer."""
+        call("hfmi_ingest_wait", self.handle, int(ticket))
+
+    def ingest_fence(self):
+        """Compute enqueued from here on sees every block uploaded so far (device-side wait, does not block the host)."""
+        call("hfmi_ingest_fence", self.handle)
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        call("hfmi_ctx_pci_bus_id", self.handle, buf, 64)
+        return buf.value.decode()
+
+    def bench_loaded_peak(self):
+        """fp64 MFMA rate while a copy kernel streams HBM on a second stream (the power-limited regime of the solve)."""
+        a, b = C.c_double(0), C.c_double(0)
+        call("hfmi_bench_loaded_peak", self.handle, C.byref(a), C.byref(b))
+        return {"mfma_f64_tflops_while_streaming": a.value, "hbm_copy_gbs_beside_it": b.value}
 
     def profile_begin(self):
         call("hfmi_profile_begin", self.handle)

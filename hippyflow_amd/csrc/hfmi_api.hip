@@ -142,6 +142,8 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_cb[i], hipEventDisableTiming));
   for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  c->ingest_stream = nullptr;
+  c->ingest_seq = 0;
   c->nn_hook = nullptr;
   c->nn_hook_user = nullptr;
   c->nn_hook_panels = 0;
@@ -173,6 +175,11 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_cb[i]);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_panel[i]);
   (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ingest_stream) {
+    (void)hipStreamSynchronize(ctx->ingest_stream);
+    for (int i = 0; i < HFMI_INGEST_RING; ++i) (void)hipEventDestroy(ctx->ev_ingest[i]);
+    (void)hipStreamDestroy(ctx->ingest_stream);
+  }
   (void)hipFree(ctx->small);
   (void)hipFree(ctx->status_dev);
   (void)hipHostFree(ctx->status_host);
@@ -374,6 +381,71 @@ extern "C" int hfmi_block_upload(hfmi_block* b, const double* host, int layout) 
   }
   return HFMI_OK;
 }
+// ------------------------------------------------------------------ streaming ingest (PODProjector.py:343-357,
+// activeSubspaceProjector.py:178-221: the reference fills its blocks sample by sample from host PDE solves)
+// A host producer appends sample i + 1 while sample i's contraction runs: the copy is enqueued on the context's INGEST stream
+// from pinned memory (hfmi_host_alloc_pinned) and returns at once with a ticket; hfmi_ingest_wait(ticket) tells the producer
+// when that pinned buffer may be overwritten; hfmi_ingest_fence makes the compute stream wait (on the device, the host is
+// not blocked) for everything uploaded so far.
+extern "C" int hfmi_host_alloc_pinned(size_t bytes, void** out) {
+  if (!out || bytes == 0) HFMI_FAIL(HFMI_ERR_INVALID, "host_alloc_pinned: bad argument");
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return HFMI_OK;
+}
+extern "C" int hfmi_host_free_pinned(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return HFMI_OK;
+}
+extern "C" int hfmi_block_upload_async(hfmi_block* b, const double* host_pinned, int layout, int64_t* ticket) {
+  if (!b || !host_pinned) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  hfmi_ctx* ctx = b->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->ingest_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->ingest_stream, hipStreamNonBlocking));
+    for (int i = 0; i < HFMI_INGEST_RING; ++i) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ingest[i], hipEventDisableTiming));
+  }
+  // the block may still be read by work queued on the compute stream (a view that is being refilled): order behind it
+  HIP_TRY(hipEventRecord(ctx->ev_status, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->ingest_stream, ctx->ev_status, 0));
+  const int slot = (int)(ctx->ingest_seq % HFMI_INGEST_RING);
+  if (ctx->ingest_seq >= HFMI_INGEST_RING) HIP_TRY(hipEventSynchronize(ctx->ev_ingest[slot]));   // ring of tickets: the oldest must be done
+  if (layout == HFMI_LAYOUT_VECTORS) {
+    // one vector per host row: straight into the block's columns, no staging, no conversion kernel
+    HIP_TRY(hipMemcpy2DAsync(b->p, (size_t)b->ld * sizeof(double), host_pinned, (size_t)b->N * sizeof(double),
+                             (size_t)b->N * sizeof(double), (size_t)b->nvec, hipMemcpyHostToDevice, ctx->ingest_stream));
+    HIP_TRY(hipEventRecord(ctx->ev_ingest[slot], ctx->ingest_stream));
+  } else if (layout == HFMI_LAYOUT_DENSE) {
+    void* stage = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_INGEST, (size_t)b->N * b->nvec * sizeof(double), &stage));
+    HIP_TRY(hipMemcpyAsync(stage, host_pinned, (size_t)b->N * b->nvec * sizeof(double), hipMemcpyHostToDevice, ctx->ingest_stream));
+    HIP_TRY(hipEventRecord(ctx->ev_ingest[slot], ctx->ingest_stream));     // the pinned buffer is free from here
+    hipStream_t saved = ctx->stream;                                        // the launchers enqueue on ctx->stream
+    ctx->stream = ctx->ingest_stream;
+    const int s = launch_dense_to_block(ctx, (const double*)stage, b->p, b->ld, b->N, b->nvec);
+    ctx->stream = saved;
+    if (s != HFMI_OK) return s;
+  } else {
+    HFMI_FAIL(HFMI_ERR_INVALID, "block_upload_async: unknown layout %d", layout);
+  }
+  if (ticket) *ticket = ctx->ingest_seq;
+  ++ctx->ingest_seq;
+  return HFMI_OK;
+}
+extern "C" int hfmi_ingest_wait(hfmi_ctx* ctx, int64_t ticket) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  if (ticket < 0 || ticket >= ctx->ingest_seq) HFMI_FAIL(HFMI_ERR_INVALID, "ingest_wait: no upload with ticket %lld", (long long)ticket);
+  if (ctx->ingest_seq - ticket > HFMI_INGEST_RING) return HFMI_OK;          // waited for when its ring slot was reused
+  HIP_TRY(hipEventSynchronize(ctx->ev_ingest[ticket % HFMI_INGEST_RING]));
+  return HFMI_OK;
+}
+extern "C" int hfmi_ingest_fence(hfmi_ctx* ctx) {
+  if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
+  if (!ctx->ingest_stream) return HFMI_OK;
+  HIP_TRY(hipEventRecord(ctx->ev_join, ctx->ingest_stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return HFMI_OK;
+}
+
 extern "C" int hfmi_block_download(const hfmi_block* b, double* host, int layout) {
   if (!b || !host) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   hfmi_ctx* ctx = b->ctx;
@@ -1623,4 +1695,14 @@ extern "C" int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* 
   if (!ctx || !mfma_f64_tflops || !fma_f64_tflops || !hbm_copy_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   return launch_bench_peaks(ctx, mfma_f64_tflops, fma_f64_tflops, hbm_copy_gbs);
+}
+extern "C" int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbs) {
+  if (!ctx || !mfma_f64_tflops || !hbm_copy_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_bench_loaded_peak(ctx, mfma_f64_tflops, hbm_copy_gbs);
+}
+extern "C" int hfmi_ctx_pci_bus_id(hfmi_ctx* ctx, char* buf, int len) {
+  if (!ctx || !buf || len < 16) HFMI_FAIL(HFMI_ERR_INVALID, "ctx_pci_bus_id: bad argument");
+  HIP_TRY(hipDeviceGetPCIBusId(buf, len, ctx->device));
+  return HFMI_OK;
 }

@@ -32,7 +32,8 @@ void hfmi_set_error(const char* fmt, ...);
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------ objects
-enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_MGS, WS_COMM, WS_NSLOTS };
+enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_MGS, WS_COMM, WS_INGEST, WS_NSLOTS };
+#define HFMI_INGEST_RING 8
 
 struct hfmi_block {
   hfmi_ctx* ctx;
@@ -99,6 +100,10 @@ struct hfmi_ctx {
   int nn_hook_panels;
   bool nn_hook_called;
   hipEvent_t ev_panel[8], ev_join;
+  // streaming ingest: uploads from pinned host memory on their own stream, a ring of completion events = tickets
+  hipStream_t ingest_stream;
+  hipEvent_t ev_ingest[HFMI_INGEST_RING];
+  int64_t ingest_seq;
   void* pinned_cb;
   size_t pinned_cb_bytes;
   hipEvent_t ev_cb[4];            // D2H done x2, H2D done x2
@@ -247,3 +252,4 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
 
 // micro-benchmarks
 int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs);
+int launch_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_tflops, double* copy_gbs);

@@ -704,3 +704,47 @@ int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, d
   *copy_gbs = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
   return HFMI_OK;
 }
+
+__global__ void k_bench_copy_loop(const d2* __restrict__ src, d2* __restrict__ dst, int64_t n, int reps) {
+  for (int rep = 0; rep < reps; ++rep)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+      __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+// The fp64 MFMA rate this box sustains WHILE HBM is being streamed: the constant-operand MFMA loop on the context's stream with
+// the copy kernel running beside it on the auxiliary stream (two workgroups per CU, ~3 TB/s).  The big contractions of the
+// solve run in exactly that regime (their clock is set by the power limit), so this, not the cold
+// micro-benchmark, is the in-job ceiling their fraction should be read against.
+int launch_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_tflops, double* copy_gbs) {
+  void* buf = nullptr;
+  const size_t bytes = (size_t)2 << 30;
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, bytes + 4096, &buf));
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int64_t n = (int64_t)(bytes / 2 / sizeof(d2));
+  d2* src = (d2*)buf;
+  d2* dst = src + n;
+  double* out = (double*)(dst + n);
+  hipEvent_t c0, c1;
+  HIP_TRY(hipEventCreate(&c0));
+  HIP_TRY(hipEventCreate(&c1));
+  const int it1 = 2000, g1 = cus * 16, copies = 24, reps = 3;
+  hipLaunchKernelGGL(k_bench_mfma, dim3(g1), dim3(256), 0, ctx->stream, out, 100);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipEventRecord(c0, ctx->aux_stream));
+  // ONE resident launch (its workgroups keep their slots beside the MFMA waves), four workgroups per CU
+  hipLaunchKernelGGL(k_bench_copy_loop, dim3(cus * 4), dim3(256), 0, ctx->aux_stream, src, dst, n, copies);
+  HIP_TRY(hipEventRecord(c1, ctx->aux_stream));
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int rep = 0; rep < reps; ++rep) hipLaunchKernelGGL(k_bench_mfma, dim3(g1), dim3(256), 0, ctx->stream, out, it1);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventSynchronize(c1));
+  float ms = 0.f, msc = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&msc, c0, c1));
+  (void)hipEventDestroy(c0);
+  (void)hipEventDestroy(c1);
+  *mfma_tflops = (double)reps * g1 * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+  *copy_gbs = (double)copies * (double)bytes / (msc * 1e-3) / 1e9;   // over the whole copy window (part of it runs alone)
+  return HFMI_OK;
+}

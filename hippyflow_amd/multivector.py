@@ -69,6 +69,21 @@ class MultiVector:
         L.call("hfmi_block_upload", mv.handle, L.ptr(rows), L.LAYOUT_VECTORS)
         return mv
 
+    def upload_async(self, rows, layout="vectors"):
+        """Streaming ingest (PODProjector.py:343-357, activeSubspaceProjector.py:178-221: the reference fills its blocks
+        sample by sample): copy a PINNED host array (``pinned_empty``) into this block -- normally a ``view`` of one
+        sample's vectors -- on the context's ingest stream, without blocking.  Returns a ticket: ``ctx.ingest_wait(ticket)``
+        before the pinned array is overwritten, ``ctx.ingest_fence()`` before compute that reads the block is enqueued."""
+        if not isinstance(rows, np.ndarray) or rows.dtype != np.float64 or not rows.flags.c_contiguous:
+            raise ValueError("upload_async: a C-contiguous float64 array from pinned_empty() is required")
+        want = (self._k, self._N) if layout == "vectors" else (self._N, self._k)
+        if tuple(rows.shape) != want:
+            raise ValueError("upload_async: array of shape %s expected, got %s" % (want, tuple(rows.shape)))
+        t = C.c_int64(-1)
+        L.call("hfmi_block_upload_async", self.handle, L.ptr(rows), L.LAYOUT_VECTORS if layout == "vectors" else L.LAYOUT_DENSE,
+               C.byref(t))
+        return t.value
+
     def to_dense(self):
         out = np.empty((self._N, self._k), dtype=np.float64)
         L.call("hfmi_block_download", self.handle, L.ptr(out), L.LAYOUT_DENSE)
@@ -267,3 +282,33 @@ def MvDSmatMult(X, A_small, Y):
     if A_small.shape != (X.nvec(), Y.nvec()):
         raise AssertionError("MvDSmatMult: matrix shape %s does not match (%d, %d)" % (A_small.shape, X.nvec(), Y.nvec()))
     L.call("hfmi_block_gemm_small", X.handle, L.ptr(A_small), 1.0, 0.0, Y.handle)
+
+
+def ingest_stream(items, count, vectors_per_item, N, ctx=None, nbuf=2):
+    """Fill a block of ``count * vectors_per_item`` vectors from an iterable that PRODUCES its items on the host one at
+    a time -- the reference's sampling loops (PODProjector.py:343-357: one observable per PDE solve;
+    activeSubspaceProjector.py:178-221: one Jacobian per sample).  Item i (``(vectors_per_item, N)`` or ``(N,)``) is
+    copied into one of ``nbuf`` pinned buffers and uploaded asynchronously while the producer works on item i + 1;
+    nothing here waits for the GPU except when a pinned buffer is about to be reused.  Returns the block; compute
+    enqueued afterwards sees all of it (``ingest_fence``)."""
+    ctx = ctx or L.Context.default()
+    block = MultiVector(int(N), int(count) * int(vectors_per_item), ctx=ctx)
+    bufs = [L.pinned_empty((int(vectors_per_item), int(N))) for _ in range(nbuf)]
+    tickets = [None] * nbuf
+    got = 0
+    for i, item in enumerate(items):
+        if i >= count:
+            raise ValueError("ingest_stream: the producer yielded more than %d items" % count)
+        b = i % nbuf
+        if tickets[b] is not None:
+            ctx.ingest_wait(tickets[b])
+        np.copyto(bufs[b], np.asarray(item, dtype=np.float64).reshape(vectors_per_item, N))
+        tickets[b] = block.view(i * vectors_per_item, vectors_per_item).upload_async(bufs[b])
+        got = i + 1
+    if got != count:
+        raise ValueError("ingest_stream: the producer yielded %d of %d items" % (got, count))
+    for t in tickets:
+        if t is not None:
+            ctx.ingest_wait(t)             # the pinned buffers are freed when this function returns
+    ctx.ingest_fence()
+    return block

@@ -27,7 +27,7 @@ import numpy as np
 
 from . import _lib as L
 from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
-from .multivector import MatMvMult, MultiVector, Vector
+from .multivector import ingest_stream, MatMvMult, MultiVector, Vector
 from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, SnapshotGramOperator, Solver2Operator,
                         as_device_operator)
@@ -189,6 +189,13 @@ class ActiveSubspaceProjector:
     def _initialize_batched_samples(self):
         """Materialise this rank's Jacobians in HBM (counterpart of :347-397)."""
         n = self.parameters['samples_per_process']
+        if hasattr(self.observable, 'jacobian_stream'):
+            # the reference's loop (one Jacobian per host PDE solve, :178-221): sample i + 1 is produced while sample i is
+            # on its way to HBM through a pinned buffer (multivector.ingest_stream)
+            q, dM = self.observable.jacobian_shape()
+            block = ingest_stream(self.observable.jacobian_stream(n), n, q, dM, ctx=self.ctx)
+            self.Js = (block, int(n), int(q))
+            return
         data = self.observable.jacobian_data(n)
         if isinstance(data, tuple):
             block, ndata, q = data
@@ -525,7 +532,11 @@ class PODProjector:
         t0 = time.time()
         if self.LocalObservables is None:
             n = self.parameters['sample_per_process']
-            self.set_snapshots(self.observable.sample_observables(n, self.prior, None))     # the loop at :343-357
+            if hasattr(self.observable, 'observable_stream'):                               # the loop at :343-357, overlapped
+                self.LocalObservables = ingest_stream(self.observable.observable_stream(n, self.prior, None), n, 1,
+                                                      self.observable.output_dimension(), ctx=self.ctx)
+            else:
+                self.set_snapshots(self.observable.sample_observables(n, self.prior, None))
         X = self.LocalObservables
         LocalPODOperator = SnapshotGramOperator(X, scale=1.0 / X.nvec())                      # :359-361
         GlobalPODOperator = CollectiveOperator(LocalPODOperator, self.collective, mpi_op='avg')  # :363

@@ -67,6 +67,7 @@ int hfmi_ctx_set_stream(hfmi_ctx* ctx, void* hip_stream);
 int hfmi_ctx_get_stream(hfmi_ctx* ctx, void** hip_stream);
 int hfmi_ctx_synchronize(hfmi_ctx* ctx);
 int hfmi_ctx_device_info(hfmi_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
+int hfmi_ctx_pci_bus_id(hfmi_ctx* ctx, char* buf, int len);   /* "0000:5d:00.0": keys the sysfs clock / power files bench.py reads */
 /* HIP-event timer on the context's stream (bench.py measures kernels with it) */
 int hfmi_timer_start(hfmi_ctx* ctx);
 int hfmi_timer_stop(hfmi_ctx* ctx, double* milliseconds); /* synchronises */
@@ -83,6 +84,17 @@ int hfmi_block_destroy(hfmi_block* b);
 int hfmi_block_info(const hfmi_block* b, int64_t* N, int* nvec, int64_t* ld, double** dptr);
 int hfmi_block_upload(hfmi_block* b, const double* host, int layout);
 int hfmi_block_download(const hfmi_block* b, double* host, int layout);
+/* streaming ingest: the reference fills its snapshot / Jacobian blocks sample by sample from host PDE solves
+ * (PODProjector.py:343-357; activeSubspaceProjector.py:178-221).  hfmi_block_upload_async copies from PINNED host memory
+ * (hfmi_host_alloc_pinned) on the context's ingest stream and returns at once; *ticket names the upload.
+ * hfmi_ingest_wait(ticket): the pinned buffer of that upload may be overwritten (host wait).  hfmi_ingest_fence: work
+ * enqueued afterwards on the compute stream sees every upload made so far (device-side wait, the host is not blocked).
+ * b is normally a view (hfmi_block_view) of the vectors of one sample. */
+int hfmi_host_alloc_pinned(size_t bytes, void** out);
+int hfmi_host_free_pinned(void* p);
+int hfmi_block_upload_async(hfmi_block* b, const double* host_pinned, int layout, int64_t* ticket);
+int hfmi_ingest_wait(hfmi_ctx* ctx, int64_t ticket);
+int hfmi_ingest_fence(hfmi_ctx* ctx);
 int hfmi_block_zero(hfmi_block* b);                                 /* MultiVector.zero */
 int hfmi_block_copy(hfmi_block* dst, const hfmi_block* src);        /* copy constructor */
 int hfmi_block_scale(hfmi_block* b, double alpha);                  /* vector *= alpha */
@@ -260,6 +272,9 @@ int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, i
 int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms);
 /* fp64 MFMA / fp64 FMA / HBM-copy micro-benchmarks (peak denominators measured in the same job) */
 int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbs);
+/* the same MFMA loop with a copy kernel streaming HBM beside it on a second stream: the ceiling of the power-limited regime the
+ * big contractions run in (bench.py: roofline.frac_of_in_job_loaded_peak) */
+int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbs);
 /* per-launch HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from the
  * timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by events on
  * the context's stream.  end() synchronises and returns one record per distinct (kernel, shape):
