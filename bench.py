@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--noise", type=float, default=0.01, help="config 4: J_i = A_i P^T + noise * E_i (SURVEY 8d: 0.01; 0 = exactly rank 100)")
     ap.add_argument("--quick", action="store_true", help="1/8-size problem (smoke / profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-workers", type=int, default=max(1, min(16, (os.cpu_count() or 1) // 4)),
+                    help="--prior: worker PROCESSES (each with its own sparse LU) the host R^-1 callback deals its vectors to")
     ap.add_argument("--ingest", action="store_true", help="report host -> HBM ingest rates instead of the solve (never part of `value`)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal-T steps after the timed region")
@@ -89,12 +91,14 @@ def build_workload(args, hf, rank, world):
         op = wl.operator
         B = Binv = None
         if args.prior:
-            prior = workloads.BiLaplacianPrior(nx, ny, delta=1.0, gamma=0.1)
+            prior = workloads.BiLaplacianPrior(nx, ny, delta=1.0, gamma=0.1, processes=args.host_workers)
             B = hf.CsrOperator(prior.R)
-            Binv = hf.HostCallbackOperator(prior.Rsolver, N)
+            # every worker process should get at least one vector of a slab: the whole block in one slab when there are many
+            Binv = hf.HostCallbackOperator(prior.Rsolver, N, chunk_vectors=(0 if args.host_workers > 8 else None))
             desc.update({"B": "R = A M_l^-1 A, A = M + 0.1 K on a %d x %d P1 grid: CSR on the device, %.1f nnz/row" % (nx, ny, prior.R.nnz / N),
-                         "Binv": "host sparse LU of A (SuperLU), two triangular sweeps per vector on %d host thread(s), slabs of %d vectors "
-                                 "through pinned double buffers" % (prior.Rsolver.threads, Binv.chunk_vectors)})
+                         "Binv": "host sparse LU of A (SuperLU), two triangular sweeps per vector in %d worker process(es) (each with its own "
+                                 "factorisation, slabs through shared memory), slabs of %s vectors through pinned double buffers"
+                                 % (prior.Rsolver.processes, Binv.chunk_vectors or "all")})
     elif args.workload == "pod":
         N, n, r, p = 500000 // scale, 2048, 128, 10
         assert n % world == 0

@@ -46,7 +46,15 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
                                                                     const double* B /* not restrict: see the stage loop */, int64_t ldb, int k,
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ out, int64_t si, int64_t sj,
-                                                                    int64_t sps, int direct, int probe) {
+                                                                    int64_t sps, int direct, int probe_arg) {
+  // timing-only diagnostic (scripts/tn_probe.py; results are garbage): compiled in only with -DHFMI_TN_PROBE
+  // (HFMI_EXTRA_HIPCC_FLAGS), the production instance carries no run-time branch for it
+#ifdef HFMI_TN_PROBE
+  const int probe = probe_arg;
+#else
+  constexpr int probe = 0;
+  (void)probe_arg;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = TN_BK;
   constexpr int COLS = NT * 16;
@@ -105,23 +113,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 
   d2 breg[NQ];
   auto stage_load = [&](int64_t ts) {
-#if defined(TN_EXP) && TN_EXP == 2     // experiment builds (scripts/build_variant.sh): LDS stores without the global loads
-    (void)ts;
-#elif defined(TN_EXP) && TN_EXP == 3   // loads that always hit the same lines
-#pragma unroll
-    for (int qd = 0; qd < NQ; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + t_begin);
-#else
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) breg[qd] = *reinterpret_cast<const d2*>(b_ptr[qd] + ts);
-#endif
   };
   auto stage_store = [&](double* L) {
-#if defined(TN_EXP) && TN_EXP == 1     // global loads without the LDS stores (the registers are kept alive)
-#pragma unroll
-    for (int qd = 0; qd < NQ; ++qd) asm volatile("" ::"v"(breg[qd]));
-    (void)L;
-    return;
-#endif
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
       const int c = tid + NTHR * qd;
@@ -206,7 +201,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
       // between the streamed operand's fragment fetched one iteration ago and the wait in front of its first MFMA.  Behind
       // a branch (as it was until round 2) the compiler has to assume the path WITHOUT them at the join and emits
       // vmcnt(6) instead of vmcnt(6 + NQ): every stage then began by waiting for these loads' L2 / HBM round trip --
-      // 10-12 % of the kernel (experiment builds TN_EXP = 1..3, scripts/build_variant.sh; profiles/r02o_tn_variants.txt).
+      // 10-12 % of the kernel (round-2 experiment builds, profiles/r02o_tn_variants.txt).
       stage_load(has_next ? ts + BK : ts);
       asm volatile("" ::: "memory");   // keeps the loads HERE: left alone they are sunk to their ds_write and waited for with vmcnt(0)
       const double* L = lds + (s & 1) * BUFD;

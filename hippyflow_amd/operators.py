@@ -566,6 +566,8 @@ class SeriallySampledJacobianOperator:
         else:
             self.zs = len(self.ms) * [None] if type(self.ms) is list else zs
         self.jacobian_factory = jacobian_factory or (lambda obs: obs.jacobian())
+        self.max_solver_retries = 100         # fresh draws per sample before a failing forward solve is reported
+        self.solver_failures = 0              # failed forward solves so far (each was followed by a fresh draw)
         self.u = observable.generate_vector(0) if hasattr(observable, "generate_vector") else None
         self.m = observable.generate_vector(1) if hasattr(observable, "generate_vector") else None
         self.z = None if control_distribution is None else observable.generate_vector(3)
@@ -593,17 +595,28 @@ class SeriallySampledJacobianOperator:
         from .randomized import parRandom
         if self.ms is None:
             for _ in range(self.nsamples):
-                self.m.zero()
-                self.noise.zero()
-                parRandom.normal(1, self.noise)
-                self.prior.sample(self.noise, self.m)
-                linearization_x = [self.u, self.m, None]
-                if self.control_distribution is not None:
-                    self.z.zero()
-                    self.control_distribution.sample(self.z)
-                    linearization_x.append(self.z)
-                self.observable.solveFwd(self.u, linearization_x)
-                self.observable.setLinearizationPoint(linearization_x)
+                # the reference re-draws the sample when the forward solve fails (activeSubspaceProjector.py:180-211: a bare
+                # try / except around sampling + solveFwd inside `while not solved`); its loop has no exit -- this one gives
+                # up after max_solver_retries fresh draws and says which sample could not be solved
+                for attempt in range(self.max_solver_retries + 1):
+                    self.m.zero()
+                    self.noise.zero()
+                    parRandom.normal(1, self.noise)
+                    self.prior.sample(self.noise, self.m)
+                    linearization_x = [self.u, self.m, None]
+                    if self.control_distribution is not None:
+                        self.z.zero()
+                        self.control_distribution.sample(self.z)
+                        linearization_x.append(self.z)
+                    try:
+                        self.observable.solveFwd(self.u, linearization_x)
+                        self.observable.setLinearizationPoint(linearization_x)
+                        break
+                    except Exception as exc:          # noqa: BLE001 -- any solver failure means "draw again", as upstream
+                        self.solver_failures += 1
+                        if attempt == self.max_solver_retries:
+                            raise RuntimeError("forward solve failed for %d consecutive draws of one sample (last error: %r)"
+                                               % (self.max_solver_retries + 1, exc)) from exc
                 self._accumulate(x, y, 1.0 / self.nsamples if self.average else 1.0)
         else:
             nsamples = len(self.ms)

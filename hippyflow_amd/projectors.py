@@ -68,53 +68,53 @@ class ParameterList(object):
 def ActiveSubspaceParameterList():
     """activeSubspaceProjector.py:33-66 (same keys, same defaults)."""
     parameters = {}
-    parameters['samples_per_process'] = [64, 'Number of samples per process']
-    parameters['jacobian_data_per_process'] = [512, 'Number of samples per process']
-    parameters['error_test_samples'] = [50, 'Number of samples for error test']
-    parameters['rank'] = [128, 'Rank of subspace']
-    parameters['jacobian_rank'] = [128, 'Rank of Jacobians generated']
-    parameters['control_jacobian_rank'] = [None, 'Rank of control Jacobians generated']
-    parameters['oversampling'] = [10, 'Oversampling parameter for randomized algorithms']
-    parameters['double_loop_samples'] = [20, 'Number of samples used in double loop MC approximation']
-    parameters['verbose'] = [True, 'Boolean for printing']
-    parameters['input_decoder_name'] = ['_input_decoder', 'string for naming']
-    parameters['output_decoder_name'] = ['_output_decoder', 'string for naming']
-    parameters['initialize_samples'] = [False, 'Boolean for the initialization of samples']
-    parameters['serialized_sampling'] = [True, 'Boolean for the serialization of sampling on a process']
-    parameters['observable_constructor'] = [None, 'observable constructor function, assumed to take a mesh, and kwargs']
-    parameters['observable_kwargs'] = [{}, 'kwargs used when instantiating multiple local instances of observables']
-    parameters['output_directory'] = [None, 'output directory for saving arrays and plots']
-    parameters['plot_label_suffix'] = ['', 'suffix for plot label']
-    parameters['save_and_plot'] = [True, 'Boolean for saving data and plots (only False for unit testing)']
-    parameters['store_Omega'] = [False, 'Boolean for storing Gaussian random matrix (only True for unit testing)']
-    parameters['ms_given'] = [False, 'Boolean for passing ms into serialized AS construction (only True for unit testing)']
+    parameters['samples_per_process'] = [64, 'Monte-Carlo Jacobian samples averaged on each rank (one GPU per rank)']
+    parameters['jacobian_data_per_process'] = [512, 'per-rank samples whose low-rank Jacobians are written out as training data']
+    parameters['error_test_samples'] = [50, 'held-out draws used by the projection-error tests']
+    parameters['rank'] = [128, 'r: eigenpairs kept (columns of the decoder)']
+    parameters['jacobian_rank'] = [128, 'truncation rank of the per-sample Jacobian SVDs']
+    parameters['control_jacobian_rank'] = [None, 'the same for Jacobians with respect to the control variable (None: not formed)']
+    parameters['oversampling'] = [10, 'p: extra probe vectors, the double pass works on r + p']
+    parameters['double_loop_samples'] = [20, 'inner samples of the nested Monte-Carlo estimator']
+    parameters['verbose'] = [True, 'print progress and timings on rank 0']
+    parameters['input_decoder_name'] = ['_input_decoder', 'tail of the input-decoder file name (after AS_<nsamples>)']
+    parameters['output_decoder_name'] = ['_output_decoder', 'tail of the output-decoder file name']
+    parameters['initialize_samples'] = [False, 'draw and store the linearisation points when the projector is built']
+    parameters['serialized_sampling'] = [True, 'one sample at a time through the host operator instead of stored Jacobians']
+    parameters['observable_constructor'] = [None, 'callable(mesh, **kwargs) building one more local observable']
+    parameters['observable_kwargs'] = [{}, 'keyword arguments handed to observable_constructor']
+    parameters['output_directory'] = [None, 'prefix of every file written (decoders, eigenvalues, plots)']
+    parameters['plot_label_suffix'] = ['', 'appended to plot titles and file names']
+    parameters['save_and_plot'] = [True, 'write the arrays and spectra (the unit tests switch it off)']
+    parameters['store_Omega'] = [False, 'keep the probe block on the projector so that a test can replay it']
+    parameters['ms_given'] = [False, 'linearisation points are supplied by the caller (tests of the serialized route)']
     return ParameterList(parameters)
 
 
 def PODParameterList():
     """PODProjector.py:35-49."""
     parameters = {}
-    parameters['sample_per_process'] = [100, 'Number of samples per process']
-    parameters['data_per_process'] = [250, 'Number of data per process']
-    parameters['rank'] = [20, 'Rank of subspace']
-    parameters['oversampling'] = [10, 'Oversampling parameter for randomized algorithms']
-    parameters['verbose'] = [True, 'Boolean for printing']
-    parameters['output_directory'] = [None, 'output directory for saving arrays and plots']
-    parameters['plot_label_suffix'] = ['', 'suffix for plot label']
+    parameters['sample_per_process'] = [100, 'state snapshots drawn on each rank for the POD']
+    parameters['data_per_process'] = [250, 'per-rank (parameter, observable) pairs written out as training data']
+    parameters['rank'] = [20, 'r: POD modes kept']
+    parameters['oversampling'] = [10, 'p: extra probe vectors, the double pass works on r + p']
+    parameters['verbose'] = [True, 'print progress and timings on rank 0']
+    parameters['output_directory'] = [None, 'prefix of every file written']
+    parameters['plot_label_suffix'] = ['', 'appended to plot titles and file names']
     return ParameterList(parameters)
 
 
 def KLEParameterList():
     """KLEProjector.py:30-45."""
     parameters = {}
-    parameters['error_test_samples'] = [50, 'Number of samples for error test']
-    parameters['rank'] = [128, 'Rank of subspace']
-    parameters['oversampling'] = [10, 'Oversampling parameter for randomized algorithms']
-    parameters['verbose'] = [True, 'Boolean for printing']
-    parameters['output_directory'] = ['./data/', 'output directory for saving arrays and plots']
-    parameters['plot_label_suffix'] = ['', 'suffix for plot label']
-    parameters['save_and_plot'] = [True, 'save and plot or not']
-    parameters['input_decoder_name'] = ['KLE_decoder', 'string for naming']
+    parameters['error_test_samples'] = [50, 'held-out prior draws used by the projection-error test']
+    parameters['rank'] = [128, 'r: Karhunen-Loeve modes kept']
+    parameters['oversampling'] = [10, 'p: extra probe vectors, the double pass works on r + p']
+    parameters['verbose'] = [True, 'print progress and timings on rank 0']
+    parameters['output_directory'] = ['./data/', 'prefix of every file written']
+    parameters['plot_label_suffix'] = ['', 'appended to plot titles and file names']
+    parameters['save_and_plot'] = [True, 'write the decoder, the eigenvalues and the spectrum plot']
+    parameters['input_decoder_name'] = ['KLE_decoder', 'file name of the decoder array (without .npy)']
     return ParameterList(parameters)
 
 

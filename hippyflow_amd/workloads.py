@@ -168,22 +168,135 @@ def grid_stiffness_matrix(nx, ny):
     return K.tocsr()
 
 
+def _lu_worker(conn, csc_parts, ml, x_name, y_name, N, kmax):
+    """One worker PROCESS of SparseLUPriorSolver: its own SuperLU factorisation of A, slabs through shared memory.
+    Started with the 'spawn' method (a fresh interpreter that never touches the GPU; nothing is forked from, or exec'ed
+    over, a process that has initialised HIP)."""
+    import numpy as _np
+    import scipy.sparse as _sp
+    import scipy.sparse.linalg as _spla
+    from multiprocessing import shared_memory as _shm
+    try:
+        from threadpoolctl import threadpool_limits as _limits
+        _ctx = _limits(limits=1)
+    except ImportError:
+        import contextlib
+        _ctx = contextlib.nullcontext()
+    data, indices, indptr = csc_parts
+    with _ctx:
+        lu = _spla.splu(_sp.csc_matrix((data, indices, indptr), shape=(N, N)))
+        xs, ys = _shm.SharedMemory(name=x_name), _shm.SharedMemory(name=y_name)
+        X = _np.ndarray((kmax, N), dtype=_np.float64, buffer=xs.buf)
+        Y = _np.ndarray((kmax, N), dtype=_np.float64, buffer=ys.buf)
+        conn.send("ready")
+        while True:
+            msg = conn.recv()
+            if msg is None:
+                break
+            r0, r1 = msg
+            try:
+                Z = lu.solve(X[r0:r1].T)             # (N, cnt) Fortran view of the slab's rows: no copy
+                Z *= ml[:, None]
+                Y[r0:r1] = lu.solve(_np.asfortranarray(Z)).T
+                conn.send(("ok", r0, r1))
+            except Exception as exc:                 # noqa: BLE001 -- reported to the parent, which raises
+                conn.send(("error", repr(exc)))
+        del X, Y
+        xs.close()
+        ys.close()
+    conn.close()
+
+
 class SparseLUPriorSolver:
     """``prior.Rsolver`` of a bi-Laplacian prior, R^-1 = A^-1 M_l A^-1, as a HOST black box: sparse LU of A (SuperLU)
     and two triangular-solve sweeps per vector.  ``solve(y, x)`` is the reference's solver protocol on 1-D arrays;
-    ``solve_block(X)`` serves (N, k) slabs (optionally spread over a thread pool)."""
+    ``solve_block(X)`` serves (N, k) slabs.
 
-    def __init__(self, A, M_lumped, threads=None):
+    ``processes > 1``: the vectors of a slab are dealt to a pool of worker processes, each holding its OWN factorisation;
+    the slabs travel through two shared-memory segments (vector-major, so a worker's share is a Fortran view, no copy).
+    SuperLU's triangular sweeps hold the GIL and do not scale over Python threads (74 vectors: 1.6 s on 1 thread, 6.3 s on
+    32, scripts/host_solver_probe.py) -- processes do.  The reference is in the same situation with one PETSc solve per
+    vector per MPI rank (activeSubspaceProjector.py:447-453)."""
+
+    def __init__(self, A, M_lumped, threads=None, processes=None):
         import scipy.sparse.linalg as spla
         self.N = A.shape[0]
-        self.lu = spla.splu(A.tocsc())
+        self._A = A.tocsc()
         self.Ml = np.asarray(M_lumped, dtype=np.float64)
-        # one thread by default: scipy's SuperLU solve does not scale over Python threads (measured on a 256-core host:
-        # 74 vectors take 1.6 s on 1 thread, 6.3 s on 32, scripts/host_solver_probe.py)
         self.threads = int(threads or 1)
+        self.processes = int(processes or 1)
+        self.lu = spla.splu(self._A) if self.processes <= 1 else None
         self._pool = None
+        self._workers = None
         self.calls, self.vectors = 0, 0
 
+    # ---- process pool -------------------------------------------------------------------
+    def _start_workers(self, kmax):
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        self.close()
+        ctx = mp.get_context("spawn")
+        nbytes = max(8, kmax * self.N * 8)
+        self._xs = shared_memory.SharedMemory(create=True, size=nbytes)
+        self._ys = shared_memory.SharedMemory(create=True, size=nbytes)
+        self._X = np.ndarray((kmax, self.N), dtype=np.float64, buffer=self._xs.buf)
+        self._Y = np.ndarray((kmax, self.N), dtype=np.float64, buffer=self._ys.buf)
+        self._kmax = kmax
+        parts = (self._A.data, self._A.indices, self._A.indptr)
+        self._workers = []
+        for _ in range(self.processes):
+            parent, child = ctx.Pipe()
+            pr = ctx.Process(target=_lu_worker, args=(child, parts, self.Ml, self._xs.name, self._ys.name, self.N, kmax), daemon=True)
+            pr.start()
+            child.close()
+            self._workers.append((pr, parent))
+        for pr, conn in self._workers:
+            if conn.recv() != "ready":
+                raise RuntimeError("SparseLUPriorSolver: a worker process did not start")
+
+    def close(self):
+        """Stop the worker processes and remove the shared-memory segments (they live in /dev/shm)."""
+        if self._workers:
+            for pr, conn in self._workers:
+                try:
+                    conn.send(None)
+                except (OSError, BrokenPipeError):
+                    pass
+            for pr, conn in self._workers:
+                pr.join(timeout=10)
+                if pr.is_alive():
+                    pr.terminate()          # exactly the processes started here
+                conn.close()
+            self._workers = None
+            self._X = self._Y = None
+            for seg in (self._xs, self._ys):
+                seg.close()
+                seg.unlink()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _solve_in_pool(self, X):
+        N, k = X.shape
+        if self._workers is None or k > self._kmax:
+            self._start_workers(max(k, 32))
+        self._X[:k] = X.T                            # vector-major slab
+        step = max(1, -(-k // self.processes))
+        busy = []
+        for w, r0 in enumerate(range(0, k, step)):
+            conn = self._workers[w][1]
+            conn.send((r0, min(k, r0 + step)))
+            busy.append(conn)
+        for conn in busy:
+            msg = conn.recv()
+            if msg[0] != "ok":
+                raise RuntimeError("SparseLUPriorSolver worker: %s" % msg[1])
+        return self._Y[:k].T.copy(order="F")
+
+    # ---- in-process -----------------------------------------------------------------------
     def _one(self, X):
         Z = self.lu.solve(np.asfortranarray(X))
         Z *= self.Ml[:, None]
@@ -203,6 +316,8 @@ class SparseLUPriorSolver:
         X = np.asarray(X)
         k = X.shape[1]
         self.calls, self.vectors = self.calls + 1, self.vectors + k
+        if self.processes > 1:
+            return self._solve_in_pool(X)
         with self._blas_serial():
             if self.threads <= 1 or k == 1:
                 return self._one(X)
@@ -214,6 +329,9 @@ class SparseLUPriorSolver:
         return np.concatenate(parts, axis=1)
 
     def solve(self, y, x):
+        if self.processes > 1:
+            y[...] = self._solve_in_pool(np.asarray(x).reshape(-1, 1))[:, 0]
+            return
         with self._blas_serial():
             y[...] = self._one(np.asarray(x).reshape(-1, 1))[:, 0]
 
@@ -223,7 +341,7 @@ class BiLaplacianPrior:
     precision R = A M_l^-1 A with A = delta M + gamma K on an nx x ny P1 grid, ``R`` as a sparse matrix (applied on the
     device as CSR), ``Rsolver`` a host sparse-LU black box, ``M`` the consistent mass matrix."""
 
-    def __init__(self, nx, ny, delta=1.0, gamma=0.1, threads=None):
+    def __init__(self, nx, ny, delta=1.0, gamma=0.1, threads=None, processes=None):
         import scipy.sparse as sp
         self.nx, self.ny, self.delta, self.gamma = nx, ny, delta, gamma
         self.M = grid_mass_matrix(nx, ny)
@@ -231,7 +349,7 @@ class BiLaplacianPrior:
         self.A = (delta * self.M + gamma * self.K).tocsr()
         self.M_lumped = np.asarray(self.M.sum(axis=1)).ravel()
         self.R = (self.A @ sp.diags(1.0 / self.M_lumped) @ self.A).tocsr()
-        self.Rsolver = SparseLUPriorSolver(self.A, self.M_lumped, threads=threads)
+        self.Rsolver = SparseLUPriorSolver(self.A, self.M_lumped, threads=threads, processes=processes)
 
     def init_vector(self, x, dim):
         x.init(self.R.shape[0])

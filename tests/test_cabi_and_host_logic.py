@@ -125,3 +125,25 @@ def test_build_tag_matches_the_sources():
     assert hf.build_tag() == _build.source_tag()          # the library in the tree was built from the sources in the tree
     tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert set(tr) >= {"build_tag", "source", "kernels"}
+
+
+def test_prior_solver_process_pool_equals_in_process_solver():
+    """The host R^-1 black box of the prior-preconditioned AS solve (prior.Rsolver, activeSubspaceProjector.py:447-453)
+    dealt to worker PROCESSES with their own factorisation (slabs through shared memory) gives the in-process result bit
+    for bit, and leaves nothing behind in /dev/shm."""
+    import os
+    from hippyflow_amd import workloads
+    before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    one = workloads.BiLaplacianPrior(40, 30)
+    pool = workloads.BiLaplacianPrior(40, 30, processes=3)
+    X = np.random.default_rng(0).standard_normal((1200, 7))
+    np.testing.assert_array_equal(pool.Rsolver.solve_block(X), one.Rsolver.solve_block(X))
+    np.testing.assert_array_equal(pool.Rsolver.solve_block(X[:, :2]), one.Rsolver.solve_block(X[:, :2]))     # fewer vectors than workers
+    y = np.zeros(1200)
+    pool.Rsolver.solve(y, X[:, 3])
+    np.testing.assert_array_equal(y, one.Rsolver.solve_block(X[:, 3:4])[:, 0])
+    big = np.random.default_rng(1).standard_normal((1200, 40))                                                # grows the segments
+    np.testing.assert_array_equal(pool.Rsolver.solve_block(big), one.Rsolver.solve_block(big))
+    pool.Rsolver.close()
+    if os.path.isdir("/dev/shm"):
+        assert set(os.listdir("/dev/shm")) <= before

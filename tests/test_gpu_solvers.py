@@ -857,6 +857,31 @@ def test_jtj_jjt_and_serially_sampled_operator(ctx, golden_dir):
     with pytest.raises(AssertionError):
         op.matMvMult(hf.MultiVector.from_dense(W), hf.MultiVector(13, 4))
 
+    # the reference re-draws a sample whose forward solve fails (activeSubspaceProjector.py:180-211): every third solve
+    # of this observable raises, the operator draws again and still averages len(Js) successful samples
+    class Flaky(Observable):
+        def solveFwd(self, u, lin):
+            self.solves += 1
+            if self.solves % 3 == 0:
+                raise RuntimeError("Newton did not converge")
+            self.i = (self.i + 1) % len(Jops)
+
+    flaky = Flaky()
+    op = hf.SeriallySampledJacobianOperator(flaky, noise, Prior(), operation="JTJ", nsamples=len(Js))
+    Yd = hf.MultiVector(13, 5)
+    op.matMvMult(hf.MultiVector.from_dense(W), Yd)
+    assert rel(Yd.to_dense(), np.mean([J.T @ (J @ W) for J in Js], axis=0)) < 1e-13
+    assert op.solver_failures == (flaky.solves // 3) and flaky.solves == len(Js) + op.solver_failures
+
+    class Broken(Observable):
+        def solveFwd(self, u, lin):
+            raise RuntimeError("mesh is inverted")
+
+    op = hf.SeriallySampledJacobianOperator(Broken(), noise, Prior(), operation="JTJ", nsamples=2)
+    op.max_solver_retries = 4
+    with pytest.raises(RuntimeError, match="5 consecutive draws"):
+        op.matMvMult(hf.MultiVector.from_dense(W), hf.MultiVector(13, 5))
+
 
 def test_state_space_identity_operator_and_reference_names(ctx):
     """StateSpaceIdentityOperator (fullStateObservable.py:18-52) and the reference's spelling of the dense wrapper."""
