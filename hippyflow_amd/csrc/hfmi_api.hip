@@ -144,6 +144,7 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   c->ingest_stream = nullptr;
   c->ingest_seq = 0;
+  c->late_pinned = nullptr;
   c->nn_hook = nullptr;
   c->nn_hook_user = nullptr;
   c->nn_hook_panels = 0;
@@ -172,6 +173,7 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_cb) (void)hipHostFree(ctx->pinned_cb);
+  if (ctx->late_pinned) (void)hipHostFree(ctx->late_pinned);
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_cb[i]);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_panel[i]);
   (void)hipEventDestroy(ctx->ev_join);
@@ -345,6 +347,12 @@ int ctx_tmp_block(hfmi_ctx* ctx, int idx, int64_t N, int nvec, hfmi_block** out)
     ctx->tmp_blocks[idx] = b;
   }
   *out = b;
+  return HFMI_OK;
+}
+
+static int ctx_late_pinned(hfmi_ctx* ctx, void** out) {
+  if (!ctx->late_pinned) HIP_TRY(hipHostMalloc(&ctx->late_pinned, 256 + (SM_LD + SM_MAXK) * sizeof(double), hipHostMallocDefault));
+  *out = ctx->late_pinned;
   return HFMI_OK;
 }
 
@@ -1159,7 +1167,19 @@ extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, in
 // deferred (optional): if non-null and B == null, the LAST pass (the one whose input is already orthonormal to 1e-2 and
 // needs no shift) does not apply its R^-1: *deferred = true and R^-1 stays in SM_RINV for the caller to fold into
 // the small matrices downstream (Q = Q_in R^-1 is never formed: one N x k x k contraction less).
-static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* passes_out, bool* deferred = nullptr) {
+// opt (optional, fused solves only): do not stop the stream for the decisions of the SECOND pass.  When the first pass needed no
+// shift, the second one is assumed to be the last (deferred R^-1, as above); its status words and the R_jj / ||z_j|| table are
+// copied to pinned memory in stream order and verified by the caller after the synchronisation it needs anyway for the
+// eigenvalues.  If the assumption was wrong the caller repeats the solve on the checked path.  (Two host round trips of ~60 us
+// each per solve: 1.4 % of the 64-sample shard step.)
+struct qr_late_checks {
+  bool used;
+  hfmi_status_words* st2;   // pinned
+  double* aux;              // pinned, SM_LD + k doubles
+  int k;
+};
+static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* passes_out, bool* deferred = nullptr,
+                   qr_late_checks* opt = nullptr) {
   hfmi_ctx* ctx = Q->ctx;
   const int64_t N = Q->N;
   const int k = Q->nvec;
@@ -1185,6 +1205,7 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
   const double pivot_tol = 0.0;   // launch_chol_inv default: 64 k eps
   int passes = 0;
   const int max_passes = 6;
+  bool first_pass_clean = false;
   for (;;) {
     const hfmi_block* right = Q;
     if (B) {
@@ -1195,6 +1216,16 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     const int rtot_mode = (passes == 0) ? 1 : 2;   // always track R = R_p ... R_1: its diagonal exposes dependent columns
     HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol));
     hfmi_status_words st;
+    if (deferred && !B && passes == 1 && opt && first_pass_clean) {
+      HIP_TRY(hipMemcpyAsync(opt->st2, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(opt->aux, sm_ptr(ctx, SM_AUX), ((size_t)SM_LD + k) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      opt->used = true;
+      opt->k = k;
+      ++passes;
+      *deferred = true;
+      if (passes_out) *passes_out = passes;
+      return HFMI_OK;                                    // the checks below are the caller's, after its own synchronisation
+    }
     if (deferred && !B && passes >= 1) {
       // candidate last pass: look at the status words first (the read-back is not hidden here) and stop WITHOUT
       // applying R^-1 if this pass would have been the last one anyway
@@ -1214,6 +1245,7 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
       HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
       HFMI_TRY(read_status_finish(ctx, &st));
       if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
+      if (passes == 0) first_pass_clean = !st.shifted;
     }
     ++passes;
     // The input of this pass had orthonormality defect st.gram_dev (column-scaled).  If it was already
@@ -1445,7 +1477,7 @@ static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T
 }
 
 static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* Omega, int r, int s, int flags,
-                            double* host_d, hfmi_block* U) {
+                            double* host_d, hfmi_block* U, bool late_checks = true) {
   if (!A || !Omega || !host_d || !U) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   hfmi_ctx* ctx = Omega->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1487,6 +1519,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   };
   HFMI_TRY(power_iterations());
   bool deferred = false;                                   // last Cholesky-QR pass left as R^-1 in SM_RINV
+  qr_late_checks late = {false, nullptr, nullptr, 0};
   hfmi_block* Qp = const_cast<hfmi_block*>(cur);           // holds the block to orthogonalise
   hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
   int ph = phase_begin(ctx, HFMI_PHASE_QR);
@@ -1497,7 +1530,13 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     // out to be numerically dependent, the block is recomputed from Omega (deterministic, every rank takes the same
     // branch) and handed to the reference's Gram-Schmidt rule
     const bool gram_path = op_has_gram_form(A) && !(flags & 4);
-    const int qs = qr_chol(Qp, B, nullptr, false, nullptr, gram_path ? &deferred : nullptr);
+    if (gram_path && late_checks && !B) {
+      void* pin = nullptr;
+      HFMI_TRY(ctx_late_pinned(ctx, &pin));
+      late.st2 = (hfmi_status_words*)pin;
+      late.aux = (double*)((char*)pin + 256);
+    }
+    const int qs = qr_chol(Qp, B, nullptr, false, nullptr, gram_path ? &deferred : nullptr, late.st2 ? &late : nullptr);
     if (qs == HFMI_ERR_NUMERIC) {
       deferred = false;
       HFMI_TRY(power_iterations());
@@ -1535,6 +1574,13 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   HFMI_TRY(read_back(ctx, (const double*)dv, r, host_d));
   const hfmi_status_words st = *ctx->status_host;
   print_status_dbg(&st);
+  if (late.used) {
+    // the second orthogonalisation pass was taken on trust: look at what it reported, now that the stream has drained
+    bool ok = !late.st2->failed && !late.st2->shifted && late.st2->gram_dev < 1e-2;
+    for (int j = 0; j < late.k && ok; ++j)
+      if (!(late.aux[SM_LD + j] > 100.0 * 2.220446049250313e-16 * late.aux[j])) ok = false;
+    if (!ok) return double_pass_impl(A, B, Binv, Omega, r, s, flags, host_d, U, false);   // the checked path decides (MGS fall-back, errors)
+  }
   if (st.failed) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "double_pass: small eigensolve did not converge (off-diagonal %.2e)", st.offdiag);
   return HFMI_OK;
 }

@@ -411,7 +411,7 @@ int launch_reduce_partials(hfmi_ctx* ctx, const double* part, int nsplit, int64_
 // hfmi_tuning_set at run time).
 //   waves: 8 = two waves per SIMD with <= 16 accumulator tiles each; 4 = one wave per SIMD with <= 32 tiles
 //   rem4 : compute a last column tile of <= 12 columns with 4x4x4 MFMAs (1, default) or as a full 16-column tile (0)
-static int g_waves = 0, g_rem4 = 1, g_probe = 0;
+static int g_waves = 0, g_rem4 = 1, g_probe = 0, g_tn_mt = 0;
 // where a launch writes: split partials (the reduce kernel sums them) or, for one split with nothing to scale, C itself
 struct TnOut {
   bool direct;
@@ -437,6 +437,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   else if (key && api_tuning_set(key, value)) {}
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
   else if (key && !strcmp(key, "probe")) g_probe = value;
+  else if (key && !strcmp(key, "tn_mt") && value >= 0 && value <= 8) g_tn_mt = value;   // A/B: wave tile height of tsgemm_tn (0 = automatic)
   else if (key && !strcmp(key, "ss_percu") && value >= 1 && value <= 4) tsgemm_ss_set_percu(value);
   else if (key && !strcmp(key, "ss_blocked") && (value == 0 || value == 1)) tsgemm_ss_set_blocked(value);
   else HFMI_FAIL(HFMI_ERR_INVALID, "tuning_set: unknown key/value");
@@ -517,6 +518,7 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   int mt = tn_mt_max(nt, small4 ? 8 : waves);
   const int need = (row_tiles + waves - 1) / waves;
   if (need < mt) mt = need;
+  if (g_tn_mt > 0 && g_tn_mt < mt) mt = g_tn_mt;
   if (mt == 7) mt = 6;
   if (mt < 1) mt = 1;
   const int rows_per_block = 16 * waves * mt;

@@ -104,6 +104,7 @@ struct hfmi_ctx {
   hipStream_t ingest_stream;
   hipEvent_t ev_ingest[HFMI_INGEST_RING];
   int64_t ingest_seq;
+  void* late_pinned;              // status words / R_jj table of an orthogonalisation pass taken on trust (hfmi_api.hip)
   void* pinned_cb;
   size_t pinned_cb_bytes;
   hipEvent_t ev_cb[4];            // D2H done x2, H2D done x2

@@ -546,23 +546,31 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_reg(const double* 
 // published through alternating LDS row buffers, one barrier per column, dead entries instead of masks, and the
 // inverse accumulated the same way bottom-up.
 // ------------------------------------------------------------------------------------------------
-template <int TR, int TC>
-__global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double* __restrict__ G, int ldg, int k,
+// NTHR = 512, MG = false: k <= 139, the factor in LDS.  NTHR = 1024, MG = true (round 3): 140 <= k <= 256, where k x k doubles
+// no longer fit the 160 KB of LDS: the tiles still live in registers (6 x 6 per thread at k = 256), only the copy of the
+// factor that the inverse reads column by column goes to an L2-resident global slot, and those reads do not depend on the
+// step's barrier, so they are issued one step ahead.  (The generic k_chol_inv with its FLAT accesses took 3.0 ms at k = 256.)
+template <int TR, int TC, int NTHR = CHOL_REG_THREADS, bool MG = false>
+__global__ __launch_bounds__(NTHR, NTHR == 1024 ? 1 : 2) void k_chol_tile(const double* __restrict__ G, int ldg, int k,
                                                                 double* __restrict__ Rout, double* __restrict__ Rinv,
                                                                 double* __restrict__ Rtot, double* __restrict__ Rtmp,
                                                                 int ldo, int rtot_mode, int full_r, double shift_rel,
                                                                 double pivot_tol, double* __restrict__ colnorm0,
                                                                 double* __restrict__ rdiag,
-                                                                hfmi_status_words* __restrict__ status) {
+                                                                hfmi_status_words* __restrict__ status,
+                                                                double* __restrict__ Mglob) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);       // 32 doubles of reduction scratch
   double* diag0 = red + 32;                            // k original diagonal entries
   double* invd = diag0 + 256;                          // 1 / R_jj
   double* rb0 = invd + 256;                            // published row, two alternating buffers
   double* rb1 = rb0 + 256;
-  double* M = rb1 + 256;                               // U, then R (upper triangle), row-major
-  const int ldm = k | 1;
-  constexpr int NT = CHOL_REG_THREADS;
+  // U, then R (upper triangle), row-major: in LDS, or (MG) in the global slot -- two differently typed names so that every
+  // access compiles to ds_* or global_* and never to FLAT
+  double* Ml = rb1 + 256;
+  const int ldm = MG ? ldo : (k | 1);
+  constexpr int NT = NTHR;
+#define CHOL_M(idx) (*(MG ? (Mglob + (idx)) : (Ml + (idx))))
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
   __shared__ int s_break;
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double*
               const int c = c0 + b;
               if (c >= j && c < k) {
                 rb[c] = v[a][b];
-                M[j * ldm + c] = v[a][b];
+                CHOL_M(j * ldm + c) = v[a][b];
               }
             }
           }
@@ -717,18 +725,24 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double*
   // R = diag(U)^{-1/2} U
   for (int i = wave; i < k; i += nw) {
     const double sc = invd[i];
-    for (int j = i + lane; j < k; j += 64) M[i * ldm + j] *= sc;
+    for (int j = i + lane; j < k; j += 64) CHOL_M(i * ldm + j) *= sc;
   }
   for (int i = tid; i < 512; i += NT) rb0[i] = 0.0;  // the inverse relies on zeros left of the published row
   __syncthreads();
   tk2 = clock64();
   for (int i = wave; i < k; i += nw)
-    for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+    for (int j = lane; j < k; j += 64) Rout[i * ldo + j] = (j >= i) ? CHOL_M(i * ldm + j) : 0.0;
   // Inverse X = R^-1, right-looking and bottom-up (see k_chol_reg)
 #pragma unroll
   for (int a = 0; a < TR; ++a)
 #pragma unroll
     for (int b = 0; b < TC; ++b) v[a][b] = 0.0;
+  double xan[TR];                                        // column l of R at this tile's rows, fetched one step ahead
+#pragma unroll
+  for (int a = 0; a < TR; ++a) {
+    const int r = r0 + a < k ? r0 + a : k - 1;
+    xan[a] = CHOL_M(r * ldm + (k - 1));
+  }
   for (int l = k - 1; l >= 0; --l) {
     double* xr = (l & 1) ? rb1 : rb0;
     const double il = invd[l];
@@ -748,13 +762,15 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double*
         }
     }
     __syncthreads();
-    if (own && r0 < l) {                                   // the tile still holds rows above row l
-      double xa[TR], xb[TC];
+    double xa[TR];
 #pragma unroll
-      for (int a = 0; a < TR; ++a) {
-        const int r = r0 + a < k ? r0 + a : k - 1;
-        xa[a] = M[r * ldm + l];
-      }
+    for (int a = 0; a < TR; ++a) {
+      xa[a] = xan[a];
+      const int r = r0 + a < k ? r0 + a : k - 1;
+      xan[a] = CHOL_M(r * ldm + (l > 0 ? l - 1 : 0));     // R is final: this read does not wait for the next barrier
+    }
+    if (own && r0 < l) {                                   // the tile still holds rows above row l
+      double xb[TC];
 #pragma unroll
       for (int b = 0; b < TC; ++b) xb[b] = xr[c0 + b];
 #pragma unroll
@@ -767,17 +783,17 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double*
   tk3 = clock64();
   for (int i = wave; i < k; i += nw)
     for (int j = lane; j < i; j += 64) Rinv[i * ldo + j] = 0.0;
-  for (int i = tid; i < k; i += NT) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * M[i * ldm + i];
+  for (int i = tid; i < k; i += NT) rdiag[i] = (rtot_mode == 1 ? 1.0 : rdiag[i]) * CHOL_M(i * ldm + i);
   if (full_r) {
     if (rtot_mode == 1) {
       for (int i = wave; i < k; i += nw)
-        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = (j >= i) ? M[i * ldm + j] : 0.0;
+        for (int j = lane; j < k; j += 64) Rtot[i * ldo + j] = (j >= i) ? CHOL_M(i * ldm + j) : 0.0;
     } else {
       for (int i = wave; i < k; i += nw)
         for (int j = lane; j < k; j += 64) {
           double acc = 0.0;
           if (j >= i)
-            for (int l = i; l <= j; ++l) acc += M[i * ldm + l] * Rtot[l * ldo + j];
+            for (int l = i; l <= j; ++l) acc += CHOL_M(i * ldm + l) * Rtot[l * ldo + j];
           Rtmp[i * ldo + j] = acc;
         }
       __syncthreads();
@@ -798,6 +814,7 @@ __global__ __launch_bounds__(CHOL_REG_THREADS, 2) void k_chol_tile(const double*
     status->tick[4] = 0;
   }
 }
+#undef CHOL_M
 
 static int chol_tiles(int k, int trr, int tcc) {
   const int ntr = (k + trr - 1) / trr, ntc = (k + tcc - 1) / tcc;
@@ -837,7 +854,7 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
     hipLaunchKernelGGL((k_chol_tile<A, B>), dim3(1), dim3(CHOL_REG_THREADS), shm, ctx->stream, sm_ptr(ctx, slot_gram),  \
                        SM_LD, k, sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot),                   \
                        sm_ptr(ctx, SM_TMP2), SM_LD, rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_AUX),       \
-                       sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev);                                                   \
+                       sm_ptr(ctx, SM_AUX) + SM_LD, ctx->status_dev, (double*)nullptr);                                 \
   } while (0)
     // smallest rectangle whose tiles fit the 512 threads
     if (use_tile && k >= 8) {
@@ -859,6 +876,21 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
     else CHOL_REG(20);
 #undef CHOL_REG
 #undef CHOL_TILE
+  } else if (!use_lds && !chol_generic) {
+    // 140 <= k <= 256: tiles in the registers of 1024 threads, the factor's copy in the global slot SM_TMP
+    const size_t shmb = (32 + 4 * 256) * sizeof(double);
+#define CHOL_BIG(A, B)                                                                                                    \
+  hipLaunchKernelGGL((k_chol_tile<A, B, 1024, true>), dim3(1), dim3(1024), shmb, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k, \
+                     sm_ptr(ctx, slot_r), sm_ptr(ctx, slot_rinv), sm_ptr(ctx, slot_rtot), sm_ptr(ctx, SM_TMP2), SM_LD,   \
+                     rtot_mode, full_r, shift_rel, pivot_tol, sm_ptr(ctx, SM_AUX), sm_ptr(ctx, SM_AUX) + SM_LD,          \
+                     ctx->status_dev, sm_ptr(ctx, SM_TMP))
+    auto tiles1024 = [&](int a, int b) { return chol_tiles(k, a, b) <= 1024; };
+    if (tiles1024(4, 4)) CHOL_BIG(4, 4);
+    else if (tiles1024(4, 5)) CHOL_BIG(4, 5);
+    else if (tiles1024(5, 5)) CHOL_BIG(5, 5);
+    else if (tiles1024(5, 6)) CHOL_BIG(5, 6);
+    else CHOL_BIG(6, 6);
+#undef CHOL_BIG
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(small_threads()), shmem, ctx->stream, sm_ptr(ctx, slot_gram), SM_LD, k,
