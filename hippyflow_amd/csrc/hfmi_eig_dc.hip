@@ -566,7 +566,79 @@ __global__ __launch_bounds__(DC_THREADS) void k_dc(dc_args p) {
 
   double* __restrict__ Qin = p.Q;
   double* __restrict__ Qout = p.Qt;
-  for (int L = p.levels - 1; L >= 0; --L) {
+  int Ltop = p.levels - 1;
+  // The deepest level only merges 1 x 1 leaves into 2 x 2 blocks: [[d_i, e_i], [e_i, d_i+1]] has its eigen-decomposition in
+  // closed form (the arithmetic of LAPACK's dlaev2), one thread per block -- a whole level of the machinery below (about a
+  // seventh of this kernel at k = 74) for a few dozen operations.  It works on the untorn diagonal of the pair.
+  if (p.levels >= 1) {
+    const int L = p.levels - 1;
+    if (tid < n) {
+      int node, lo, mid, hi;
+      dc_node(n, L, tid, node, lo, mid, hi);
+      if (hi - lo == 2 && tid == lo) {
+        const double e = p.evec[lo];
+        const double a = sD[lo] + fabs(e), c = sD[lo + 1] + fabs(e), b = e;     // give the pair its own coupling back
+        const double sm = a + c, df = a - c, adf = fabs(df), tb = b + b, ab = fabs(tb);
+        const double acmx = fabs(a) > fabs(c) ? a : c, acmn = fabs(a) > fabs(c) ? c : a;
+        double rt;
+        if (adf > ab) rt = adf * sqrt(1.0 + (ab / adf) * (ab / adf));
+        else if (adf < ab) rt = ab * sqrt(1.0 + (adf / ab) * (adf / ab));
+        else rt = ab * 1.4142135623730951;
+        double rt1, rt2;
+        int sgn1;
+        if (sm < 0.0) {
+          rt1 = 0.5 * (sm - rt);
+          sgn1 = -1;
+          rt2 = (acmx / rt1) * acmn - (b / rt1) * b;
+        } else if (sm > 0.0) {
+          rt1 = 0.5 * (sm + rt);
+          sgn1 = 1;
+          rt2 = (acmx / rt1) * acmn - (b / rt1) * b;
+        } else {
+          rt1 = 0.5 * rt;
+          rt2 = -0.5 * rt;
+          sgn1 = 1;
+        }
+        int sgn2;
+        double cs;
+        if (df >= 0.0) {
+          cs = df + rt;
+          sgn2 = 1;
+        } else {
+          cs = df - rt;
+          sgn2 = -1;
+        }
+        double cs1, sn1;
+        if (fabs(cs) > ab) {
+          const double ct = -tb / cs;
+          sn1 = 1.0 / sqrt(1.0 + ct * ct);
+          cs1 = ct * sn1;
+        } else if (ab == 0.0) {
+          cs1 = 1.0;
+          sn1 = 0.0;
+        } else {
+          const double tn = -cs / tb;
+          cs1 = 1.0 / sqrt(1.0 + tn * tn);
+          sn1 = tn * cs1;
+        }
+        if (sgn1 == sgn2) {
+          const double tn = cs1;
+          cs1 = -sn1;
+          sn1 = tn;
+        }
+        // (cs1, sn1) is the unit eigenvector of rt1, (-sn1, cs1) that of rt2
+        sD[lo] = rt1;
+        sD[lo + 1] = rt2;
+        Qin[(size_t)lo * ldq + lo] = cs1;
+        Qin[(size_t)lo * ldq + lo + 1] = sn1;
+        Qin[(size_t)(lo + 1) * ldq + lo] = -sn1;
+        Qin[(size_t)(lo + 1) * ldq + lo + 1] = cs1;
+      }
+    }
+    __syncthreads();
+    Ltop = p.levels - 2;
+  }
+  for (int L = Ltop; L >= 0; --L) {
     int node = 0, lo = 0, mid = 0, hi = 0;
     bool active = false;
     if (tid < n) {
@@ -939,38 +1011,46 @@ __global__ __launch_bounds__(64) void k_dc_back(const double* __restrict__ Q, in
   const int l = threadIdx.x, g = l >> 4, m = l & 15;
   const int col = blockIdx.x * 4 + g;
   const bool live = col < n;
-  double z[EL], v[EL], vn[EL];
+  double z[EL];
 #pragma unroll
   for (int e = 0; e < EL; ++e) {
     const int r = m + 16 * e;
     z[e] = (live && r < n) ? Q[(size_t)col * ldq + r] : 0.0;
   }
-  int j = n - 3;
-  if (j >= 0) {
+  // The reflector rows come from L2 (1-2 us away) and one reflector takes ~0.15 us to apply: a ring of PF rows is kept in
+  // flight (one row ahead, as first written, the loop waited for memory three quarters of the time: 58 us at k = 138).
+  constexpr int PF = EL <= 9 ? 8 : (EL <= 12 ? 6 : 4);       // as deep as the registers of a one-wave workgroup allow
+  double vb[PF][EL], tb[PF];
+  auto fetch = [&](double (&dst)[EL], double& tdst, int j) {
+    const int jj = j >= 0 ? j : 0;                       // past the end: re-read row 0 (never used)
+    tdst = tauv[jj];
 #pragma unroll
     for (int e = 0; e < EL; ++e) {
       const int r = m + 16 * e;
-      vn[e] = (r < ldv) ? Vh[(size_t)j * ldv + r] : 0.0;
+      dst[e] = (r < ldv) ? Vh[(size_t)jj * ldv + r] : 0.0;
     }
-  }
-  for (; j >= 0; --j) {
+  };
+  int j = n - 3;
 #pragma unroll
-    for (int e = 0; e < EL; ++e) v[e] = vn[e];
-    if (j > 0) {
+  for (int u = 0; u < PF; ++u) fetch(vb[u], tb[u], j - u);
+  for (; j >= 0; j -= PF) {
 #pragma unroll
-      for (int e = 0; e < EL; ++e) {
-        const int r = m + 16 * e;
-        vn[e] = (r < ldv) ? Vh[(size_t)(j - 1) * ldv + r] : 0.0;
+    for (int u = 0; u < PF; ++u) {
+      const int jr = j - u;
+      if (jr >= 0) {                                     // uniform
+        const double tau = tb[u];
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int e = 0; e < EL; e += 2) {
+          d0 = fma(vb[u][e], z[e], d0);
+          if (e + 1 < EL) d1 = fma(vb[u][e + 1], z[e + 1], d1);
+        }
+        const double f = -tau * group_sum<16>(d0 + d1);
+#pragma unroll
+        for (int e = 0; e < EL; ++e) z[e] = fma(f, vb[u][e], z[e]);
       }
+      fetch(vb[u], tb[u], jr - PF);
     }
-    const double tau = tauv[j];
-    double dot = 0.0;
-#pragma unroll
-    for (int e = 0; e < EL; ++e) dot = fma(v[e], z[e], dot);
-    dot = group_sum<16>(dot);
-    const double f = -tau * dot;
-#pragma unroll
-    for (int e = 0; e < EL; ++e) z[e] = fma(f, v[e], z[e]);
   }
   if (live) {
     const int pc = perm[col];
@@ -1061,16 +1141,19 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
   else hipLaunchKernelGGL((k_dc<4>), dim3(1), dim3(DC_THREADS), 0, ctx->stream, a);
   HIP_TRY(hipGetLastError());
   if (a.split_top) {
-    // level 0 is the last of `levels` merges: its input is the buffer after levels - 1 swaps
-    const double* Qin0 = ((a.levels - 1) & 1) ? Qt : Qm;
-    double* Qout0 = ((a.levels - 1) & 1) ? Qm : Qt;
+    // level 0 is the last of the ping-pong merges (levels - 1 of them: the deepest level works in place): its input is the
+    // buffer after levels - 2 swaps
+    const int before = a.levels >= 2 ? a.levels - 2 : 0;
+    const double* Qin0 = (before & 1) ? Qt : Qm;
+    double* Qout0 = (before & 1) ? Qm : Qt;
     const int T = (k + 15) / 16;
     hipLaunchKernelGGL(k_dc_top, dim3(T * T + 16), dim3(64), 0, ctx->stream, Qin0, Qout0, Sm, ldq, k, top_meta);
     HIP_TRY(hipGetLastError());
   }
   double* Vout = sm_ptr(ctx, slot_v);
   const int blocks = (k + 3) / 4;
-  const double* Qfin = (a.levels & 1) ? Qt : Qm;     // the merges ping-pong between the two buffers, one swap per level
+  const int swaps = a.levels >= 1 ? a.levels - 1 : 0;  // the deepest level is solved in place (2 x 2 blocks in closed form)
+  const double* Qfin = (swaps & 1) ? Qt : Qm;          // the other merges ping-pong between the two buffers
 #define BACK(ELV) \
   hipLaunchKernelGGL((k_dc_back<ELV>), dim3(blocks), dim3(64), 0, ctx->stream, Qfin, ldq, k, Vh, ldq, tauv, perm, Vout, SM_LD)
   if (k <= 80) BACK(5);

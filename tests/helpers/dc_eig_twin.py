@@ -228,6 +228,48 @@ def merge(D, Q, lo, mid, hi, beta, stats=None):
     D[lo:hi] = d
 
 
+def pair_2x2(D, Q, lo, e):
+    """[[a, e], [e, c]] in closed form (the arithmetic of LAPACK's dlaev2); a, c = the pair's diagonal with its own coupling
+    given back (the tearing took |e| off both)."""
+    a, c, b = D[lo] + abs(e), D[lo + 1] + abs(e), e
+    sm, df = a + c, a - c
+    adf, tb = abs(df), b + b
+    ab = abs(tb)
+    acmx, acmn = (a, c) if abs(a) > abs(c) else (c, a)
+    if adf > ab:
+        rt = adf * np.sqrt(1.0 + (ab / adf) ** 2)
+    elif adf < ab:
+        rt = ab * np.sqrt(1.0 + (adf / ab) ** 2)
+    else:
+        rt = ab * np.sqrt(2.0)
+    if sm < 0.0:
+        rt1, sgn1 = 0.5 * (sm - rt), -1
+        rt2 = (acmx / rt1) * acmn - (b / rt1) * b
+    elif sm > 0.0:
+        rt1, sgn1 = 0.5 * (sm + rt), 1
+        rt2 = (acmx / rt1) * acmn - (b / rt1) * b
+    else:
+        rt1, rt2, sgn1 = 0.5 * rt, -0.5 * rt, 1
+    if df >= 0.0:
+        cs, sgn2 = df + rt, 1
+    else:
+        cs, sgn2 = df - rt, -1
+    if abs(cs) > ab:
+        ct = -tb / cs
+        sn1 = 1.0 / np.sqrt(1.0 + ct * ct)
+        cs1 = ct * sn1
+    elif ab == 0.0:
+        cs1, sn1 = 1.0, 0.0
+    else:
+        tn = -cs / tb
+        cs1 = 1.0 / np.sqrt(1.0 + tn * tn)
+        sn1 = tn * cs1
+    if sgn1 == sgn2:
+        cs1, sn1 = -sn1, cs1
+    D[lo], D[lo + 1] = rt1, rt2
+    Q[lo:lo + 2, lo:lo + 2] = [[cs1, -sn1], [sn1, cs1]]
+
+
 def dc_tridiagonal(d, e, stats=None):
     """Eigen-decomposition of tridiag(d, e) by divide and conquer down to 1 x 1 leaves.  Returns (lam, Z) unsorted."""
     n = len(d)
@@ -249,7 +291,11 @@ def dc_tridiagonal(d, e, stats=None):
             if hi - lo >= 2:
                 mid = ((2 * i + 1) * n) >> (L + 1)
                 assert lo < mid < hi
-                merge(D, Q, lo, mid, hi, e[mid - 1], stats)
+                if L == levels - 1:
+                    assert hi - lo == 2              # the deepest level only pairs up 1 x 1 leaves: closed form
+                    pair_2x2(D, Q, lo, e[lo])
+                else:
+                    merge(D, Q, lo, mid, hi, e[mid - 1], stats)
     return D, Q
 
 
