@@ -526,7 +526,21 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
       msplit = 1;
     } else {
       const int stages = (m + NN_KC - 1) / NN_KC;
-      int ms = cus / tail;                                  // one round of CUs for the tail
+      // split the tail tiles ms ways so that their pieces fill whole rounds of CUs: the tail then costs
+      // ceil(tail ms / cus) / ms of a round instead of a whole one (config 3: 162 tail tiles, ms = 3 -> 486 pieces = 2 rounds
+      // of a third each = 0.67 of a round; unsplit it was the 8th round of 7.63).  A few tail tiles: one round of short pieces.
+      int ms = cus / tail;
+      if (ms < 2) {
+        double best = 1.0;
+        ms = 1;
+        for (int c = 2; c <= 8; ++c) {
+          const double cost = (double)((tail * c + cus - 1) / cus) / c + 0.01 * c;     // + the partials' round trip
+          if (cost < best - 1e-9) {
+            best = cost;
+            ms = c;
+          }
+        }
+      }
       if (ms > stages / 4) ms = stages / 4;                 // at least four LDS stages per workgroup
       if (ms < 1) ms = 1;
       msplit = ms;
