@@ -123,17 +123,28 @@ __device__ __forceinline__ double dc_rcp(double x) {
 //       its other rows                                                                                             | barrier |
 // Rows are processed in chunks of four with ONE wave-uniform test per chunk (finished chunks are skipped, so the work per column
 // shrinks with the trailing block; a test per row costs two taken branches, more than the row's arithmetic).
-template <int RI, int CJ, int NW>
+// LR > 0 (192 < k <= 256): 64 k^2 doubles do not fit the registers of one compute unit (it has 64 K of them), so the LAST LR rows
+// live in LDS (row r on wave r mod NW as well, 128 KB for LR = 64) and are multiplied / updated from there; the per-row values
+// v[r], w[r] are then read where they are used instead of being held (registers), and w[r] comes from a lane read (LDS is full).
+template <int RI, int CJ, int NW, int LR = 0>
 __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ T, int ldt, int n, double* __restrict__ dvec,
                                                     double* __restrict__ evec, double* __restrict__ Vh, int ldv,
                                                     double* __restrict__ tauv, int* __restrict__ sexp_out,
                                                     long long* __restrict__ ticks) {
   static_assert(RI % 4 == 0, "rows per wave come in chunks of four");
-  static_assert(RI * NW <= 64 * CJ, "row indices must fit the column groups");
+  static_assert(RI * NW + LR <= 64 * CJ, "row indices must fit the column groups");
+  static_assert(LR % NW == 0, "LDS rows are dealt to the waves like the register rows");
   constexpr int NCH = RI / 4;
-  __shared__ double s_v[DC_MAXN];
+  constexpr int RREG = RI * NW;                 // rows [0, RREG) in registers, [RREG, RREG + LR) in LDS
+  constexpr int LI = LR / NW;                   // LDS rows per wave
+  constexpr bool PRE = (LR == 0);               // per-row v / w values preloaded into registers
+  constexpr int LSTR = 64 * CJ;                 // LDS row stride
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [LR][LSTR] when LR > 0
+  // v_j: one buffer when every wave copies what it needs into registers before the barrier (PRE); two alternating ones when
+  // v[r] is read during the update, which overlaps the owner's writing of v_j+1
+  __shared__ double s_v2[PRE ? 1 : 2][DC_MAXN];
   __shared__ double s_part[NW][DC_MAXN];
-  __shared__ double s_w[NW][DC_MAXN];
+  __shared__ double s_w[PRE ? NW : 1][PRE ? DC_MAXN : 1];
   __shared__ double s_tau;
   __shared__ double s_red[NW];
   const int tid = threadIdx.x, l = tid & 63;
@@ -152,6 +163,18 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
       amax = fmax(amax, fabs(a));
     }
   }
+#pragma unroll
+  for (int i2 = 0; i2 < LI; ++i2) {
+    const int r = RREG + w + NW * i2;
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) {
+      const int c = l + 64 * jj;
+      double a = 0.0;
+      if (r < n && c < n) a = 0.5 * (T[(size_t)r * ldt + c] + T[(size_t)c * ldt + r]);
+      s_dyn[(r - RREG) * LSTR + c] = a;
+      amax = fmax(amax, fabs(a));
+    }
+  }
   // power-of-two scaling to max |entry| in [1, 2): norms cannot overflow / underflow, eigenvalues scale back exactly
   amax = wave_max(amax);
   if (l == 0) s_red[w] = amax;
@@ -165,6 +188,10 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
   for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int jj = 0; jj < CJ; ++jj) A[i][jj] *= sc;
+#pragma unroll
+  for (int i2 = 0; i2 < LI; ++i2)
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) s_dyn[(w + NW * i2) * LSTR + l + 64 * jj] *= sc;      // this wave's own rows
   if (tid == 0) *sexp_out = sexp;
 
   // reflector j from x = A[j][.] (the owner wave's copy of row j): -> s_v, s_tau now; Vh, tau, e[j], d[j] go to global memory
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
     for (int jj = 0; jj < CJ; ++jj) {
       const int c = l + 64 * jj;
       const double v = (c == j + 1) ? 1.0 : ((c > j + 1 && c < n) ? x[jj] * scl : 0.0);
-      s_v[c] = v;
+      s_v2[PRE ? 0 : (j & 1)][c] = v;
       pend_v[jj] = v;
     }
     if (l == 0) s_tau = tau;
@@ -224,6 +251,11 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
   auto pick_row = [&](int ch, int rsel, double (&x)[CJ]) {
 #pragma unroll
     for (int jj = 0; jj < CJ; ++jj) x[jj] = 0.0;
+    if (LR > 0 && rsel >= RREG) {
+#pragma unroll
+      for (int jj = 0; jj < CJ; ++jj) x[jj] = s_dyn[(rsel - RREG) * LSTR + l + 64 * jj];
+      return;
+    }
 #pragma unroll
     for (int c4 = 0; c4 < NCH; ++c4) {
       if (c4 == ch) {
@@ -250,17 +282,21 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
   TRI_TICK_DECL;
   for (int j = 0; j + 2 < n; ++j) {
     const double tau = s_tau;
+    const double* s_v = s_v2[PRE ? 0 : (j & 1)];
     const bool next_mine = (j + 3 < n) && (w == ((j + 1) & (NW - 1)));
-    const int chn = ((j + 1) / NW) >> 2;       // chunk of row j + 1 on its owner
+    const bool next_lds = LR > 0 && j + 1 >= RREG;             // row j + 1 lives in LDS
+    const int chn = ((j + 1) / NW) >> 2;       // chunk of row j + 1 on its owner (register rows)
     double vc[CJ];
 #pragma unroll
     for (int jj = 0; jj < CJ; ++jj) vc[jj] = s_v[l + 64 * jj];
     if (tau != 0.0) {   // uniform over the workgroup
       // (b) this wave's slice of A v.  v[r] of the wave's rows: wave-uniform LDS reads, all issued up front (a lane read of vc
       // costs 40 cycles a row in dependent hazards); finished rows inside a live chunk multiply by v[r] = 0.
-      double vr[RI];
+      double vr[PRE ? RI : 1];
+      if constexpr (PRE) {
 #pragma unroll
-      for (int i = 0; i < RI; ++i) vr[i] = s_v[w + NW * i];
+        for (int i = 0; i < RI; ++i) vr[i] = s_v[w + NW * i];
+      }
       flush_pending();
       {
         double acc[CJ][2];
@@ -270,12 +306,28 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
         for (int ch = 0; ch < NCH; ++ch) {
           if (w + NW * (4 * ch + 3) > j) {
             asm volatile("");
+            double v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if constexpr (PRE) v4[u] = vr[4 * ch + u];
+              else v4[u] = s_v[w + NW * (4 * ch + u)];
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int i = 4 * ch + u;
 #pragma unroll
-              for (int jj = 0; jj < CJ; ++jj) acc[jj][u & 1] = fma(A[i][jj], vr[i], acc[jj][u & 1]);
+              for (int jj = 0; jj < CJ; ++jj) acc[jj][u & 1] = fma(A[i][jj], v4[u], acc[jj][u & 1]);
             }
+          }
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < LI; ++i2) {
+          const int r = RREG + w + NW * i2;
+          if (r > j) {
+            asm volatile("");
+            const double vri = s_v[r];
+#pragma unroll
+            for (int jj = 0; jj < CJ; ++jj) acc[jj][i2 & 1] = fma(s_dyn[(r - RREG) * LSTR + l + 64 * jj], vri, acc[jj][i2 & 1]);
           }
         }
 #pragma unroll
@@ -304,37 +356,78 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
 #pragma unroll
         for (int jj = 0; jj < CJ; ++jj) {
           wc[jj] = fma(-kk, vc[jj], pc[jj]);
-          s_w[w][l + 64 * jj] = wc[jj];
+          if constexpr (PRE) s_w[w][l + 64 * jj] = wc[jj];
         }
       }
-      double wr[RI];
+      double wr[PRE ? RI : 1];
+      if constexpr (PRE) {
 #pragma unroll
-      for (int i = 0; i < RI; ++i) wr[i] = s_w[w][w + NW * i];
+        for (int i = 0; i < RI; ++i) wr[i] = s_w[w][w + NW * i];
+      }
       TRI_TICK(tk1);
       auto update_chunk = [&](int ch) {
+        double v4[4], w4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 4 * ch + u;
+          if constexpr (PRE) {
+            v4[u] = vr[i];
+            w4[u] = wr[i];
+          } else {
+            v4[u] = s_v[w + NW * i];
+            w4[u] = lane_get(wc[(NW * i) / 64], (w + NW * i) & 63);
+          }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = 4 * ch + u;
 #pragma unroll
-          for (int jj = 0; jj < CJ; ++jj) A[i][jj] = fma(-wr[i], vc[jj], fma(-vr[i], wc[jj], A[i][jj]));
+          for (int jj = 0; jj < CJ; ++jj) A[i][jj] = fma(-w4[u], vc[jj], fma(-v4[u], wc[jj], A[i][jj]));
         }
       };
-      if (next_mine) {     // the chunk with row j + 1 first, then the next reflector, then the rest
+      auto update_lds_row = [&](int i2) {
+        const int r = RREG + w + NW * i2;
+        const double vri = s_v[r];
+        const double wri = lane_get(wc[((RREG + NW * i2) / 64) < CJ ? (RREG + NW * i2) / 64 : 0], r & 63);
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-          if (ch == chn) {
-            asm volatile("");
-            update_chunk(ch);
-          }
+        for (int jj = 0; jj < CJ; ++jj) {
+          double* a = &s_dyn[(r - RREG) * LSTR + l + 64 * jj];
+          *a = fma(-wri, vc[jj], fma(-vri, wc[jj], *a));
+        }
+      };
+      if (next_mine) {     // the chunk (or LDS row) with row j + 1 first, then the next reflector, then the rest
+        if (next_lds) {
+#pragma unroll
+          for (int i2 = 0; i2 < LI; ++i2)
+            if (RREG + w + NW * i2 == j + 1) {
+              asm volatile("");
+              update_lds_row(i2);
+            }
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+            if (ch == chn) {
+              asm volatile("");
+              update_chunk(ch);
+            }
+        }
         double x[CJ];
         pick_row(chn, j + 1, x);
         form_reflector(j + 1, x);
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        if (w + NW * (4 * ch + 3) > j && !(next_mine && ch == chn)) {
+        if (w + NW * (4 * ch + 3) > j && !(next_mine && !next_lds && ch == chn)) {
           asm volatile("");
           update_chunk(ch);
+        }
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < LI; ++i2) {
+        const int r = RREG + w + NW * i2;
+        if (r > j && !(next_mine && r == j + 1)) {
+          asm volatile("");
+          update_lds_row(i2);
         }
       }
     } else {
@@ -361,6 +454,19 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
       if (r < n && r + 2 >= n) {
         if (c == r) dvec[r] = A[i][jj];
         if (r + 2 == n && c == r + 1) evec[r] = A[i][jj];
+      }
+    }
+  }
+#pragma unroll
+  for (int i2 = 0; i2 < LI; ++i2) {
+    const int r = RREG + w + NW * i2;
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj) {
+      const int c = l + 64 * jj;
+      if (r < n && r + 2 >= n) {
+        const double a = s_dyn[(r - RREG) * LSTR + c];
+        if (c == r) dvec[r] = a;
+        if (r + 2 == n && c == r + 1) evec[r] = a;
       }
     }
   }
@@ -1110,7 +1216,13 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
     else if (k <= 128) TRI(16, 2, 8);
     else if (k <= 160) TRI(20, 3, 8);
     else if (k <= 192) TRI(24, 3, 8);
-    else TRI(32, 4, 8);
+    else {
+      // 192 < k <= 256: rows 0..191 in registers, rows 192..255 in 128 KB of LDS
+      auto kern = k_tridiag<24, 4, 8, 64>;
+      const size_t shm = (size_t)64 * 256 * sizeof(double);
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      hipLaunchKernelGGL(kern, dim3(1), dim3(512), shm, ctx->stream, T, SM_LD, k, dvec, evec, Vh, ldq, tauv, sexp, ticks);
+    }
   }
 #undef TRI
   HIP_TRY(hipGetLastError());
