@@ -439,7 +439,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   else if (key && !strcmp(key, "probe")) g_probe = value;
   else if (key && !strcmp(key, "tn_mt") && value >= 0 && value <= 8) g_tn_mt = value;   // A/B: wave tile height of tsgemm_tn (0 = automatic)
   else if (key && !strcmp(key, "ss_percu") && value >= 1 && value <= 4) tsgemm_ss_set_percu(value);
-  else if (key && !strcmp(key, "ss_blocked") && (value == 0 || value == 1)) tsgemm_ss_set_blocked(value);
+  else if (key && !strcmp(key, "ss_blocked") && value >= 0 && value <= 2) tsgemm_ss_set_blocked(value);
   else HFMI_FAIL(HFMI_ERR_INVALID, "tuning_set: unknown key/value");
   return HFMI_OK;
 }

@@ -327,9 +327,64 @@ __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* 
   }
 }
 
+// Software-pipelined form of ssb_stage (round 3): the stage's barrier sits between the third and the fourth group of eight
+// reduction indices instead of after the fourth.  The next stage's LDS image is complete by then (its stores moved to the
+// first two groups), so the fragments of the NEXT stage's first group are fetched under the MFMAs of this stage's last
+// group, and a stage no longer begins with every wave waiting for its first ds_read_b128s (PMC: the n = 64 ... 138 shapes
+// kept the MFMA pipe 75-78 % busy at full clock, i.e. stalled, not power-limited).  fa / fb / ea / eb slot 0 hold the first
+// group's fragments on entry and the next stage's on exit.  Reads of the current buffer issued before the barrier are ahead
+// of any later store to it in the LDS queue, so the buffer can be refilled by the stage after next without another barrier.
+template <int RB, int CB, int EN, int NQ>
+__device__ __forceinline__ void ssb_stage_pipe(const double* __restrict__ L, double* __restrict__ Lnext, const int la, const int la1,
+                                               const int (&toa)[RB], const int (&tob)[CB], const int (&etoa)[EN > 0 ? EN : 1],
+                                               const int (&etob)[EN > 0 ? EN : 1], d4 (&acc)[RB][CB], d4 (&eacc)[EN > 0 ? EN : 1],
+                                               const d2 (&r)[NQ], const int dst0, d2 (&fa)[2][RB], d2 (&fb)[2][CB],
+                                               d2 (&ea)[2][EN > 0 ? EN : 1], d2 (&eb)[2][EN > 0 ? EN : 1]) {
+  constexpr int CT = NQ * 32;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (it == 3) __syncthreads();
+    {
+      // groups 1..3 of this stage from L; after the barrier the first group of the next stage from Lnext
+      const double* src = (it + 1 < 4) ? L : Lnext;
+      const int g = (it + 1) & 3;
+      const int lx = ((g & 1) ? la1 : la) + g * (8 * CT);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) fa[(it + 1) & 1][i] = *reinterpret_cast<const d2*>(src + toa[i] + lx);
+#pragma unroll
+      for (int j = 0; j < CB; ++j) fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(src + tob[j] + lx);
+#pragma unroll
+      for (int e = 0; e < EN; ++e) {
+        ea[(it + 1) & 1][e] = *reinterpret_cast<const d2*>(src + etoa[e] + lx);
+        eb[(it + 1) & 1][e] = *reinterpret_cast<const d2*>(src + etob[e] + lx);
+      }
+    }
+    if (it < 2) {   // the next stage goes to the other LDS buffer under the MFMAs of the FIRST two groups
+      constexpr int H = (NQ + 1) / 2;
+#pragma unroll
+      for (int q = it * H; q < (it * H + H < NQ ? it * H + H : NQ); ++q)
+        *reinterpret_cast<d2*>(Lnext + dst0 + q * 64) = r[q];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = MFMA_F64(fa[it & 1][i].x, fb[it & 1][j].x, acc[i][j]);
+#pragma unroll
+    for (int e = 0; e < EN; ++e) eacc[e] = MFMA_F64(ea[it & 1][e].x, eb[it & 1][e].x, eacc[e]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = MFMA_F64(fa[it & 1][i].y, fb[it & 1][j].y, acc[i][j]);
+#pragma unroll
+    for (int e = 0; e < EN; ++e) eacc[e] = MFMA_F64(ea[it & 1][e].y, eb[it & 1][e].y, eacc[e]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ext0 / ext_step: this wave's left-over tiles are the tile numbers ext0, ext0 + ext_step, ... (EN of them) of the
 // left-over columns, numbered down the columns: tile e = (row e % RT, column CM + e / RT).
-template <int RB, int CB, int EN, int NQ, int PF, int RT>
+template <int RB, int CB, int EN, int NQ, int PF, int RT, bool PIPE>
 __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* __restrict__ ptab, const int nstages, const int col0,
                                         const int off, const int dst0, const int la, const int la1, const int row_tile0,
                                         const int col_tile0, const int bcol0, double* __restrict__ P, const int kpad, const int r16,
@@ -371,7 +426,37 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     if constexpr (PF == 2) stage_load(reg[0], 1);
     __syncthreads();
   }
-  if constexpr (PF == 2) {
+  if constexpr (PIPE) {
+    d2 fa[2][RB], fb[2][CB], ea[2][EA], eb[2][EA];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) fa[0][i] = *reinterpret_cast<const d2*>(lds + toa[i] + la);
+#pragma unroll
+    for (int j = 0; j < CB; ++j) fb[0][j] = *reinterpret_cast<const d2*>(lds + tob[j] + la);
+#pragma unroll
+    for (int e = 0; e < EN; ++e) {
+      ea[0][e] = *reinterpret_cast<const d2*>(lds + etoa[e] + la);
+      eb[0][e] = *reinterpret_cast<const d2*>(lds + etob[e] + la);
+    }
+    if constexpr (PF == 2) {
+      for (int s = 0; s < nstages; s += 2) {
+        stage_load(reg[1], s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ssb_stage_pipe<RB, CB, EN, NQ>(lds, lds + BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0, fa, fb, ea, eb);
+        if (s + 1 < nstages) {
+          stage_load(reg[0], s + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          ssb_stage_pipe<RB, CB, EN, NQ>(lds + BUF, lds, la, la1, toa, tob, etoa, etob, acc, eacc, reg[1], dst0, fa, fb, ea, eb);
+        }
+      }
+    } else {
+      for (int s = 0; s < nstages; ++s) {
+        stage_load(reg[0], s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ssb_stage_pipe<RB, CB, EN, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, etoa, etob, acc, eacc,
+                                       reg[0], dst0, fa, fb, ea, eb);
+      }
+    }
+  } else if constexpr (PF == 2) {
     for (int s = 0; s < nstages; s += 2) {
       stage_load(reg[1], s + 2);
       __builtin_amdgcn_sched_barrier(0);
@@ -405,7 +490,7 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     for (int e = 0; e < 4; ++e) P[(int64_t)(er[x] * 16 + kk + 4 * e) * kpad + ec[x] * 16 + r16] = eacc[x][e];
 }
 
-template <int RT, int CTL, int NQ>
+template <int RT, int CTL, int NQ, bool PIPE>
 __global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __restrict__ A, int64_t lda, int m,
                                                               const double* __restrict__ B, int64_t ldb, int k, int64_t Npad,
                                                               int64_t chunk, double* __restrict__ part) {
@@ -445,7 +530,7 @@ __global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __re
   // two register stages while a stage of MFMAs (tiles per SIMD x 512 cycles) is shorter than about 3.5 us of HBM latency under
   // load; the larger blocks need the registers for their accumulators
   constexpr int PF = (RT * CTL <= 56) ? 2 : 1;
-#define SSB_RUN(RBV, ENV) ssb_run<RBV, CBF, ENV, NQ, PF, RT>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk, ext0, CM)
+#define SSB_RUN(RBV, ENV) ssb_run<RBV, CBF, ENV, NQ, PF, RT, PIPE>(lds, ptab, nstages, col0, cq * 2, dst0, la, la1, row_tile0, col_tile0, acols, P, kpad, r16, kk, ext0, CM)
   if (rg == 0) {
     if (ENT_HI != ENT_LO && en == ENT_LO) SSB_RUN(RB0, ENT_LO);
     else SSB_RUN(RB0, ENT_HI);
@@ -456,19 +541,29 @@ __global__ __launch_bounds__(SS_THREADS, 2) void k_tsgemm_ssb(const double* __re
 #undef SSB_RUN
 }
 
+static bool ssb_pipe();
 template <int RT, int CTL>
 static int ssb_launch(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k, int64_t Npad,
                       int64_t chunk, int nsplit, double* part) {
   constexpr int NQ = (RT + CTL + 1) / 2;
   const size_t shmem = 2 * (size_t)NQ * 32 * SS_BK * sizeof(double) + (size_t)NQ * 32 * sizeof(double*);
-  auto kern = k_tsgemm_ssb<RT, CTL, NQ>;
-  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kern, dim3(nsplit), dim3(SS_THREADS), shmem, ctx->stream, A, lda, m, B, ldb, k, Npad, chunk, part);
+  // pipelined stages where the fragments fit next to two register stages (measured, scripts/ss_shapes.py: n = 32 / 48 / 64 at
+  // k = 138 +4 / +2.5 / +2 %; the 9 x 9 tile shape loses 10 % to the registers the carried fragments cost)
+  if (ssb_pipe() && RT * CTL <= 56) {
+    auto kern = k_tsgemm_ssb<RT, CTL, NQ, true>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, dim3(nsplit), dim3(SS_THREADS), shmem, ctx->stream, A, lda, m, B, ldb, k, Npad, chunk, part);
+  } else {
+    auto kern = k_tsgemm_ssb<RT, CTL, NQ, false>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, dim3(nsplit), dim3(SS_THREADS), shmem, ctx->stream, A, lda, m, B, ldb, k, Npad, chunk, part);
+  }
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
-static int g_ss_blocked = 1;   // A/B knob "ss_blocked"
+static int g_ss_blocked = 1;   // A/B knob "ss_blocked": 0 = round-robin kernel, 1 = blocked, 2 = blocked without the stage pipelining
 void tsgemm_ss_set_blocked(int v) { g_ss_blocked = v; }
+static bool ssb_pipe() { return g_ss_blocked != 2; }
 // rt <= ct after the caller's role swap
 static bool ssb_has_instance(int rt, int ct) { return rt >= 2 && rt <= ct && (ct == 5 || ct == 6 || ct == 9) && rt + ct <= 18; }
 static int ssb_dispatch(hfmi_ctx* ctx, int rt, int ct, const double* A, int64_t lda, int m, const double* B, int64_t ldb, int k,

@@ -13,7 +13,7 @@ for N, m, k, same in ((1000000, 8, 138, 0), (1000000, 32, 138, 0), (1000000, 138
     B = A if same else hf.MultiVector(N, k)
     if not same: hf.parRandom.normal(1.0, B)
     res, Cs = [], []
-    for blocked in (0, 1):
+    for blocked in (0, 2, 1):
         L.call("hfmi_tuning_set", b"ss_blocked", blocked)
         ts = []
         Ch = np.zeros((m, k))
@@ -22,8 +22,10 @@ for N, m, k, same in ((1000000, 8, 138, 0), (1000000, 32, 138, 0), (1000000, 138
             L.call("hfmi_bench_tsgemm_tn", A.handle, B.handle, 0, 10, L.ptr(Ch), C.byref(ms))
             ts.append(ms.value)
         res.append(np.median(ts)); Cs.append(Ch)
-    err = np.abs(Cs[0] - Cs[1]).max() / np.abs(Cs[0]).max()
+    err = max(np.abs(Cs[0] - Cs[1]).max(), np.abs(Cs[0] - Cs[2]).max()) / np.abs(Cs[0]).max()
     fl = (N * k * (k + 1.0)) if same else 2.0 * N * m * k
-    out.append("%dx%d%s: round-robin %.4f ms %.1f TF | blocked %.4f ms %.1f TF | diff %.1e" % (m, k, "s" if same else "", res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9, err))
+    out.append("%dx%d%s: round-robin %.4f ms %.1f TF | blocked %.4f ms %.1f TF | blocked + pipelined stages %.4f ms %.1f TF | diff %.1e"
+               % (m, k, "s" if same else "", res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9, res[2], fl / res[2] / 1e9, err))
     del A, B
+L.call("hfmi_tuning_set", b"ss_blocked", 1)
 print("\n".join(out))
