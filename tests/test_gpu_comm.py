@@ -93,3 +93,37 @@ def test_ranks_sharing_the_gpu_p2p_transport(tmp_path, world, sync):
         np.testing.assert_allclose(r["d_unfused"], rs[0]["d_all"], rtol=1e-11)
     sgn = np.sign(np.sum(rs[0]["U_gram"] * rs[0]["U_all"], axis=0))
     np.testing.assert_allclose(rs[0]["U_gram"] * sgn, rs[0]["U_all"], atol=1e-9)
+
+
+def test_row_panel_reduction_is_bit_identical_and_overlapped():
+    """Round 3: the rank reduction of an operator application is issued panel by panel on the auxiliary stream while the rest
+    of the product is computed (hfmi_api.hip panel_reduce_hook).  Same arithmetic per element: a solve with panels equals the
+    solve with ONE all-reduce after the product bit for bit, and the profile shows collective work off the main stream.
+    Shape: large enough for two rounds of row tiles and a small matrix too big for the LDS-resident kernel (what config 4 is)."""
+    import ctypes as C
+    import hippyflow_amd as hf
+    from hippyflow_amd import _lib as L
+    from hippyflow_amd import workloads
+    coll = hf.NativeCollective.from_unique_id(hf.NativeCollective.unique_id(), 1, 0)
+    N, ns, q, k, r = 270000, 16, 100, 12, 8          # two rounds of 512-row tiles on 256 CUs + a tail
+    wl = workloads.as_workload(N, ns, q=q, latent=20, rate=0.2, seed=11)
+    Omega = hf.MultiVector(N, k)
+    hf.parRandom.reseed(5)
+    hf.parRandom.normal(1.0, Omega)
+    A = hf.CollectiveOperator(wl.operator, coll, mpi_op="avg")
+    ctx = hf.Context.default()
+    out = {}
+    for panels in (0, 4):
+        L.call("hfmi_tuning_set", b"comm_panels", panels)
+        ctx.profile_begin()
+        d, U = hf.doublePass(A, Omega, r, s=1)
+        ctx.profile_end()
+        out[panels] = (d, U.to_dense(), ctx.profile_phases())
+    L.call("hfmi_tuning_set", b"comm_panels", 4)
+    np.testing.assert_array_equal(out[0][0], out[4][0])
+    np.testing.assert_array_equal(out[0][1], out[4][1])
+    assert out[0][2]["allreduce_overlapped"] == 0.0 and out[4][2]["allreduce_overlapped"] > 0.0
+    d0, U0 = hf.doublePass(wl.operator, Omega, r, s=1)               # and both equal the solve without a communicator
+    np.testing.assert_array_equal(d0, out[4][0])
+    np.testing.assert_array_equal(U0.to_dense(), out[4][1])
+    coll.close()
