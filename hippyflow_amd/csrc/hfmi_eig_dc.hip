@@ -1215,13 +1215,21 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
     else if (k <= 96) TRI(12, 2, 8);
     else if (k <= 128) TRI(16, 2, 8);
     else if (k <= 160) TRI(20, 3, 8);
-    else if (k <= 192) TRI(24, 3, 8);
     else {
-      // 192 < k <= 256: rows 0..191 in registers, rows 192..255 in 128 KB of LDS
-      auto kern = k_tridiag<24, 4, 8, 64>;
-      const size_t shm = (size_t)64 * 256 * sizeof(double);
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      hipLaunchKernelGGL(kern, dim3(1), dim3(512), shm, ctx->stream, T, SM_LD, k, dvec, evec, Vh, ldq, tauv, sexp, ticks);
+      // 160 < k <= 256: 64 k^2 doubles leave no registers for anything else (the compiler spills 84..99 values per thread
+      // and the reduction runs 3x slower), so the last LR rows live in LDS; the shapes below are the ones that do not spill
+      // (k <= 192) or spill 5 values (k <= 224); above that 64 rows are all the LDS holds beside the work arrays
+#define TRI_LDS(RIV, CJV, LRV)                                                                                                   \
+  do {                                                                                                                          \
+    auto kern = k_tridiag<RIV, CJV, 8, LRV>;                                                                                    \
+    const size_t shm = (size_t)(LRV) * 64 * (CJV) * sizeof(double);                                                             \
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                      \
+    hipLaunchKernelGGL(kern, dim3(1), dim3(512), shm, ctx->stream, T, SM_LD, k, dvec, evec, Vh, ldq, tauv, sexp, ticks);        \
+  } while (0)
+      if (k <= 192) TRI_LDS(20, 3, 32);
+      else if (k <= 224) TRI_LDS(20, 4, 64);
+      else TRI_LDS(24, 4, 64);
+#undef TRI_LDS
     }
   }
 #undef TRI

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out; mkdir -p $out
 rm -rf /tmp/prof_shard
-( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py --samples-total 64 --steps 5 --warmup 2 --no-cpu-baseline --no-check > $out/shard_bench.json 2> $out/shard_prof.err )
+( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py --samples-total 64 --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-literal > $out/shard_bench.json 2> $out/shard_prof.err )
 db=$(find /tmp/prof_shard -name "*.db" | head -1)
 python3 $R/profiles/summarize_rocpd.py $db > $out/shard_kernel_stats.csv
 python3 - <<PY
@@ -13,7 +13,7 @@ db = sqlite3.connect("$db"); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+rows = [r for r in cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start") if "k_bench" not in r[0]]
 # last full step: find the last 3 launches of the big tn/nn and print the timeline from the first of them
 big = [i for i, r in enumerate(rows) if ("k_tsgemm_tn" in r[0] or "k_tsgemm_nn" in r[0]) and (r[2] - r[1]) > 2e6]
 start = big[-3]
