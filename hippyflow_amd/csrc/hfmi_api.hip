@@ -534,8 +534,8 @@ static void print_status_dbg(const hfmi_status_words* out) {
             out->tick[4] == 3 ? "chol-polish(load,-,-,out)" : out->tick[4] ? "jacobi(total,phase1,phase2,sweeps)" : "chol(load,chol,inv,out)",
             out->tick[0], out->tick[1], out->tick[2], out->tick[3]);
   if (dbg && (!out->tick[4] || out->tick[4] == 3))
-    fprintf(stderr, "[hfmi timing]   chol status: min pivot ratio %.3e, input defect %.3e, shifted %d\n", out->min_pivot_ratio,
-            out->gram_dev, out->shifted);
+    fprintf(stderr, "[hfmi timing]   chol status: min pivot ratio %.3e, input defect %.3e, shifted %d; blocked phases (diag, row, trailing) %lld %lld %lld\n",
+            out->min_pivot_ratio, out->gram_dev, out->shifted, out->tick[5], out->tick[6], out->tick[7]);
 }
 
 extern "C" int hfmi_block_norms(const hfmi_block* b, double* host_norms) {

@@ -434,6 +434,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   else if (key && !strcmp(key, "rem4") && (value == 0 || value == 1)) { g_rem4 = value; nn_tuning_set(key, value); }
   else if (key && nn_tuning_set(key, value)) {}
   else if (key && eig_tuning_set(key, value)) {}
+  else if (key && chol_tuning_set(key, value)) {}
   else if (key && api_tuning_set(key, value)) {}
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
   else if (key && !strcmp(key, "probe")) g_probe = value;

@@ -241,6 +241,9 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
 // dispatcher: method 0 = default (divide and conquer unless tuning "eig" = 1), 1 = Jacobi (high relative accuracy)
 int launch_sym_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, int sort_by_abs, int method);
 int eig_tuning_set(const char* key, int value);   // 1 = key handled
+int chol_tuning_set(const char* key, int value);  // "chol": 0 = blocked MFMA kernel (default), 1 = column-at-a-time kernels
+int launch_chol_mfma(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode, int full_r,
+                     double shift_rel, double pivot_tol);   // hfmi_chol.hip
 int api_tuning_set(const char* key, int value);   // 1 = key handled ("comm_panels")
 int launch_small_set_identity(hfmi_ctx* ctx, int k, int slot);
 // slot_c (k x r, zero padded to 16 columns) = slot_a (k x k) * slot_b[:, :r]

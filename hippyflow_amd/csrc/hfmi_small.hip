@@ -825,9 +825,24 @@ static int chol_tiles(int k, int trr, int tcc) {
   return n;
 }
 
+static int g_chol_default = -1;
+int chol_tuning_set(const char* key, int value) {
+  if (key && !strcmp(key, "chol") && (value == 0 || value == 1)) {
+    g_chol_default = value;
+    return 1;
+  }
+  return 0;
+}
 int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_rinv, int slot_rtot, int rtot_mode,
                     int full_r, double shift_rel, double pivot_tol) {
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "chol_inv: k=%d out of range", k);
+  // default: the blocked MFMA kernel (hfmi_chol.hip); the column-at-a-time kernels below stay for A/B runs
+  // (HFMI_CHOL=tile, tuning "chol" = 1) and as the reference the tests compare the blocked kernel with
+  if (g_chol_default < 0) {
+    const char* e = getenv("HFMI_CHOL");
+    g_chol_default = (e && !strcmp(e, "tile")) ? 1 : 0;
+  }
+  if (g_chol_default == 0) return launch_chol_mfma(ctx, k, slot_gram, slot_r, slot_rinv, slot_rtot, rtot_mode, full_r, shift_rel, pivot_tol);
   const int use_lds = (k <= 139) ? 1 : 0;   // (32 + 3 * 256) * 8 + 139 * 139 * 8 = 160,968 bytes <= 160 KB (163,840)
   const size_t shmem = (32 + 3 * 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;

@@ -1,12 +1,15 @@
 #!/bin/bash
-# Kernel trace of the per-GPU share of the 8-GPU config-4 run (64 of the 512 samples on one GPU): what does NOT scale.
+# Kernel timeline of one step.  Default: the per-GPU share of the 8-GPU config-4 run (64 of the 512 samples on one GPU): what
+# does NOT scale.  bash scripts/shard_profile.sh <name> <bench.py arguments> traces another workload (e.g. pod --workload pod).
+name=${1:-shard}; [ $# -gt 0 ] && shift
+args=${@:-"--samples-total 64"}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out; mkdir -p $out
 rm -rf /tmp/prof_shard
-( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py --samples-total 64 --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-literal > $out/shard_bench.json 2> $out/shard_prof.err )
+( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py $args --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-literal > $out/${name}_bench.json 2> $out/${name}_prof.err )
 db=$(find /tmp/prof_shard -name "*.db" | head -1)
-python3 $R/profiles/summarize_rocpd.py $db > $out/shard_kernel_stats.csv
+python3 $R/profiles/summarize_rocpd.py $db > $out/${name}_kernel_stats.csv
 python3 - <<PY
 import sqlite3, json
 db = sqlite3.connect("$db"); cur = db.cursor()
@@ -24,5 +27,5 @@ print("timeline of the last step (us from its first big launch): name, start, du
 for r in rows[start:]:
     name = r[0].split("(")[0][:60]
     print("%-60s %10.1f %9.1f %8.1f" % (name, (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3))
-    prev_end = r[2]
+    prev_end = max(prev_end, r[2])
 PY
