@@ -6,15 +6,15 @@
 // accumulator layout in registers, and a step handles sixteen columns:
 //
 //   for K = 0 .. nb-1:   (nb = ceil(k / 16))
-//     A  one wave factors the diagonal block A_KK = R_KK^T R_KK by Gaussian elimination on [A_KK | I] with one column per
-//        lane (lanes 0..15 the block, lanes 16..31 the identity): sixteen steps of readlane broadcasts, no barrier; the
-//        augmented half ends as R_KK^-T.
+//     A  one wave factors the diagonal block A_KK = R_KK^T R_KK by Gaussian elimination on [A_KK | I], lane l holding column
+//        l mod 16 of both halves: sixteen steps whose broadcasts are 64-bit DPP operands of the accumulate itself
+//        (v_fmac_f64_dpp row_newbcast), no barrier; the augmented half ends as R_KK^-T.
 //     B  block row K:   R_KJ = R_KK^-T A_KJ (J > K)   and   Z_KJ = R_KK^-T W_KJ (J < K),  Z_KK = R_KK^-T
 //     C  everything below:   A_IJ -= R_KI^T R_KJ (K < I <= J)   and   W_IJ -= R_KI^T Z_KJ (J <= K < I)
 //
 //   W is the identity carried through the same elimination: Z = R^-T comes out row by row, and X = R^-1 = Z^T is written
 //   transposed.  Block (J, I) of A (J < I) dies at step J, exactly when W_IJ is born: they share one register slot, so the
-//   nb (nb + 1) / 2 slots of the upper triangle hold everything (8.5 slots of four doubles per wave at k = 256).
+//   nb (nb + 1) / 2 slots of the upper triangle hold everything (17 slots of four doubles per wave at k = 256).
 //
 // Every product has the form X^T Y with X and Y in the accumulator layout -- lane (li, lk) holds rows 4 s + lk, column li
 // in register s -- and that is exactly what v_mfma_f64_16x16x4 wants as its A operand (X^T: A[li][4 s + lk]) and B operand
@@ -22,7 +22,9 @@
 // into the next MFMA, no shuffles.  Two barriers per block step; the published block row is double-buffered.
 //
 // Semantics (status words, shift-and-retry on breakdown, first-order polish for an orthonormal input, running product of the
-// factors) are those of k_chol_tile.  k = 138: 205 -> about 40 us.
+// factors) are those of k_chol_tile.  Kernel time 80 -> 25 us at k = 74, 205 -> 55 us at k = 138, 730 -> 170 us at k = 256; per
+// block step about 4.8 k cycles for the diagonal block (scripts/chol_diag_probe.hip), 2.7 k for the block row, 2.3 k for the
+// trailing update at k = 138 (HFMI_DEBUG_TIMING=1 prints the three sums).
 #include "hfmi_internal.h"
 
 #include <stdlib.h>
@@ -87,67 +89,100 @@ __device__ __forceinline__ int cm_opaque(int x) {
 // stored, which nobody reads before the kernel ends (or before the __syncthreads() in front of the running product).
 __device__ __forceinline__ void cm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int CM_SCR = 2 * 16 * 17;   // two padded 16 x 16 blocks of scratch per wave
+constexpr int CM_SCR = 4 * 16 * 17;   // padded 16 x 16 blocks of scratch per wave: input / R_KK, Z_KK, two dump blocks
 
-// Phase A.  scr: the diagonal block, row-major with stride 17 (written by this wave).  Outputs, all in LDS: R_KK over the input
-// (scr, stride 17), R_KK^-T in scz (stride 17) and in zpan (row-major 16 x 16, the published block Z_KK), the pivots in spiv,
-// diag(R) in srd; *s_fail on breakdown.  The global copies are written by the caller after the barrier, off the critical path.
+// 64-bit DPP: lane l gets x of lane I of its own row of sixteen (row_newbcast, the one DPP mode the double-precision ALU has) --
+// as a plain copy and fused into the accumulate acc += bcast_I(src) * mul.  The compiler neither knows these instructions
+// (v_readlane into SGPRs is what it offers: two per double and ~20 cycles each, 60 % of the elimination's time) nor their
+// hazard (two wait states between a VALU write of src and its DPP read): the copy, which is always the first DPP reader of a
+// freshly written row, carries the s_nop.
+template <int I>
+__device__ __forceinline__ double cm_bcast(double x) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(I));
+  return r;
+}
+template <int I>
+__device__ __forceinline__ void cm_fmac_bcast(double& acc, double src, double mul) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(I));
+}
+template <int J, int I>
+struct cm_elim_rows {   // rows I .. 15 of step J: v[i] -= U[J][i] (v[J] / pivot), the same for the augmented half
+  static __device__ __forceinline__ void run(double (&v)[16], double (&w)[16], double tv, double tw) {
+    if constexpr (I < 16) {
+      cm_fmac_bcast<I>(v[I], v[J], tv);
+      cm_fmac_bcast<I>(w[I], v[J], tw);
+      cm_elim_rows<J, I + 1>::run(v, w, tv, tw);
+    }
+  }
+};
+template <int J>
+struct cm_elim_steps {
+  static __device__ __forceinline__ void run(double (&v)[16], double (&w)[16], double piv, double inv, double& mypiv, int c) {
+    if constexpr (J < 16) {
+      if (c == J) mypiv = piv;                       // lane c keeps pivot c: checks, square roots and scaling are done once, after
+      const double tv = -(v[J] * inv), tw = -(w[J] * inv);
+      double piv_n = 1.0, inv_n = 1.0;
+      if constexpr (J + 1 < 16) {
+        // row J + 1 first, and the reciprocal of ITS pivot started right away: the dependent chain (broadcast, v_rcp_f64, two
+        // Newton steps) runs under the other updates
+        cm_fmac_bcast<J + 1>(v[J + 1], v[J], tv);
+        cm_fmac_bcast<J + 1>(w[J + 1], v[J], tw);
+        piv_n = cm_bcast<J + 1>(v[J + 1]);
+        inv_n = cm_rcp(piv_n);
+      }
+      cm_elim_rows<J, J + 2>::run(v, w, tv, tw);
+      cm_elim_steps<J + 1>::run(v, w, piv_n, inv_n, mypiv, c);
+    }
+  }
+};
+template <int J>
+struct cm_scale_out {   // row J of R = diag(U)^-1/2 U and of Z = diag(U)^-1/2 L^-1 to their blocks
+  static __device__ __forceinline__ void run(const double (&v)[16], const double (&w)[16], double rsv, bool mat, int c, double* dst,
+                                             double* dsz) {
+    if constexpr (J < 16) {
+      const double rs = cm_bcast<J>(rsv);
+      const double x = (mat ? ((J <= c) ? v[J] : 0.0) : ((J >= c) ? w[J] : 0.0)) * rs;
+      dst[J * 17] = x;
+      dsz[16 * J] = x;
+      cm_scale_out<J + 1>::run(v, w, rsv, mat, c, dst, dsz);
+    }
+  }
+};
+
+// Phase A.  scr: the diagonal block, row-major with stride 17 (written by this wave).  Gaussian elimination on [A_KK | I], lane
+// l holds column l mod 16 of both halves (the four rows of sixteen lanes do the same work: the broadcasts stay inside a row).
+// Outputs, all in LDS: R_KK over the input (scr, stride 17), Z = R_KK^-T in scz (stride 17) and in zpan (row-major 16 x 16, the
+// published block Z_KK; scz + 272 .. scz + 3 * 272 is a dump area), the pivots in spiv, diag(R) in srd; *s_fail on breakdown.  The global copies are written by the
+// caller after the barrier, off the critical path.
 __device__ __forceinline__ void chol_diag16(double* scr, double* scz, double* zpan, const double* sref, double* spiv, double* srd,
                                             int K, double ptol, int* s_fail, int lane) {
   asm volatile("" : "+v"(lane));                 // lane masks and addresses are recomputed per call, not kept live across calls
   const int c = lane & 15;
-  const bool mat = lane < 16, aug = (lane >> 4) == 1;
-  double v[16];
+  double v[16], w[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const double m = scr[r * 17 + c];
-    v[r] = mat ? m : ((aug && r == c) ? 1.0 : 0.0);
+    v[r] = scr[r * 17 + c];
+    w[r] = (r == c) ? 1.0 : 0.0;
   }
   const int g0 = 16 * K;
-  bool bad = false;
-  double rd = 0.0;
-  // Step j: t = (row j) / pivot; row i -= U[j][i] t for i > j.  Row j + 1 goes first and the reciprocal of ITS pivot is started
-  // right away, so that the dependent chain (broadcast, v_rcp_f64, two Newton steps) runs under the other fourteen updates.
-  double piv = cm_readlane(v[0], 0);
-  double inv = cm_rcp(piv);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const double ref = sref[g0 + j];
-    bad = bad || !(piv > ptol * ref) || !(ref > 0.0);
-    spiv[g0 + j] = piv;                            // every lane the same word: no branch, the elimination stays one basic block
-    const double t = v[j] * inv;
-    const double rs = cm_rsqrt(piv);
-    double piv_n = 1.0, inv_n = 1.0;
-    if (j + 1 < 16) {
-      const double s1 = cm_readlane(v[j], j + 1);
-      v[j + 1] = fma(-s1, t, v[j + 1]);
-      piv_n = cm_readlane(v[j + 1], j + 1);
-      inv_n = cm_rcp(piv_n);
-    }
-#pragma unroll
-    for (int i = j + 2; i < 16; ++i) {
-      const double s = cm_readlane(v[j], i);       // U[j][i]: the multiplier of row i is s / piv
-      v[i] = fma(-s, t, v[i]);
-    }
-    v[j] *= rs;                                    // row j is final: R = diag(U)^-1/2 U
-    if (lane == j) rd = v[j];
-    // all updates of step j are done before step j + 1 starts: left alone, the compiler defers the updates of row i until step i
-    // needs them and parks the 120 multipliers in spilled SGPRs meanwhile
-    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                      "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(inv_n));
-    piv = piv_n;
-    inv = inv_n;
-  }
-  // lanes 0..15: column c of R_KK (zero below the diagonal); lanes 16..31: column c of Z = R_KK^-T (zero above it)
-  double* dst = mat ? scr : scz;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const double x = mat ? ((j <= c) ? v[j] : 0.0) : ((j >= c) ? v[j] : 0.0);
-    if (lane < 32) dst[j * 17 + c] = x;
-    if (aug) zpan[16 * j + c] = x;
-  }
-  if (mat) srd[g0 + c] = rd;                        // R_jj, folded into the running diagonal after a clean run
-  if (lane == 0 && bad) *s_fail = 1;
+  double mypiv = 1.0;
+  const double piv0 = cm_bcast<0>(v[0]);
+  cm_elim_steps<0>::run(v, w, piv0, cm_rcp(piv0), mypiv, c);
+  const double ref = sref[g0 + c];
+  const bool bad = !(mypiv > ptol * ref) || !(ref > 0.0);
+  const double rsv = cm_rsqrt(mypiv);
+  // lanes 0..15: column c of R_KK (zero below the diagonal) over the input; lanes 16..31: column c of Z (zero above it) to scz and
+  // to the published block; the other lanes write the same values to a dump block, so that no store sits behind a branch
+  // (predicated, the 48 stores cost more than the elimination)
+  const int row = lane >> 4;
+  const bool mat = row == 0, aug = row == 1;
+  double* dst = (mat ? scr : aug ? scz : scz + 272) + c;
+  double* dsz = (aug ? zpan : scz + 2 * 272) + c;
+  cm_scale_out<0>::run(v, w, rsv, mat, c, dst, dsz);
+  spiv[g0 + c] = mypiv;                             // (the four rows of lanes write the same words)
+  srd[g0 + c] = mypiv * rsv;                        // R_cc, folded into the running diagonal after a clean run
+  if (bad) *s_fail = 1;
 }
 
 template <int NW, int SLOTS>
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(64 * NW) void k_chol_mfma(const double* __restrict_
   double* sref = invd + 256;                       // diag0 + shift
   double* spiv = sref + 256;                       // pivots
   double* srd = spiv + 256;                        // diag(R)
-  double* scratch = srd + 256;                     // two padded 16 x 16 blocks per wave
+  double* scratch = srd + 256;                     // four padded 16 x 16 blocks per wave
   double* panel = scratch + NW * CM_SCR;           // 2 x nb published blocks
   __shared__ int s_fail;
 
@@ -203,26 +238,51 @@ __global__ __launch_bounds__(64 * NW) void k_chol_mfma(const double* __restrict_
     int ln = lane0;
     asm volatile("" : "+v"(ln));                    // (the reload of a shifted retry must not park its addresses in registers)
     const int li = ln & 15, lk = ln >> 4;
+    // All loads of a group of slots are issued before the first one is used, unconditionally (clamped indices; a slot beyond
+    // the last block pair loads block (0, 0) and is never looked at): the Gram matrix was written by another kernel and is a
+    // 3 k-cycle round trip away, which was paid once per ELEMENT behind per-element branches and once per slot without groups.
+    constexpr int GS = SLOTS < 6 ? SLOTS : 6;
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-      if (!sv[t]) continue;
-      const int a = cm_opaque(sa[t]), b = cm_opaque(sb[t]);
-      const int c = 16 * b + li;
+    for (int t0 = 0; t0 < SLOTS; t0 += GS) {
+      double g1[GS][4], g2[GS][4];
+      int ga[GS], gb[GS];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int r = 16 * a + 4 * s + lk;
-        double g = (r == c) ? 1.0 : 0.0;
-        if (r < k && c < k) {
-          g = 0.5 * (G[(size_t)r * ldg + c] + G[(size_t)c * ldg + r]);
-          if (measure) {
-            const double x = g * invd[r] * invd[c] - (r == c ? 1.0 : 0.0);
-            dev += (a == b ? 1.0 : 2.0) * x * x;
-            if (r == c) tr += g;
-          }
-          if (r == c) g += shift;
+      for (int u = 0; u < GS; ++u) {
+        if (t0 + u >= SLOTS) continue;
+        ga[u] = cm_opaque(sa[t0 + u]);
+        gb[u] = cm_opaque(sb[t0 + u]);
+      }
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        if (t0 + u >= SLOTS) continue;
+        const int c = 16 * gb[u] + li;
+        const int cc = c < k ? c : k - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = 16 * ga[u] + 4 * s + lk;
+          const int rc = r < k ? r : k - 1;
+          g1[u][s] = G[(size_t)rc * ldg + cc];
+          g2[u][s] = G[(size_t)cc * ldg + rc];
         }
-        acc[t][s] = g;
+      }
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        if (t0 + u >= SLOTS) continue;
+        const int t = t0 + u;
+        const int c = 16 * gb[u] + li;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = 16 * ga[u] + 4 * s + lk;
+          const bool in = r < k && c < k;
+          double g = in ? 0.5 * (g1[u][s] + g2[u][s]) : ((r == c) ? 1.0 : 0.0);
+          if (measure && sv[t]) {
+            const double x = in ? g * invd[r] * invd[c] - (r == c ? 1.0 : 0.0) : 0.0;
+            dev += (ga[u] == gb[u] ? 1.0 : 2.0) * x * x;
+            if (in && r == c) tr += g;
+          }
+          if (in && r == c) g += shift;
+          acc[t][s] = g;
+        }
       }
     }
   };

@@ -921,20 +921,36 @@ __global__ void k_small_identity(double* M, int ld, int k) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < k * ld) M[e] = ((e / ld) == (e % ld)) ? 1.0 : 0.0;
 }
-// C (k x r, zero padded to a multiple of 16 columns) = A (k x k) * B[:, :r], all row-major small-arena matrices
-__global__ void k_small_matmul(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ Cm, int ld,
-                               int k, int r, int rpad) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (j >= rpad) return;
-  double s = 0.0;
-  if (j < r)
-    for (int l = 0; l < k; ++l) s += A[i * ld + l] * B[l * ld + j];
-  Cm[i * ld + j] = s;
+// C (k x r, zero padded to a multiple of 16 columns) = A (k x k) * B[:, :r], all row-major small-arena matrices.  One wave per
+// 16 x 16 tile of C on the fp64 MFMA, sixteen k-steps of loads in flight (the scalar version -- one thread per entry, k
+// dependent multiply-adds behind two loads each -- took 37 us at k = 138 for 5 Mflop).
+typedef double sm_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_small_matmul(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ Cm, int ld,
+                                                     int k, int r, int rpad) {
+  const int l = threadIdx.x, li = l & 15, lk = l >> 4;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const bool rowok = i0 + li < k, colok = j0 + li < r;
+  sm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < k; k0 += 64) {
+    double a[16], b[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int kk = k0 + 4 * u + lk;
+      a[u] = (rowok && kk < k) ? A[(i0 + li) * ld + kk] : 0.0;      // A operand: lane (li, lk) = A[row li][k-index lk]
+      b[u] = (colok && kk < k) ? B[kk * ld + j0 + li] : 0.0;        // B operand: lane (li, lk) = B[k-index lk][column li]
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int i = i0 + 4 * s + lk, j = j0 + li;                     // accumulator: register s = row 4 s + lk, column li
+    if (i < k && j < rpad) Cm[i * ld + j] = acc[s];
+  }
 }
 int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int slot_c) {
   const int rpad = (r + 15) & ~15;
-  hipLaunchKernelGGL(k_small_matmul, dim3((rpad + 63) / 64, k), dim3(64), 0, ctx->stream, sm_ptr(ctx, slot_a), sm_ptr(ctx, slot_b),
+  hipLaunchKernelGGL(k_small_matmul, dim3(rpad / 16, (k + 15) / 16), dim3(64), 0, ctx->stream, sm_ptr(ctx, slot_a), sm_ptr(ctx, slot_b),
                      sm_ptr(ctx, slot_c), SM_LD, k, r, rpad);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;

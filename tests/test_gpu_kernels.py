@@ -325,6 +325,51 @@ def test_Borthogonalize(ctx, method):
     assert np.abs(Qd - Qo).max() < 1e-9 and rel(R, Ro) < 1e-9
 
 
+@pytest.mark.parametrize("k", [1, 2, 15, 16, 17, 31, 33, 74, 80, 81, 112, 113, 138, 144, 145, 192, 193, 200, 255, 256])
+def test_blocked_cholesky_against_lapack_and_the_column_kernel(ctx, k):
+    """hfmi_chol.hip (16 x 16 blocks on the MFMA) at every block-count boundary: thin QR of a graded block vs numpy's
+    Householder QR, and the same call on the column-at-a-time kernels (tuning "chol" = 1)."""
+    from hippyflow_amd import _lib as L
+    rng = np.random.default_rng(1000 + k)
+    N = 4 * k + 64
+    Z = rng.standard_normal((N, k)) * np.exp(-0.03 * np.arange(k))
+    out = {}
+    for which in (0, 1):
+        L.call("hfmi_tuning_set", b"chol", which)
+        try:
+            Q = hf.MultiVector.from_dense(Z)
+            out[which] = (Q.orthogonalize(), Q.to_dense())
+        finally:
+            L.call("hfmi_tuning_set", b"chol", 0)
+    R, Qd = out[0]
+    Qn, Rn = np.linalg.qr(Z)
+    sgn = np.sign(np.diag(Rn))
+    Rn, Qn = Rn * sgn[:, None], Qn * sgn
+    assert np.abs(Qd.T @ Qd - np.eye(k)).max() < 1e-14 * max(k, 8)
+    assert not np.tril(R, -1).any() and np.all(np.diag(R) > 0)
+    assert rel(R, Rn) < 1e-12 and np.abs(Qd - Qn).max() < 1e-11
+    assert rel(R, out[1][0]) < 1e-13 and np.abs(Qd - out[1][1]).max() < 1e-12
+
+
+def test_blocked_cholesky_shifted_retry_and_rank_deficiency(ctx):
+    """cond(Z) = 1e9: the first Gram matrix is numerically singular, the factorisation breaks down inside a diagonal block,
+    the kernel restarts with the diagonal shift and the later passes repair the basis; an exactly dependent column ends on
+    the Gram-Schmidt route exactly as with the column kernel."""
+    rng = np.random.default_rng(5)
+    N, k = 6000, 100
+    Z = rng.standard_normal((N, k)) @ np.diag(np.logspace(0, -9, k)) @ np.linalg.qr(rng.standard_normal((k, k)))[0]
+    Q = hf.MultiVector.from_dense(Z)
+    R = Q.orthogonalize()
+    Qd = Q.to_dense()
+    assert Q.last_qr_passes >= 3
+    assert np.abs(Qd.T @ Qd - np.eye(k)).max() < 1e-13 and rel(Qd @ R, Z) < 1e-12
+    Z2 = rng.standard_normal((800, 40))
+    Z2[:, 33] = Z2[:, 2] + Z2[:, 17]
+    Q2 = hf.MultiVector.from_dense(Z2)
+    R2 = Q2.orthogonalize()
+    assert R2[33, 33] == 0.0 and not Q2.to_dense()[:, 33].any()
+
+
 # ------------------------------------------------------------------ small eigensolve (a8)
 @pytest.mark.parametrize("method", ["dc", "jacobi"])
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 16, 17, 30, 31, 64, 65, 74, 80, 81, 84, 96, 97, 128, 129, 137, 138, 144, 145, 148, 192, 193, 200, 256])
