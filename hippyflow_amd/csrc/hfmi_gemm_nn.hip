@@ -9,12 +9,14 @@ static int g_nn_hybrid = 1;   // split only the row tiles beyond the last full r
 static int g_nn_tt = 0;       // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_rem4 = 1;        // last column tile of <= 12 columns in 4-column groups (4x4x4 MFMA)
 static int g_nn_res = 1;      // small matrix resident in LDS + persistent workgroups when it fits
+static int g_nn_res_tt = 0;   // 0: tile height of nn_res by the round count (below); 1: always the table's; 2: always one less (A/B)
 int nn_tuning_set(const char* key, int value) {
   if (!strcmp(key, "rem4") && (value == 0 || value == 1)) g_rem4 = value;
   else if (!strcmp(key, "nn_waves") && (value == 0 || value == 4 || value == 8)) g_nn_waves = value;
   else if (!strcmp(key, "nn_tt") && value >= 0 && value <= 3) g_nn_tt = value;
   else if (!strcmp(key, "nn_hybrid") && (value == 0 || value == 1)) g_nn_hybrid = value;
   else if (!strcmp(key, "nn_res") && (value == 0 || value == 1)) g_nn_res = value;
+  else if (!strcmp(key, "nn_res_tt") && value >= 0 && value <= 2) g_nn_res_tt = value;
   else return 0;
   return 1;
 }
@@ -667,9 +669,22 @@ static int nn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
     const int sld = nt * 16 + ((nt % 2 == 0) ? 16 : 0);
     const size_t shmem = (size_t)((m + 3) & ~3) * sld * sizeof(double);
     if (shmem <= 160 * 1024) {
-#define NN_RES(NTV, TTV) \
-  case NTV:              \
-    return nn_launch_res<TTV, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, shmem);
+      // Tile height: the persistent workgroups take whole tiles of 128 TT rows in turn, so the product costs
+      // ceil(tiles / CUs) rounds of TT units each.  N = 2e5 with TT = 3 is 521 tiles = 2.03 rounds -> 3 rounds (9 units) where
+      // TT = 2 needs 4 rounds of 2 (8 units): the shorter tile is taken when it saves more than the ~5 % its worse
+      // MFMA-to-LDS ratio costs.
+      const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+      auto units = [&](int tt) {
+        const int64_t tiles = (N + 128 * tt - 1) / (128 * tt);
+        return (double)((tiles + cus - 1) / cus) * tt;
+      };
+#define NN_RES(NTV, TTV)                                                                                      \
+  case NTV: {                                                                                                 \
+    constexpr int TL = TTV > 1 ? TTV - 1 : 1;                                                                 \
+    const bool lower = g_nn_res_tt == 2 || (g_nn_res_tt == 0 && TL != TTV && units(TL) * 1.05 < units(TTV)); \
+    if (lower) return nn_launch_res<TL, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, shmem);                   \
+    return nn_launch_res<TTV, NTV>(ctx, A, lda, m, S, lds_, r, Y, ldy, N, shmem);                             \
+  }
       switch (nt) {
         NN_RES(1, 4) NN_RES(2, 4) NN_RES(3, 4) NN_RES(4, 4) NN_RES(5, 3) NN_RES(6, 2) NN_RES(7, 2) NN_RES(8, 2) NN_RES(9, 2)
         NN_RES(10, 1)

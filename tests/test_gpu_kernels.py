@@ -265,6 +265,32 @@ def test_csr_irregular_rows_use_the_csr_kernel(ctx, k):
     assert rel(Z.to_dense(), spla.splu(arrow.tocsc()).solve(X)) < 1e-10
 
 
+def test_resident_nn_product_is_independent_of_the_tile_height(ctx):
+    """Q R^-1 with the small matrix resident in LDS: the tile height is chosen by the number of rounds the persistent
+    workgroups need (N = 2e5, k = 74: two 16-row tiles per wave instead of three); the choice moves rows between waves and
+    must not change a single bit, including in place."""
+    from hippyflow_amd import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for N, m, r in [(200000, 74, 74), (70001, 40, 33)]:
+        A = hf.MultiVector(N, m)
+        hf.parRandom.normal(1.0, A)
+        S = rng.standard_normal((m, r))
+        outs = []
+        for tt in (1, 2, 0):
+            L.call("hfmi_tuning_set", b"nn_res_tt", tt)
+            try:
+                Y = hf.MultiVector(N, r)
+                ms = C.c_double(0)
+                L.call("hfmi_bench_tsgemm_nn", A.handle, L.ptr(S), Y.handle, 1, C.byref(ms))
+                outs.append(Y.to_dense())
+            finally:
+                L.call("hfmi_tuning_set", b"nn_res_tt", 0)
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        ref = A.to_dense() @ S
+        assert np.abs(outs[0] - ref).max() < 1e-12 * np.abs(ref).max() * m
+
+
 # ------------------------------------------------------------------ QR (a7)
 @pytest.mark.parametrize("N,k,cond", [(300, 20, 1e0), (4225, 30, 1e3), (4225, 30, 1e9), (20000, 138, 1e5), (1000, 200, 1e2)])
 def test_orthogonalize_matches_reference_mgs(ctx, N, k, cond):
