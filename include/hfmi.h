@@ -288,7 +288,9 @@ int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, double* hbm_c
  * tsgemm_nn workgroup / wave-tile height (0 = automatic); ("nn_hybrid", 0|1) split only the tail row tiles; ("nn_res", 1|0) small matrix resident in LDS with persistent
  * workgroups when it fits (short reductions: Q R^-1, U = Q V); ("ss", 0|1) route skinny x skinny contractions to
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized; ("eig", 0|1) Rayleigh-Ritz
- * eigensolver of every call: divide and conquer | Jacobi; ("comm_panels", 0..8) row panels of an operator application whose
+ * eigensolver of every call: divide and conquer | Jacobi; ("chol", 0|1) Cholesky + inverse of the QR passes: blocked MFMA kernel |
+ * column-at-a-time kernels; ("nn_res_tt", 0|1|2) tile height of the LDS-resident nn product: by round count | table | one less;
+ * ("comm_panels", 0..8) row panels of an operator application whose
  * rank reduction overlaps the rest of the product (0 / 1 = one all-reduce after the product; default 4). */
 int hfmi_tuning_set(const char* key, int value);
 /* phases of hfmi_double_pass[_g], accumulated between hfmi_profile_begin and hfmi_profile_end (milliseconds, summed
