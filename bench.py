@@ -510,6 +510,9 @@ def main():
     barrier()
     pci = ctx.pci_bus_id()
     sysfs_before = gpu_sysfs_snapshot(pci) if rank == 0 else {}
+    if os.environ.get("HFMI_BENCH_PROF_LEVEL"):        # A/B of what the profiling events cost (scripts/prof_level_ab.py)
+        from hippyflow_amd import _lib as _L
+        _L.call("hfmi_tuning_set", b"prof_level", int(os.environ["HFMI_BENCH_PROF_LEVEL"]))
     ctx.profile_begin()
     step_ms = []
     t0 = time.perf_counter()

@@ -1012,9 +1012,18 @@ static int panel_reduce_hook(void* user, double* Y, int64_t ldy, int r, int64_t 
   return HFMI_OK;
 }
 static int g_comm_panels = -1;    // HFMI_COMM_PANELS: 0 = one all-reduce after the product, n = at most n row panels (default 4)
+// What a profiling region (hfmi_profile_begin .. _end) records.  Every record is a pair of events on the stream, and an event
+// between two dependent kernels costs 2-4 us of idle GPU: with one pair per contraction and per phase a 64-sample shard step of
+// config 4 carried ~32 of them.  Level 2 (default): contractions and phases.  Level 1: only contractions of at least
+// HFMI_PROF_MIN_GFLOP (2.0) Gflop -- what a roofline line needs -- and no phases.
+static int g_prof_level = 2;
 int api_tuning_set(const char* key, int value) {
   if (key && !strcmp(key, "comm_panels") && value >= 0 && value <= 8) {
     g_comm_panels = value;
+    return 1;
+  }
+  if (key && !strcmp(key, "prof_level") && (value == 1 || value == 2)) {
+    g_prof_level = value;
     return 1;
   }
   return 0;
@@ -1597,6 +1606,7 @@ extern "C" int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const h
 // ------------------------------------------------------------------ instrumentation
 int prof_start(hfmi_ctx* ctx, int kind, int64_t m, int64_t k, int64_t N) {
   if (!ctx->profiling) return -1;
+  if (g_prof_level < 2 && 2.0 * (double)N * (double)m * (double)k < 2.0e9) return -1;
   hfmi_ctx::prof_rec r;
   r.kind = kind;
   r.m = m;
@@ -1615,7 +1625,7 @@ int prof_stop(hfmi_ctx* ctx, int idx) {
   return HFMI_OK;
 }
 static int phase_begin_on(hfmi_ctx* ctx, int phase, hipStream_t st) {
-  if (!ctx->profiling) return -1;
+  if (!ctx->profiling || g_prof_level < 2) return -1;
   hfmi_ctx::phase_rec r;
   r.phase = phase;
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
