@@ -9,7 +9,7 @@ python3 -c "import sys; sys.path.insert(0, '$R'); from hippyflow_amd import _bui
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$R/hippyflow_amd/csrc "$@" -c $R/hippyflow_amd/csrc/$tu -o $B/${tu%.hip}_$name.o || exit 1
 objs=""
 for o in $B/hfmi_*.o; do
-  case $o in *_tn[0-9]*.o|*_exp*.o) continue;; esac
+  case $o in *_tn[0-9]*.o|*_exp*.o|*_$name.o) continue;; esac
   [ "$o" = "$B/${tu%.hip}.o" ] && o=$B/${tu%.hip}_$name.o
   objs="$objs $o"
 done
