@@ -511,9 +511,13 @@ def main():
     barrier()
     pci = ctx.pci_bus_id()
     sysfs_before = gpu_sysfs_snapshot(pci) if rank == 0 else {}
-    if os.environ.get("HFMI_BENCH_PROF_LEVEL"):        # A/B of what the profiling events cost (scripts/prof_level_ab.py)
-        from hippyflow_amd import _lib as _L
-        _L.call("hfmi_tuning_set", b"prof_level", int(os.environ["HFMI_BENCH_PROF_LEVEL"]))
+    # Inside the timed region only the contractions of at least 2 Gflop are bracketed by events (what `roofline` needs): every
+    # event pair between two dependent kernels costs ~5 us of idle GPU, and with one pair per contraction and per phase the
+    # 64-sample shard step carried ~32 of them (30-70 us per step, scripts/prof_level_ab.py).  The per-phase breakdown comes from
+    # extra, untimed steps below.  HFMI_BENCH_PROF_LEVEL=2 puts everything back inside the timed region (A/B).
+    from hippyflow_amd import _lib as _L
+    timed_level = int(os.environ.get("HFMI_BENCH_PROF_LEVEL", "1"))
+    _L.call("hfmi_tuning_set", b"prof_level", timed_level)
     ctx.profile_begin()
     step_ms = []
     t0 = time.perf_counter()
@@ -526,6 +530,16 @@ def main():
     sysfs_after = gpu_sysfs_snapshot(pci) if rank == 0 else {}
     prof = ctx.profile_end()
     phases = ctx.profile_phases()
+    phase_steps = args.steps
+    if timed_level < 2:
+        _L.call("hfmi_tuning_set", b"prof_level", 2)
+        phase_steps = max(1, min(3, args.steps))
+        ctx.profile_begin()
+        for _ in range(phase_steps):
+            step()
+        barrier()
+        ctx.profile_end()
+        phases = ctx.profile_phases()
     median_ms = float(np.median(step_ms))
     if use_dist:
         elapsed = collective.allReduceMax(elapsed)   # the slowest rank's clock
@@ -570,7 +584,9 @@ def main():
     out["gpu_sysfs"] = {"pci_bus_id": pci, "before_timed_region": sysfs_before, "after_timed_region": sysfs_after}
     if literal_ms is not None:
         out["literal_T_ms_per_step"] = literal_ms
-    out["phases_ms_per_step"] = {name: ms / args.steps for name, ms in phases.items()}
+    out["phases_ms_per_step"] = {name: ms / phase_steps for name, ms in phases.items()}
+    out["phases_from"] = ("the timed steps" if timed_level >= 2 else
+                          "%d extra untimed steps with per-phase events (the timed steps carry events on the big contractions only)" % phase_steps)
 
     # roofline of the dominant kernel (= the (kernel, shape) group with the largest total time), from per-launch
     # HIP events recorded inside the timed region on the stream the kernels run on

@@ -139,6 +139,7 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_status, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
   for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_cb[i], hipEventDisableTiming));
   for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -188,6 +189,7 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipEventDestroy(ctx->ev_status);
+  (void)hipEventDestroy(ctx->ev_side);
   (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -511,6 +513,20 @@ static int read_status_begin(hfmi_ctx* ctx) {
   HIP_TRY(hipEventRecord(ctx->ev_status, ctx->stream));
   HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_status, 0));
   HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->aux_stream));
+  return HFMI_OK;
+}
+// Small device -> host copies that nothing on the main stream waits for: a copy engine / blit between two dependent kernels costs
+// the main stream 5 us of copy and 10-15 us of bubbles (timeline of the shard step), on the auxiliary stream it costs nothing.
+// side_copies_begin orders the auxiliary stream behind the current point of the main stream; the copies are then enqueued on
+// ctx->aux_stream by the caller; side_copies_end leaves an event the main stream can be made to wait for before a kernel
+// overwrites the source.
+static int side_copies_begin(hfmi_ctx* ctx) {
+  HIP_TRY(hipEventRecord(ctx->ev_status, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_status, 0));
+  return HFMI_OK;
+}
+static int side_copies_end(hfmi_ctx* ctx) {
+  HIP_TRY(hipEventRecord(ctx->ev_side, ctx->aux_stream));
   return HFMI_OK;
 }
 static void print_status_dbg(const hfmi_status_words* out);
@@ -1226,8 +1242,10 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol));
     hfmi_status_words st;
     if (deferred && !B && passes == 1 && opt && first_pass_clean) {
-      HIP_TRY(hipMemcpyAsync(opt->st2, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(hipMemcpyAsync(opt->aux, sm_ptr(ctx, SM_AUX), ((size_t)SM_LD + k) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HFMI_TRY(side_copies_begin(ctx));
+      HIP_TRY(hipMemcpyAsync(opt->st2, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->aux_stream));
+      HIP_TRY(hipMemcpyAsync(opt->aux, sm_ptr(ctx, SM_AUX), ((size_t)SM_LD + k) * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
+      HFMI_TRY(side_copies_end(ctx));                      // the eigensolver (next writer of the status words) waits for ev_side
       opt->used = true;
       opt->k = k;
       ++passes;
@@ -1568,8 +1586,15 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));
   ph = phase_begin(ctx, HFMI_PHASE_EIG);
+  if (late.used) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));   // the late-check copies read the status words (done ms ago)
   HFMI_TRY(launch_sym_eig(ctx, k, SM_T, SM_V, (double*)dv, flags & 1, (flags >> 3) & 1));
   phase_end(ctx, ph);
+  // eigenvalues and status words leave for the host now, beside the back-transformation, instead of behind it
+  void* dpin = nullptr;
+  HFMI_TRY(ctx_pinned(ctx, (size_t)r * sizeof(double), &dpin));
+  HFMI_TRY(side_copies_begin(ctx));
+  HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->aux_stream));
+  HIP_TRY(hipMemcpyAsync(dpin, dv, (size_t)r * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
   ph = phase_begin(ctx, HFMI_PHASE_BACK);
   if (deferred) {   // U = (Q R^-1) V = Q (R^-1 V)
     HFMI_TRY(launch_small_matmul(ctx, k, r, SM_RINV, SM_V, SM_TMP2));
@@ -1578,9 +1603,9 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
     HFMI_TRY(launch_tsgemm_nn(ctx, Qp->p, Qp->ld, k, sm_ptr(ctx, SM_V), SM_LD, r, 1.0, 0.0, U->p, U->ld, N));
   }
   phase_end(ctx, ph);
-  // one synchronisation for both read-backs: the status words are copied asynchronously, the eigenvalue copy waits
-  HIP_TRY(hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->stream));
-  HFMI_TRY(read_back(ctx, (const double*)dv, r, host_d));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+  memcpy(host_d, dpin, (size_t)r * sizeof(double));
   const hfmi_status_words st = *ctx->status_host;
   print_status_dbg(&st);
   if (late.used) {

@@ -67,6 +67,7 @@ struct hfmi_ctx {
   hipEvent_t ev0, ev1;
   hipStream_t aux_stream;         // status read-backs that overlap work queued on `stream`
   hipEvent_t ev_status;
+  hipEvent_t ev_side;             // small device -> host copies taken off the main stream (late QR checks, eigenvalues)
   int num_cus;
   void* ws[WS_NSLOTS];
   size_t ws_bytes[WS_NSLOTS];

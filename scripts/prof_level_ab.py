@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:] or ["--samples-total", "64"]
 for rep in range(2):
-    for lvl in ("2", "1"):
+    for lvl in ("2", "1"):   # 2 = every contraction and phase inside the timed region (the old way), 1 = the default
         env = dict(os.environ, HFMI_BENCH_PROF_LEVEL=lvl)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--no-cpu-baseline", "--no-check", "--no-literal"],
                              env=env, capture_output=True, text=True).stdout
