@@ -1,4 +1,8 @@
-"""Random-size check of the fused double pass against the CPU restatement (same Omega, same snapshot operator)."""
+"""Random-size check of the fused double pass against the CPU restatement (same Omega, same snapshot operator).
+Eigenvalues are compared relative to max(lambda, 1e-7 lambda_0): both sides solve the k x k Rayleigh-Ritz problem with a
+tridiagonalisation-based eigensolver (device divide and conquer / LAPACK), whose accuracy is ABSOLUTE (eps ||T||) -- Ritz values ten
+decades below the largest differ by 1e-8 relatively between two such solvers (HFMI_EIG=jacobi, which is relatively accurate, does
+not show it)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +25,7 @@ for it in range(ncase):
     d, U = hf.doublePass(op, hf.MultiVector.from_dense(Om), r)
     d_ref, U_ref = hp_o.double_pass_blas3(lambda W: np.asfortranarray(X.T @ (X @ W) / n), np.asfortranarray(Om), r)
     big = d_ref > 1e-10 * d_ref[0]
-    e = np.max(np.abs(d[big] - d_ref[big]) / d_ref[big]) if big.any() else 0.0
+    e = np.max(np.abs(d[big] - d_ref[big]) / np.maximum(d_ref[big], 1e-7 * d_ref[0])) if big.any() else 0.0
     Ud = U.to_dense()
     o = np.linalg.norm(Ud[:, big].T @ Ud[:, big] - np.eye(int(big.sum())))
     worst = max(worst, e)
