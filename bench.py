@@ -235,7 +235,7 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
             W_s = np.ascontiguousarray(Omega_host[:N_s, :k_s])
             Z = hp_o.as_block(Omega_host[:N_s])
             if args.workload == "as":
-                ns_s = 4
+                ns_s = max(1, min(4, wl.J.nvec() // wl.q))
                 J_s = wl.J.view(0, ns_s * wl.q).to_vectors()[:, :N_s].reshape(ns_s, wl.q, N_s).copy()
                 op = hf_o.MeanJTJOperator(J_s)
                 units, units_s = wl.ns_total, ns_s
@@ -277,7 +277,7 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
                                            "; B / B^-1 applications not included" if (prior is not None or args.workload == "kle") else ""))
             # ------------------------------------------------------------ BLAS-3 leg, full N, bounded operator sample
             if args.workload == "as":
-                ns_b = 16
+                ns_b = max(1, min(16, wl.J.nvec() // wl.q))     # this rank's share may hold fewer than 16 samples (many ranks, few samples)
                 Jh = wl.J.view(0, ns_b * wl.q).to_vectors()
                 _, t_apply = _timed(lambda: Jh.T @ (Jh @ Omega_host))
                 t_apply *= wl.ns_total / ns_b

@@ -67,11 +67,11 @@ def test_rccl_first_contact_failure_falls_back_to_p2p_by_agreement():
     assert d["transport"] == "p2p" and "librccl not usable" in d["why"] and len(d["devices"]) == 1 and d["devices"][0]
 
 
-@pytest.mark.parametrize("sync", ["host", "stream"])
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world,sync", [(2, "host"), (2, "stream"), (4, "host"), (4, "stream"), (8, "stream")])
 def test_ranks_sharing_the_gpu_p2p_transport(tmp_path, world, sync):
     """sync = "stream": the stream-ordered p2p path (arrival / completion counters in the node segment, written and polled
-    by kernels: no host synchronisation inside a collective) -- what an 8-GPU run falls back to if RCCL misbehaves."""
+    by kernels: no host synchronisation inside a collective) -- what an 8-GPU run falls back to if RCCL misbehaves.  world = 8:
+    the rank count of the node this is written for, here with all eight ranks on the one GPU of the box."""
     from hippyflow_amd.launch import spawn_ranks
     env = dict(os.environ, HFMI_COMM_TIMEOUT_S="60", HFMI_P2P_SYNC=sync)
     assert spawn_ranks([WORKER, str(tmp_path)], world, env=env, timeout=600) == 0
