@@ -26,6 +26,13 @@
 // tsgemm_tn
 // =====================================================================================
 constexpr int TN_BK = 32;   // reduction indices per LDS stage
+// the finely split tail of a launch (see the block mapping in k_tsgemm_tn); nrb = 0: none
+struct TnTail {
+  int nrb, nsplit;
+  int64_t chunk;
+  double* out;
+  int64_t si, sj, sps;
+};
 
 // Preconditions (guaranteed by the block layout, hfmi.h): lda, ldb multiples of 32 doubles, rows N..ld-1 of
 // every vector are zero, so the reduction runs over whole 32-row stages with NO masks or branches in the loop:
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
                                                                     const double* B /* not restrict: see the stage loop */, int64_t ldb, int k,
                                                                     int64_t Npad, int64_t chunk, int nrb, int nsplit,
                                                                     double* __restrict__ out, int64_t si, int64_t sj,
-                                                                    int64_t sps, int direct, int probe_arg) {
+                                                                    int64_t sps, int direct, int probe_arg, TnTail tail) {
   // timing-only diagnostic (scripts/tn_probe.py; results are garbage): compiled in only with -DHFMI_TN_PROBE
   // (HFMI_EXTRA_HIPCC_FLAGS), the production instance carries no run-time branch for it
 #ifdef HFMI_TN_PROBE
@@ -74,8 +81,24 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kk = lane >> 4;
 
-  const int logical = xcd_remap(blockIdx.x, nrb * nsplit);
-  const int sp = logical / nrb, rb = logical % nrb;
+  // Row blocks [0, nrb) are whole rounds of the CUs, each split nsplit ways over the reduction axis; the tail.nrb row blocks
+  // behind them (fewer than one round: m = 1e5 is 261 blocks of 384 rows on 256 CUs) are split tail.nsplit ways -- as finely as
+  // it takes to fill one more round of workgroups for 1 / tail.nsplit of a block's time -- and write to their own, compact
+  // partial buffer.  The two groups are remapped over the XCDs separately (see k_tsgemm_nn).
+  const int nfull = nrb * nsplit;
+  const bool in_tail = (int)blockIdx.x >= nfull;
+  const int logical = in_tail ? xcd_remap((int)blockIdx.x - nfull, tail.nrb * tail.nsplit) : xcd_remap(blockIdx.x, nfull);
+  const int sp = in_tail ? logical / tail.nrb : logical / nrb;
+  const int rb = in_tail ? nrb + logical % tail.nrb : logical % nrb;
+  if (in_tail) {
+    chunk = tail.chunk;
+    out = tail.out;
+    si = tail.si;
+    sj = tail.sj;
+    sps = tail.sps;
+    direct = 0;
+  }
+  const int row_off = in_tail ? nrb * (16 * MT * WAVES) : 0;   // the tail's partial buffer starts at its first row
   const int64_t t_begin = (int64_t)sp * chunk;
   int64_t t_end = t_begin + chunk;
   if (t_end > Npad) t_end = Npad;
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
       for (int r = 0; r < 4; ++r) {
         const int i = TR ? rowbase + mt * 16 + r16 : rowbase + mt * 16 + kk + 4 * r;
         const int j = TR ? nt * 16 + kk + 4 * r : nt * 16 + r16;
-        if (!direct || (i < m && j < k)) P[(int64_t)i * si + (int64_t)j * sj] = acc[mt][nt][r];
+        if (!direct || (i < m && j < k)) P[(int64_t)(i - row_off) * si + (int64_t)j * sj] = acc[mt][nt][r];
       }
   if constexpr (R4 > 0) {
     // 4x4x4 results: lane 16 i + 4 g + j holds (row 4 g + i of the tile, column 4 q + j of the last tile)
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
       for (int q = 0; q < R4; ++q) {
         const int i = rowbase + mt * 16 + 4 * g4 + i4;
         const int j = NTF * 16 + 4 * q + j4;
-        if (!direct || (i < m && j < k)) P[(int64_t)i * si + (int64_t)j * sj] = acc4[mt][q];
+        if (!direct || (i < m && j < k)) P[(int64_t)(i - row_off) * si + (int64_t)j * sj] = acc4[mt][q];
       }
   }
 }
@@ -417,8 +440,14 @@ struct TnOut {
   bool direct;
   double* C;
   int64_t rs, cs;
+  // tail plan (tn_panel): row blocks beyond the whole rounds, their split and their compact partial buffer
+  int tail_nrb, tail_nsplit;
+  int64_t tail_chunk;
+  double* tail_part;
+  int tail_mpad;
 };
 static int g_ss = 1;                                 // route skinny x skinny contractions to tsgemm_ss (hfmi_skinny.hip)
+static int g_tn_hybrid = 1;                          // tsgemm_tn: whole rounds of row blocks coarsely split + a finely split tail (A/B: "tn_hybrid")
 static void tuning_init() {
   if (g_waves) return;
   const char* e = getenv("HFMI_GEMM_WAVES");
@@ -438,6 +467,7 @@ extern "C" int hfmi_tuning_set(const char* key, int value) {
   else if (key && api_tuning_set(key, value)) {}
   else if (key && !strcmp(key, "ss") && (value == 0 || value == 1)) g_ss = value;
   else if (key && !strcmp(key, "probe")) g_probe = value;
+  else if (key && !strcmp(key, "tn_hybrid") && (value == 0 || value == 1)) g_tn_hybrid = value;
   else if (key && !strcmp(key, "tn_mt") && value >= 0 && value <= 8) g_tn_mt = value;   // A/B: wave tile height of tsgemm_tn (0 = automatic)
   else if (key && !strcmp(key, "ss_percu") && value >= 1 && value <= 4) tsgemm_ss_set_percu(value);
   else if (key && !strcmp(key, "ss_blocked") && value >= 0 && value <= 2) tsgemm_ss_set_blocked(value);
@@ -459,8 +489,9 @@ static int tn_launch_one(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   double* out = o.direct ? o.C : part;
   const int64_t si = o.direct ? o.rs : (TR ? 1 : kpad), sj = o.direct ? o.cs : (TR ? mpad : 1);
-  hipLaunchKernelGGL(kern, dim3(nrb * nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k, N, chunk, nrb,
-                     nsplit, out, si, sj, (int64_t)mpad * kpad, o.direct ? 1 : 0, g_probe);
+  TnTail tail = {o.tail_nrb, o.tail_nsplit, o.tail_chunk, o.tail_part, TR ? 1 : kpad, TR ? o.tail_mpad : 1, (int64_t)o.tail_mpad * kpad};
+  hipLaunchKernelGGL(kern, dim3(nrb * nsplit + o.tail_nrb * o.tail_nsplit), dim3(WAVES * 64), shmem, ctx->stream, A, lda, m, B, ldb, k,
+                     N, chunk, nrb, nsplit, out, si, sj, (int64_t)mpad * kpad, o.direct ? 1 : 0, g_probe, tail);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
@@ -547,6 +578,88 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
     nsplit = best;
   }
   const int64_t stage_len = TN_BK;
+  // Hybrid plan: when the row blocks make at least one whole round of the CUs, the rounds that ARE whole need no fine split at
+  // all (ns_full = 1 or 2: their partial traffic is a single slice or none) and only the blocks beyond them are split finely
+  // enough to fill one more round for 1 / ns_tail of a block's time.  m = 1e5 (config 2): 261 blocks = 256 whole + 5 x 51 instead
+  // of 261 x 19 (the uniform plan's best: 3 % quantisation loss, 1.5 GB of partials written and read back, a 0.3 ms reduction);
+  // m = 51200 (config 4): 128 x 2 + 6 x 42 instead of 134 x 21 (0.7 GB of partials, 0.12 ms).
+  const bool can_direct = (scale == 1.0 && beta == 0.0 && C != A && C != B);
+  int ns_full = 0, nrb_full = 0, ns_tail = 0;
+  if (nsplit_req <= 0 && g_tn_hybrid) {
+    const int64_t stages = Npad / TN_BK;
+    const double ideal = (double)nrb / cus;
+    const double part_unit = 2.0 * (double)rows_per_block * kpad / ((double)N * (m + k));   // one slice of one row block
+    double uniform_cost;
+    {
+      const int64_t blocks = (int64_t)nrb * nsplit;
+      const int64_t rounds = (blocks + cus - 1) / cus;
+      uniform_cost = (double)(rounds * cus) / (double)blocks + part_unit * nsplit * nrb;
+    }
+    double best_cost = uniform_cost;
+    static const int cand[] = {1, 2, 3, 4, 6, 8};
+    for (int ci = 0; ci < 6; ++ci) {
+      const int nsf = cand[ci];
+      if (nsf > 1 && stages / nsf < 16) break;
+      const int64_t R = ((int64_t)nrb * nsf) / cus;            // whole rounds of full-region workgroups
+      if (R < 1 || (R * cus) % nsf != 0) continue;
+      const int nf = (int)(R * cus / nsf);
+      const int nt_blocks = nrb - nf;
+      if (nt_blocks <= 0) continue;                             // the uniform plan already is this one
+      int nst = cus / nt_blocks;
+      if (nst > stages / 16) nst = (int)(stages / 16);
+      if (nst > 128) nst = 128;
+      if (nst < 1) nst = 1;
+      const int64_t tail_rounds = ((int64_t)nt_blocks * nst + cus - 1) / cus;
+      const double time = (double)R / nsf + (double)tail_rounds / nst;
+      const double parts = part_unit * ((nsf == 1 && can_direct ? 0.0 : (double)nsf * nf) + (double)nst * nt_blocks);
+      const double cost = time / ideal + parts;
+      if (cost < best_cost - 1e-9) {
+        best_cost = cost;
+        ns_full = nsf;
+        nrb_full = nf;
+        ns_tail = nst;
+      }
+    }
+  }
+  const int rem = k - (nt - 1) * 16;
+  const int r4 = (g_rem4 && waves == 8 && rem <= 12) ? (rem + 3) / 4 : 0;
+  if (ns_full > 0) {
+    const int nrb_t = nrb - nrb_full;
+    const int mpad_f = nrb_full * rows_per_block, mpad_t = nrb_t * rows_per_block;
+    int64_t chunk_f = round_up((Npad + ns_full - 1) / ns_full, stage_len);
+    ns_full = (int)((Npad + chunk_f - 1) / chunk_f);
+    int64_t chunk_t = round_up((Npad + ns_tail - 1) / ns_tail, stage_len);
+    ns_tail = (int)((Npad + chunk_t - 1) / chunk_t);
+    const bool direct_f = ns_full == 1 && can_direct;
+    const size_t full_doubles = direct_f ? 0 : (size_t)ns_full * mpad_f * kpad;
+    void* partv = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_PART, (full_doubles + (size_t)ns_tail * mpad_t * kpad) * sizeof(double), &partv));
+    double* part_f = (double*)partv;
+    double* part_t = part_f + full_doubles;
+    const TnOut o = {direct_f, C, rs, cs, nrb_t, ns_tail, chunk_t, part_t, mpad_t};
+    const int pidx = prof_start(ctx, 0, m, k, N);
+#define TN_NT(NTV)                                                                                                       \
+  case NTV:                                                                                                              \
+    if (waves == 8)                                                                                                      \
+      HFMI_TRY((tn_dispatch_mt<NTV, 8>(ctx, mt, tr, r4, A, lda, m, B, ldb, k, Npad, chunk_f, nrb_full, ns_full, part_f, mpad_f, kpad, o))); \
+    else                                                                                                                 \
+      HFMI_TRY((tn_dispatch_mt<NTV, 4>(ctx, mt, tr, 0, A, lda, m, B, ldb, k, Npad, chunk_f, nrb_full, ns_full, part_f, mpad_f, kpad, o))); \
+    break;
+    switch (nt) {
+      TN_NT(1) TN_NT(2) TN_NT(3) TN_NT(4) TN_NT(5) TN_NT(6) TN_NT(7) TN_NT(8) TN_NT(9) TN_NT(10) TN_NT(11) TN_NT(12)
+      TN_NT(13) TN_NT(14) TN_NT(15) TN_NT(16)
+      default:
+        HFMI_FAIL(HFMI_ERR_INVALID, "tsgemm_tn: panel too wide (%d)", k);
+    }
+#undef TN_NT
+    prof_stop(ctx, pidx);
+    const int m_full = mpad_f;                        // every row of the whole rounds is a real row (only the last block is ragged)
+    if (!direct_f)
+      HFMI_TRY(launch_reduce_partials(ctx, part_f, ns_full, (int64_t)mpad_f * kpad, tr ? mpad_f : kpad, tr, m_full, k, scale, beta, C,
+                                      rs, cs));
+    return launch_reduce_partials(ctx, part_t, ns_tail, (int64_t)mpad_t * kpad, tr ? mpad_t : kpad, tr, m - m_full, k, scale, beta,
+                                  C + (int64_t)m_full * rs, rs, cs);
+  }
   int64_t chunk = round_up((Npad + nsplit - 1) / nsplit, stage_len);
   if (chunk < stage_len) chunk = stage_len;
   nsplit = (int)((Npad + chunk - 1) / chunk);
@@ -556,10 +669,8 @@ static int tn_panel(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const do
   double* part = (double*)partv;
   // algorithmic work of this launch: flops 2 N m k, bytes 8 (N m + N k + m k)
   // columns of the last tile: up to 12 are done as 1..3 groups of 4 with the 4x4x4 MFMA (16 instead of 64 cycles each)
-  const int rem = k - (nt - 1) * 16;
-  const int r4 = (g_rem4 && waves == 8 && rem <= 12) ? (rem + 3) / 4 : 0;
-  const bool direct = (nsplit == 1 && scale == 1.0 && beta == 0.0 && C != A && C != B);   // blocks never overlap partially
-  const TnOut o = {direct, C, rs, cs};
+  const bool direct = (nsplit == 1 && can_direct);   // blocks never overlap partially
+  const TnOut o = {direct, C, rs, cs, 0, 0, 0, nullptr, 0};
   const int pidx = prof_start(ctx, 0, m, k, N);
 #define TN_NT(NTV)                                                                                                       \
   case NTV:                                                                                                              \

@@ -290,6 +290,7 @@ int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, double* hbm_c
  * tsgemm_ss; ("ss_percu", 1..4) resident tsgemm_ss workgroups per CU assumed when the grid is sized; ("eig", 0|1) Rayleigh-Ritz
  * eigensolver of every call: divide and conquer | Jacobi; ("chol", 0|1) Cholesky + inverse of the QR passes: blocked MFMA kernel |
  * column-at-a-time kernels; ("nn_res_tt", 0|1|2) tile height of the LDS-resident nn product: by round count | table | one less;
+ * ("tn_hybrid", 0|1) tsgemm_tn with more row blocks than CUs: uniform split | whole rounds coarsely split + finely split tail;
  * ("prof_level", 1|2) what a profiling region records: 2 = every contraction and every phase (default), 1 = contractions of at
  * least 2 Gflop only (each record is a pair of stream events, 2-4 us of idle GPU between dependent kernels: scripts/prof_level_ab.py);
  * ("comm_panels", 0..8) row panels of an operator application whose

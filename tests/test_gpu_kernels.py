@@ -265,6 +265,40 @@ def test_csr_irregular_rows_use_the_csr_kernel(ctx, k):
     assert rel(Z.to_dense(), spla.splu(arrow.tocsc()).solve(X)) < 1e-10
 
 
+@pytest.mark.parametrize("m,k,N", [(100003, 9, 2048), (51277, 20, 1024), (70000, 74, 512)])
+def test_tn_hybrid_plan_whole_rounds_plus_split_tail(ctx, m, k, N):
+    """tsgemm_tn with more row blocks than CUs: the blocks that make whole rounds are split coarsely (or not at all and written
+    straight to the result), the ragged rest finely, into its own partial buffer.  Against the uniform split (tuning
+    "tn_hybrid" = 0) and numpy, through the row-major result of block_dot and through the scaled, column-major one of a
+    snapshot-Gram apply."""
+    from hippyflow_amd import _lib as L
+    A = hf.MultiVector(N, m)
+    B = hf.MultiVector(N, k)
+    hf.parRandom.reseed(m)
+    hf.parRandom.normal(1.0, A)
+    hf.parRandom.normal(1.0, B)
+    Ad, Bd = A.to_dense(), B.to_dense()
+    ref = Ad.T @ Bd
+    out, app = {}, {}
+    for hyb in (0, 1):
+        L.call("hfmi_tuning_set", b"tn_hybrid", hyb)
+        try:
+            out[hyb] = A.dot_mv(B)
+            if k >= 20:      # Y = X^T (X W) / m with the m "snapshots" as the vectors of A: the first half is the scaled tn launch
+                op = hf.SnapshotGramOperator(A)
+                Y = hf.MultiVector(N, k)
+                op.matMvMult(B, Y)
+                app[hyb] = Y.to_dense()
+        finally:
+            L.call("hfmi_tuning_set", b"tn_hybrid", 1)
+    scale = np.abs(ref).max()
+    assert np.abs(out[1] - ref).max() < 1e-13 * scale * np.sqrt(N)
+    assert np.abs(out[1] - out[0]).max() < 1e-13 * scale * np.sqrt(N)
+    if app:
+        refY = Ad @ (Ad.T @ Bd) / m
+        assert rel(app[1], refY) < 1e-12 and rel(app[1], app[0]) < 1e-13
+
+
 def test_resident_nn_product_is_independent_of_the_tile_height(ctx):
     """Q R^-1 with the small matrix resident in LDS: the tile height is chosen by the number of rounds the persistent
     workgroups need (N = 2e5, k = 74: two 16-row tiles per wave instead of three); the choice moves rows between waves and
