@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
     """Compile every translation unit for gfx950 and link hippyflow_amd/libhfmi.so."""
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "hfmi_internal.h"), os.path.join(CSRC, "hfmi_gemm_common.h"), os.path.join(INCLUDE, "hfmi.h")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(INCLUDE, "hfmi.h")]
     tag = source_tag()
     tag_file = os.path.join(OBJDIR, "source_tag.txt")
     tag_changed = not os.path.exists(tag_file) or open(tag_file).read().strip() != tag

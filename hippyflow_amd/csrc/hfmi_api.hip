@@ -579,7 +579,7 @@ extern "C" int hfmi_block_fill_matern32(hfmi_block* C, int nx, int ny, double si
 extern "C" int hfmi_philox_raw(hfmi_block* shape_of, uint64_t seed, uint32_t stream, uint32_t* host_out) {
   if (!shape_of || !host_out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   hfmi_ctx* ctx = shape_of->ctx;
-  const size_t words = (size_t)shape_of->nvec * ((shape_of->N + 1) / 2) * 4;
+  const size_t words = (size_t)shape_of->nvec * ((shape_of->N + 3) / 4) * 4;
   void* dev = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_STAGE, words * sizeof(uint32_t), &dev));
   HFMI_TRY(launch_philox_raw(ctx, (uint32_t*)dev, shape_of->N, shape_of->nvec, seed, stream));

@@ -2,6 +2,7 @@
 // CSR SpMM, per-vector dot products and the fused vector updates of the block PCG, plus the
 // micro-benchmarks that measure the roofline denominators in the same job.
 #include "hfmi_internal.h"
+#include "hfmi_randn_math.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -142,63 +143,66 @@ int launch_axpy(hfmi_ctx* ctx, double* y, int64_t ldy, double alpha, const doubl
 }
 
 // ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
-// Element map documented in oracle/philox.py (the checker): ctr = (p lo, p hi, column, stream),
-// key = (seed lo, seed hi); rows 2p and 2p+1 of the column come from one counter.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-  for (int rnd = 0; rnd < 10; ++rnd) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__global__ void k_randn(double* __restrict__ p, int64_t N, int nvec, int64_t ld, uint32_t k0, uint32_t k1, uint32_t stream, double sigma) {
-  const int64_t npairs = (N + 1) / 2;
+// hfmi_randn_math.h: the integer generator, the range-specific fp64 functions and the element map (four normals per
+// Philox output, rows 4g .. 4g+3 of column j from counter (g, j, stream)).  Thread = one row group per step, one 32-byte
+// store; a wave writes 2 KiB contiguous.  VEC = false: blocks wrapped around foreign memory whose columns are not
+// 32-byte aligned.
+using hfmi_rng::philox4x32_10;
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_randn(double* __restrict__ p, int64_t N, int nvec, int64_t ld, uint32_t k0, uint32_t k1,
+                                               uint32_t stream, double sigma) {
+  const int64_t nfull = N >> 2, ngroups = (N + 3) >> 2;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  const hfmi_rng::normal_consts kc = hfmi_rng::make_consts(sigma);
   for (int j = blockIdx.y; j < nvec; j += gridDim.y) {
     double* c = p + (int64_t)j * ld;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; g < nfull; g += step) {
       uint32_t x[4];
-      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)j, stream, k0, k1, x);
-      const uint64_t a = (((uint64_t)x[1] << 32) | x[0]) >> 11;
-      const uint64_t b = (((uint64_t)x[3] << 32) | x[2]) >> 11;
-      const double u1 = ((double)a + 0.5) * 0x1.0p-53;
-      const double u2 = ((double)b + 0.5) * 0x1.0p-53;
-      const double rad = sigma * sqrt(-2.0 * log(u1));
-      double sn, cs;
-      sincospi(2.0 * u2, &sn, &cs);
-      const int64_t t = 2 * q;
-      if (t + 1 < N) *reinterpret_cast<d2*>(c + t) = d2{rad * cs, rad * sn};
-      else c[t] = rad * cs;
+      double z[4];
+      philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)j, stream, k0, k1, x);
+      hfmi_rng::box_muller4(x, kc, z);
+      if (VEC) *reinterpret_cast<d4*>(c + 4 * g) = d4{z[0], z[1], z[2], z[3]};
+      else { c[4 * g] = z[0]; c[4 * g + 1] = z[1]; c[4 * g + 2] = z[2]; c[4 * g + 3] = z[3]; }
+    }
+    if (g < ngroups) {   // the ragged last group: one thread of the grid
+      uint32_t x[4];
+      double z[4];
+      philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)j, stream, k0, k1, x);
+      hfmi_rng::box_muller4(x, kc, z);
+      for (int i = 0; i < 3; ++i) if (4 * g + i < N) c[4 * g + i] = z[i];
     }
   }
 }
+static inline dim3 randn_grid(int64_t N, int nvec) {
+  const int64_t ngroups = (N + 3) / 4;
+  int64_t gx = (ngroups + 256 * 4 - 1) / (256 * 4);   // ~4 row groups per thread
+  if (gx < 1) gx = 1;
+  if (gx > 4096) gx = 4096;
+  return dim3((unsigned)gx, (unsigned)(nvec < 1024 ? nvec : 1024));
+}
 int launch_randn(hfmi_ctx* ctx, double* p, int64_t N, int nvec, int64_t ld, uint64_t seed, uint32_t stream, double sigma) {
   if (N <= 0 || nvec <= 0) return HFMI_OK;
-  hipLaunchKernelGGL(k_randn, ew_grid(N, nvec), dim3(256), 0, ctx->stream, p, N, nvec, ld, (uint32_t)seed, (uint32_t)(seed >> 32), stream, sigma);
+  if (sigma == 0.0) return launch_fill(ctx, p, N, nvec, ld, 0.0, false);
+  const bool vec = ((uintptr_t)p % 32 == 0) && (ld % 4 == 0 || nvec == 1);
+  if (vec) hipLaunchKernelGGL(k_randn<true>, randn_grid(N, nvec), dim3(256), 0, ctx->stream, p, N, nvec, ld, (uint32_t)seed, (uint32_t)(seed >> 32), stream, sigma);
+  else hipLaunchKernelGGL(k_randn<false>, randn_grid(N, nvec), dim3(256), 0, ctx->stream, p, N, nvec, ld, (uint32_t)seed, (uint32_t)(seed >> 32), stream, sigma);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
-__global__ void k_philox_raw(uint32_t* __restrict__ out, int64_t npairs, int nvec, uint32_t k0, uint32_t k1, uint32_t stream) {
+// the raw integer stream behind the draw: out[(j * ngroups + g) * 4 + 0..3], ngroups = ceil(N / 4)
+__global__ void k_philox_raw(uint32_t* __restrict__ out, int64_t ngroups, int nvec, uint32_t k0, uint32_t k1, uint32_t stream) {
   for (int j = blockIdx.y; j < nvec; j += gridDim.y)
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * blockDim.x) {
       uint32_t x[4];
-      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)j, stream, k0, k1, x);
-      uint32_t* o = out + ((int64_t)j * npairs + q) * 4;
+      philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)j, stream, k0, k1, x);
+      uint32_t* o = out + ((int64_t)j * ngroups + g) * 4;
       o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3];
     }
 }
 int launch_philox_raw(hfmi_ctx* ctx, uint32_t* out, int64_t N, int nvec, uint64_t seed, uint32_t stream) {
   if (N <= 0 || nvec <= 0) return HFMI_OK;
-  hipLaunchKernelGGL(k_philox_raw, ew_grid(N, nvec), dim3(256), 0, ctx->stream, out, (N + 1) / 2, nvec, (uint32_t)seed, (uint32_t)(seed >> 32), stream);
+  hipLaunchKernelGGL(k_philox_raw, randn_grid(N, nvec), dim3(256), 0, ctx->stream, out, (N + 3) / 4, nvec, (uint32_t)seed, (uint32_t)(seed >> 32), stream);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }

@@ -104,9 +104,11 @@ int hfmi_block_norms(const hfmi_block* b, double* host_norms);      /* MultiVect
 /* a1: the probe draw -- hp.parRandom.normal(sigma, Omega)
  * (activeSubspaceProjector.py:433-443,536-551; PODProjector.py:365-374;
  * KLEProjector.py:151-160).  Counter-based Philox4x32-10 + Box-Muller: every GPU
- * regenerates the same Omega from (seed, stream), replacing collective.bcast. */
+ * regenerates the same Omega from (seed, stream), replacing collective.bcast.
+ * Rows 4g .. 4g+3 of vector j come from the counter (g, j, stream) under the key
+ * seed: four 32-bit uniforms -> two radius/angle pairs (oracle/philox.py). */
 int hfmi_randn_fill(hfmi_block* b, uint64_t seed, uint32_t stream, double sigma);
-/* the raw 32-bit stream behind it (bit-exact parity test): out[nvec][ceil(N/2)][4] */
+/* the raw 32-bit stream behind it (bit-exact parity test): out[nvec][ceil(N/4)][4] */
 int hfmi_philox_raw(hfmi_block* shape_of, uint64_t seed, uint32_t stream, uint32_t* host_out);
 
 /* synthetic config-2 input: C (N x N block) = Matern-3/2 covariance

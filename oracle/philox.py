@@ -16,11 +16,13 @@ broadcast.  This file is the checker for that generator:
   the Random123 known-answer vectors in ``tests/test_oracle_philox.py``;
 * the normals are compared to a few ulp (device log/sincos differ from libm).
 
-Element map (shared with ``hippyflow_amd/csrc``): for column j and row pair p
-(rows 2p, 2p+1):  ctr = (p & 0xffffffff, p >> 32, j, stream), key = (seed &
-0xffffffff, seed >> 32);  x = philox4x32_10(ctr, key);
-u1 = ((x0 | x1<<32) >> 11) + 0.5) * 2^-53,  u2 likewise from (x2, x3);
-r = sqrt(-2 ln u1);  row 2p = r cos(2 pi u2),  row 2p+1 = r sin(2 pi u2).
+Element map (shared with ``hippyflow_amd/csrc/hfmi_randn_math.h``): for column j and row group g
+(rows 4g .. 4g+3):  ctr = (g & 0xffffffff, g >> 32, j, stream), key = (seed &
+0xffffffff, seed >> 32);  x = philox4x32_10(ctr, key);  u(x) = (x + 0.5) * 2^-32
+(the 32-bit uniform lattice of hipRAND / cuRAND's Philox normal draws: four
+normals per generator call, |z| <= 6.76);
+rows 4g, 4g+1 = sqrt(-2 ln u(x0)) * (cos, sin)(2 pi u(x1)),
+rows 4g+2, 4g+3 = sqrt(-2 ln u(x2)) * (cos, sin)(2 pi u(x3)).
 """
 import numpy as np
 
@@ -50,25 +52,24 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def raw_block(N, k, seed, stream=0):
-    """uint32 array (k, npairs, 4): the integer stream behind randn_block."""
-    npairs = (N + 1) // 2
-    p = np.arange(npairs, dtype=np.uint64)[None, :]
+    """uint32 array (k, ngroups, 4), ngroups = ceil(N / 4): the integer stream behind randn_block."""
+    ngroups = (N + 3) // 4
+    g = np.arange(ngroups, dtype=np.uint64)[None, :]
     j = np.arange(k, dtype=np.uint64)[:, None]
     seed = int(seed)
-    x = philox4x32_10(p & _MASK, p >> _S32, j, np.uint64(stream & 0xFFFFFFFF),
+    x = philox4x32_10(g & _MASK, g >> _S32, j, np.uint64(stream & 0xFFFFFFFF),
                       np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF))
     return np.stack(x, axis=-1)
 
 
 def randn_block(N, k, seed, stream=0, sigma=1.0):
     """(N, k) Fortran-ordered block of i.i.d. N(0, sigma^2)."""
-    x = raw_block(N, k, seed, stream).astype(np.uint64)
-    a = (x[..., 0] | (x[..., 1] << _S32)) >> np.uint64(11)
-    b = (x[..., 2] | (x[..., 3] << _S32)) >> np.uint64(11)
-    u1 = (a.astype(np.float64) + 0.5) * 2.0 ** -53
-    u2 = (b.astype(np.float64) + 0.5) * 2.0 ** -53
-    r = np.sqrt(-2.0 * np.log(u1))
-    z = np.empty((k, 2 * u1.shape[1]))
-    z[:, 0::2] = r * np.cos(2.0 * np.pi * u2)
-    z[:, 1::2] = r * np.sin(2.0 * np.pi * u2)
+    x = raw_block(N, k, seed, stream).astype(np.float64)
+    u = (x + 0.5) * 2.0 ** -32
+    z = np.empty((k, 4 * u.shape[1]))
+    for half in (0, 1):
+        r = np.sqrt(-2.0 * np.log(u[..., 2 * half]))
+        ang = 2.0 * np.pi * u[..., 2 * half + 1]
+        z[:, 2 * half::4] = r * np.cos(ang)
+        z[:, 2 * half + 1::4] = r * np.sin(ang)
     return np.asfortranarray(sigma * z[:, :N].T)

@@ -22,7 +22,7 @@ def test_stream_layout_is_shard_independent():
     the property that replaces the reference's Omega broadcast
     (activeSubspaceProjector.py:443,551)."""
     full = raw_block(1001, 7, seed=0x1234567890ABCDEF, stream=3)
-    assert full.shape == (7, 501, 4)
+    assert full.shape == (7, 251, 4)
     sub = philox4x32_10(np.uint64(250), 0, np.uint64(5), 3, 0x90ABCDEF, 0x12345678)
     assert tuple(int(v) for v in sub) == tuple(int(v) for v in full[5, 250])
 
