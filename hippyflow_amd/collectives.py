@@ -87,6 +87,13 @@ class _Collective:
 
     name = "collective"
 
+    def _split_random(self):
+        """hp.parRandom is seeded per process; here the process-wide generator's PRIVATE streams are keyed by this
+        communicator's rank (the sample-parallel rank), so that the Monte-Carlo draws of the ranks differ while shared
+        draws (probe blocks) stay identical (randomized._ParRandom)."""
+        from .randomized import parRandom
+        parRandom.split(self.rank())
+
     # ---- reductions
     def allReduce(self, v, op):
         code = _reduce_code(op, self.name + ".allReduce")
@@ -197,6 +204,7 @@ class NativeCollective(_Collective):
         n, r, t = C.c_int(0), C.c_int(0), C.c_int(0)
         L.call("hfmi_comm_info", self._comm, C.byref(n), C.byref(r), C.byref(t))
         self._size, self._rank, self.transport = n.value, r.value, self.TRANSPORTS.get(t.value, str(t.value))
+        self._split_random()
 
     # ---- construction
     @staticmethod
@@ -298,6 +306,7 @@ class TorchCollective(_Collective):
         self.is_serial_check = is_serial_check
         if not dist.is_initialized():
             raise RuntimeError("TorchCollective: torch.distributed is not initialised")
+        self._split_random()
 
     def size(self):
         return self.dist.get_world_size(self.group)
@@ -386,20 +395,78 @@ class TorchCollective(_Collective):
         return self._block_collective(mv, lambda t: self.dist.broadcast(t, src=root, group=self.group))
 
 
+def _is_mpi_comm(comm):
+    return all(hasattr(comm, m) for m in ("Get_size", "Get_rank", "bcast"))
+
+
+def _native_over_mpi(comm, is_serial_check=False):
+    """A ``NativeCollective`` for the ranks of an mpi4py communicator: rank 0 makes the communicator id and mpi4py
+    carries its 256 bytes -- the only use of MPI; every reduction afterwards is RCCL / the device fabric."""
+    if comm.Get_size() == 1:
+        return NullCollective()
+    id_bytes = comm.bcast(NativeCollective.unique_id() if comm.Get_rank() == 0 else None, root=0)
+    coll = NativeCollective.from_unique_id(id_bytes, comm.Get_size(), comm.Get_rank())
+    coll.is_serial_check = is_serial_check
+    return coll
+
+
 def MultipleSamePartitioningPDEsCollective(comm=None, is_serial_check=False):
     """The reference's constructor name (collective.py:43).  ``comm``: None = the ranks of this launch
-    (``NativeCollective.from_env``), an existing collective (returned), or a torch.distributed group."""
+    (``NativeCollective.from_env``), an existing collective (returned), an mpi4py communicator such as the one
+    ``splitCommunicators`` hands back (a native communicator is bootstrapped over it), or a torch.distributed group."""
     if comm is None:
         coll = NativeCollective.from_env()
         coll.is_serial_check = is_serial_check
         return coll
     if isinstance(comm, (_Collective, NullCollective)):
         return comm
+    if _is_mpi_comm(comm):
+        return _native_over_mpi(comm, is_serial_check)
     return TorchCollective(comm, is_serial_check=is_serial_check)
 
 
 def MultipleSerialPDEsCollective(comm=None):
     return MultipleSamePartitioningPDEsCollective(comm, is_serial_check=True)
+
+
+class _SelfCommunicator:
+    """The mesh communicator of a rank that owns its whole mesh (``MPI.COMM_SELF`` without mpi4py)."""
+    rank = 0
+    size = 1
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 1
+
+
+def splitCommunicators(comm_world, n_subdomain, n_instances):
+    """(mesh_constructor_comm, collective_comm) as collectives/comm_utils.py:19-40 returns them, for the only layout
+    that exists with one process per GPU: NO mesh partitioning (``n_subdomain == 1``), every rank a sampling instance.
+    The mesh communicator is then the rank itself and the collective communicator is the world: with an mpi4py world
+    both are made by ``Split`` exactly as in the reference (color / key as there); with ``comm_world=None`` or an
+    ``hfmi`` / torch communicator the world is handed back for ``MultipleSamePartitioningPDEsCollective`` to wrap."""
+    if int(n_subdomain) != 1:
+        raise NotImplementedError("splitCommunicators: n_subdomain = %d -- mesh-partitioned PDE solves are host (FEniCS) "
+                                  "territory; one process per GPU shards samples only (n_subdomain = 1)" % n_subdomain)
+    if comm_world is None:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert world == int(n_instances), "world size %d != n_subdomain * n_instances = %d" % (world, n_instances)
+        return _SelfCommunicator(), None
+    size = comm_world.Get_size() if hasattr(comm_world, "Get_size") else comm_world.size()
+    rank = comm_world.Get_rank() if hasattr(comm_world, "Get_rank") else comm_world.rank()
+    assert size == int(n_subdomain) * int(n_instances)
+    if hasattr(comm_world, "Split"):
+        color, key = rank // int(n_subdomain), rank % int(n_subdomain)
+        return comm_world.Split(color=color, key=key), comm_world.Split(color=key, key=color)
+    return _SelfCommunicator(), comm_world
+
+
+def checkMeshConsistentPartitioning(mesh, collective):
+    """comm_utils.py:63-75 asks whether every sampling instance partitioned its mesh the same way.  Without mesh
+    partitioning (see ``splitCommunicators``) there is one partition: consistent by construction."""
+    return True
 
 
 class CollectiveOperator:

@@ -23,6 +23,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
+from . import hostvec as H
 from .multivector import MultiVector, Vector
 
 
@@ -245,37 +246,56 @@ class CsrPCGSolver(DeviceOperator):
 class HostCallbackOperator(DeviceOperator):
     """A host black box plugged into the device solve (FEniCS/hIPPYlib PDE solves stay on the host).
 
-    ``fn`` is one of: a callable mapping an (N, k) array to an (N, k) array; an object with
-    ``matMvMult_np(X) -> Y`` or (solvers) ``solve_block(X) -> Y`` on (N, k) arrays; an object with ``solve(y, x)`` or
-    ``mult(x, y)`` on 1-D numpy arrays (applied column by column, like hp.MatMvMult's fallback loop).
+    ``fn`` is, in this order of preference:
+
+    * numpy fast paths -- a plain callable mapping an (N, k) array to an (N, k) array; an object with
+      ``matMvMult_np(X) -> Y`` or (solvers) ``solve_block(X) -> Y`` on (N, k) arrays;
+    * the REFERENCE'S OWN PROTOCOL -- an object whose vectors can be shaped (``init_vector(x, dim)`` on the object, on
+      its ``operator()`` / ``get_operator()`` as hp.Solver2Operator looks it up, or passed as ``init_vector=``): the
+      slab is moved column by column into host vectors made by ``hostvec.new_host_vector`` + that ``init_vector``
+      through ``set_local`` and the result read back with ``get_local`` (how collectives/collective.py:98-107 moves
+      data), calling ``fn.matMvMult(X, Y)`` with host column lists when the object has the block form (Y arrives
+      zeroed: the reference's block operators accumulate, activeSubspaceProjector.py:214-221), else ``fn.mult(x, y)`` /
+      ``fn.solve(y, x)`` per column -- so ``prior.R``, ``prior.Rsolver``, ``JTJ(ObservableJacobian(obs))``, PETSc
+      matrices and Krylov solvers plug in as they are;
+    * objects with ``solve(y, x)`` / ``mult(x, y)`` on 1-D numpy arrays and no ``init_vector`` (numpy test doubles).
 
     ``chunk_vectors``: for black boxes that treat the vectors independently (solvers), the callback is invoked on
     slabs of that many vectors and the PCIe copies of the neighbouring slabs overlap the host work
     (``hfmi_op_host_set_chunk``).  Default: solver-like objects (``solve`` / ``solve_block``) 32, everything else the
     whole block in one call (a serialized-sampling Jacobian operator re-solves its PDEs on every call)."""
 
-    def __init__(self, fn, N, ctx=None, chunk_vectors=None):
-        super().__init__(ctx, N)
+    def __init__(self, fn, N=None, ctx=None, chunk_vectors=None, init_vector=None):
         self.fn = fn
         self.error = None
         solver_like = hasattr(fn, "solve") or hasattr(fn, "solve_block")
+        shaper = init_vector
+        if shaper is None and not (hasattr(fn, "matMvMult_np") or hasattr(fn, "solve_block")):
+            shaper = H.find_init_vector(fn)
+        plain_callable = callable(fn) and not hasattr(fn, "mult") and not hasattr(fn, "matMvMult") and not solver_like
+        if plain_callable:
+            self.mode = "array"
+        elif hasattr(fn, "matMvMult_np"):
+            self.mode = "block_np"
+        elif hasattr(fn, "solve_block"):
+            self.mode = "solve_np"
+        elif shaper is not None:
+            self.mode = "block" if hasattr(fn, "matMvMult") else ("solve" if hasattr(fn, "solve") else "mult")
+        else:
+            self.mode = "solve_1d" if hasattr(fn, "solve") else "mult_1d"
+        self._shaper = shaper
+        self._x = self._y = None           # host vectors, shaped on first use (domain, range)
+        if N is None:
+            if shaper is None:
+                raise ValueError("HostCallbackOperator: the vector length is needed to wrap an operator without init_vector")
+            N = H.shape_with(shaper, 0, self._comm()).size()
+        super().__init__(ctx, N)
 
         def _cb(user, w_ptr, y_ptr, n, k):
             try:
                 W = np.ctypeslib.as_array(w_ptr, shape=(k, n))    # one vector per row
                 Y = np.ctypeslib.as_array(y_ptr, shape=(k, n))
-                if callable(fn) and not hasattr(fn, "mult") and not solver_like:
-                    Y[...] = np.asarray(fn(W.T)).T
-                elif hasattr(fn, "matMvMult_np"):
-                    Y[...] = np.asarray(fn.matMvMult_np(W.T)).T
-                elif hasattr(fn, "solve_block"):
-                    Y[...] = np.asarray(fn.solve_block(W.T)).T
-                elif hasattr(fn, "solve"):
-                    for j in range(k):
-                        fn.solve(Y[j], W[j])
-                else:
-                    for j in range(k):
-                        fn.mult(W[j], Y[j])
+                self._apply_rows(W, Y)
                 return 0
             except Exception as exc:  # never let an exception cross the C boundary
                 self.error = exc
@@ -288,6 +308,54 @@ class HostCallbackOperator(DeviceOperator):
         self.chunk_vectors = int(chunk_vectors)
         if self.chunk_vectors:
             L.call("hfmi_op_host_set_chunk", self._op, self.chunk_vectors)
+
+    def _comm(self):
+        try:
+            return self.fn.mpi_comm() if hasattr(self.fn, "mpi_comm") and callable(self.fn.mpi_comm) else None
+        except Exception:          # noqa: BLE001
+            return None
+
+    def _host_pair(self):
+        if self._x is None:
+            comm = self._comm()
+            # a solver maps the range of its operator back to the domain: both shapes coincide on this (square) path
+            self._x = H.shape_with(self._shaper, 1, comm)
+            self._y = H.shape_with(self._shaper, 0, comm)
+        return self._x, self._y
+
+    def _apply_rows(self, W, Y):
+        fn, mode = self.fn, self.mode
+        if mode == "array":
+            Y[...] = np.asarray(fn(W.T)).T
+        elif mode == "block_np":
+            Y[...] = np.asarray(fn.matMvMult_np(W.T)).T
+        elif mode == "solve_np":
+            Y[...] = np.asarray(fn.solve_block(W.T)).T
+        elif mode == "block":
+            x, y = self._host_pair()
+            X, Yh = H.HostMultiVector(x, W.shape[0]), H.HostMultiVector(y, W.shape[0])
+            for j in range(W.shape[0]):
+                X[j].set_local(W[j])
+                X[j].apply("")
+            fn.matMvMult(X, Yh)
+            for j in range(W.shape[0]):
+                Y[j] = Yh[j].get_local()
+        elif mode in ("mult", "solve"):
+            x, y = self._host_pair()
+            for j in range(W.shape[0]):
+                x.set_local(W[j])
+                x.apply("")
+                if mode == "mult":
+                    fn.mult(x, y)
+                else:
+                    fn.solve(y, x)
+                Y[j] = y.get_local()
+        elif mode == "solve_1d":
+            for j in range(W.shape[0]):
+                fn.solve(Y[j], W[j])
+        else:
+            for j in range(W.shape[0]):
+                fn.mult(W[j], Y[j])
 
     def _raise_pending(self):
         if self.error is not None:
@@ -355,24 +423,47 @@ class ComposedOperator(DeviceOperator):
         L.call("hfmi_op_compose3", self.ctx.handle, a._op, b._op, c._op, C.byref(self._op))
 
 
-def as_device_operator(obj, N=None, ctx=None):
-    """Coerce the kinds of objects the reference passes as A / B / B^{-1} into device operators."""
+def csr_from_matrix(M):
+    """scipy CSR from the kinds of assembled matrices a prior carries: a scipy sparse matrix, a PETSc matrix
+    (``getValuesCSR()``, the call the reference itself uses to export matrices, PODProjector.py:322-324), a dolfin
+    matrix (``.mat()`` of its PETSc backend).  None when ``M`` is none of these."""
+    import scipy.sparse as sp
+    if sp.issparse(M):
+        return sp.csr_matrix(M)
+    for unwrap in (lambda m: m, lambda m: m.mat(), _dolfin_backend_mat):
+        try:
+            petsc = unwrap(M)
+            indptr, indices, data = petsc.getValuesCSR()
+        except Exception:          # noqa: BLE001 -- not that kind of matrix
+            continue
+        n_rows = len(indptr) - 1
+        n_cols = petsc.getSize()[1] if hasattr(petsc, "getSize") else n_rows
+        return sp.csr_matrix((np.asarray(data, dtype=np.float64), np.asarray(indices), np.asarray(indptr)), shape=(n_rows, n_cols))
+    return None
+
+
+def _dolfin_backend_mat(M):
+    import dolfin
+    return dolfin.as_backend_type(M).mat()
+
+
+def as_device_operator(obj, N=None, ctx=None, init_vector=None):
+    """Coerce the kinds of objects the reference passes as A / B / B^{-1} into device operators: device operators
+    and adapters as they are, assembled matrices (scipy / PETSc / dolfin) as CSR in HBM, dense symmetric arrays, and
+    every other operator or solver as a host callback -- through the reference's vector protocol when its vectors
+    can be shaped (``init_vector`` on the object or passed in), on numpy slices otherwise."""
     if isinstance(obj, DeviceOperator):
         return obj
     if hasattr(obj, "_device_operator"):
         return obj._device_operator()
-    try:
-        import scipy.sparse as sp
-        if sp.issparse(obj):
-            return CsrOperator(obj, ctx=ctx)
-    except ImportError:
-        pass
     if isinstance(obj, np.ndarray) and obj.ndim == 2:
         return npToDeviceOperator(obj, ctx=ctx)
-    if callable(obj) or hasattr(obj, "mult") or hasattr(obj, "solve") or hasattr(obj, "matMvMult_np") or hasattr(obj, "solve_block"):
-        if N is None:
-            raise ValueError("as_device_operator: vector length needed to wrap a host operator")
-        return HostCallbackOperator(obj, N, ctx=ctx)
+    if hasattr(obj, "getValuesCSR") or hasattr(obj, "mat") or hasattr(obj, "tocsr"):
+        csr = csr_from_matrix(obj)
+        if csr is not None:
+            return CsrOperator(csr, ctx=ctx)
+    if callable(obj) or any(hasattr(obj, m) for m in ("mult", "solve", "matMvMult", "matMvMult_np", "solve_block")):
+        return HostCallbackOperator(obj, N, ctx=ctx, init_vector=init_vector)
     raise TypeError("cannot use %r as an operator" % (type(obj),))
 
 
@@ -381,31 +472,76 @@ class Solver2Operator:
 
     def __init__(self, solver, mpi_comm=None, init_vector=None):
         self.solver = solver
-        self._init_vector = init_vector
+        self._mpi_comm = mpi_comm
+        self._init_vector = init_vector or H.find_init_vector(solver)
+
+    def mpi_comm(self):
+        return self._mpi_comm
 
     def init_vector(self, x, dim):
-        if self._init_vector is not None:
-            self._init_vector(x, dim)
-        elif hasattr(self.solver, "init_vector"):
-            self.solver.init_vector(x, dim)
-        else:
+        if self._init_vector is None:
             raise NotImplementedError("Solver2Operator: no init_vector available")
+        self._init_vector(x, dim)
 
     def mult(self, x, y):
         self.solver.solve(y, x)
 
     def _device_operator(self):
         s = self.solver
-        return s if isinstance(s, DeviceOperator) else as_device_operator(s, getattr(s, "N", None))
+        return s if isinstance(s, DeviceOperator) else as_device_operator(s, getattr(s, "N", None), init_vector=self._init_vector)
+
+
+# ======================================================================================================================
+# The reference's small adapter classes (same names, constructor arguments and duck types).  They are written around
+# three helpers: a chain of maps through scratch vectors, a weighted sum of operator applications, and a retrying
+# sample loop.  Every one of them works on device vectors / blocks and on host (dolfin-like) vectors alike: only
+# ``zero``, ``axpy`` and the block members ``dot_v`` / ``reduce`` are used.
+# ======================================================================================================================
+def _scratch(like_init, dim, ctx=None):
+    """A work vector shaped by an operator's ``init_vector``: in HBM when the owner lives on the device (it has a
+    context), else a host vector of the kind the host operator expects."""
+    if ctx is None:
+        return H.shape_with(like_init, dim)
+    v = Vector(ctx=ctx)
+    like_init(v, dim)
+    return v
+
+
+def _run_chain(steps, x, y, scratch):
+    """y = steps[-1](... steps[0](x)): each step is ``f(src, dst)``, intermediates live in ``scratch``."""
+    src = x
+    for f, dst in zip(steps[:-1], scratch):
+        f(src, dst)
+        src = dst
+    steps[-1](src, y)
+
+
+def _weighted_sum(applications, y, weight, make_like):
+    """y = weight * sum of f(tmp) over ``applications`` (each fills ``tmp``); the accumulator starts from zero."""
+    tmp, acc = make_like(y), make_like(y)
+    acc.zero()
+    for f in applications:
+        f(tmp)
+        acc.axpy(1.0, tmp)
+    y.zero()
+    y.axpy(weight, acc)
+
+
+def _low_rank_apply(left, weights, right, x, y):
+    """y = left diag(weights) right^T x."""
+    coeff = right.dot_v(x)
+    y.zero()
+    left.reduce(y, coeff if weights is None else weights * coeff)
 
 
 class MassPreconditionedCovarianceOperator:
-    """Linear operator M C M (KLEProjector.py:47-69)."""
+    """M C M (KLEProjector.py:47-69).  On the device the three factors are composed into one operator; called with host
+    vectors it runs the chain there."""
 
     def __init__(self, C, M):
-        self.C = C
-        self.M = M
+        self.C, self.M = C, M
         self._dev = None
+        self._host_scratch = None
 
     def mpi_comm(self):
         return self.M.mpi_comm()
@@ -416,53 +552,49 @@ class MassPreconditionedCovarianceOperator:
     def _device_operator(self):
         if self._dev is None:
             Md = as_device_operator(self.M)
-            Cd = as_device_operator(self.C, Md.shape[0], Md.ctx)
-            self._dev = ComposedOperator(Md, Cd, Md)
+            self._dev = ComposedOperator(Md, as_device_operator(self.C, Md.shape[0], Md.ctx), Md)
         return self._dev
 
     def mult(self, x, y):
-        self._device_operator().mult(x, y)
+        if H.is_host_vector(x):
+            if self._host_scratch is None:
+                self._host_scratch = [H.shape_with(self.M.init_vector, 0), H.shape_with(self.M.init_vector, 0)]
+            _run_chain([self.M.mult, self.C.mult, self.M.mult], x, y, self._host_scratch)
+        else:
+            self._device_operator().mult(x, y)
 
     def matMvMult(self, X, Y):
         self._device_operator().matMvMult(X, Y)
 
 
 class SummedListOperator:
-    """Mean (or sum) of a list of operators of equal dimension (activeSubspaceProjector.py:69-95).
-    The accumulator starts from zero (the reference seeds it with a copy of the incoming y, :83-86,
-    which is only a mean when y arrives zero-filled -- SURVEY.md section 3.6)."""
+    """Mean (``average``) or sum of operators of one shape (activeSubspaceProjector.py:69-95).  The accumulator starts
+    from zero; the reference seeds it with the incoming y (:83-86), which is a mean only when y arrives zero-filled
+    (SURVEY.md section 3.6)."""
 
     def __init__(self, operators, communicator=None, average=True):
         assert type(operators) is list
         self.operators = operators
         self.average = average
 
+    def _weight(self):
+        return 1.0 / float(len(self.operators)) if self.average else 1.0
+
     def init_vector(self, x, dim=0):
         self.operators[0].init_vector(x, dim)
 
     def mult(self, x, y):
-        temp = Vector(y)
-        temp.zero()
-        for op in self.operators:
-            op.mult(x, y)
-            temp.axpy(1.0, y)
-        y.zero()
-        y.axpy(1.0 / float(len(self.operators)) if self.average else 1.0, temp)
+        _weighted_sum([lambda t, op=op: op.mult(x, t) for op in self.operators], y, self._weight(), H._copy_vector if H.is_host_vector(y) else Vector)
 
     def matMvMult(self, X, Y):
-        temp = MultiVector(Y)
-        temp.zero()
         from .multivector import MatMvMult
-        for op in self.operators:
-            MatMvMult(op, X, Y)
-            temp.axpy(1.0, Y)
-        Y.zero()
-        Y.axpy(1.0 / float(len(self.operators)) if self.average else 1.0, temp)
+        make = H.HostMultiVector if isinstance(Y, H.HostMultiVector) else MultiVector
+        _weighted_sum([lambda T, op=op: MatMvMult(op, X, T) for op in self.operators], Y, self._weight(), make)
 
 
 class StateSpaceIdentityOperator:
-    """Identity observable on the state space (fullStateObservable.py:18-52): ``mult`` copies; ``transpmult`` applies
-    the mass matrix (the adjoint in the M-inner product) unless ``use_mass_matrix`` is False."""
+    """The observation operator of a full-state observable (fullStateObservable.py:18-52): the identity, whose adjoint
+    in the M inner product is M itself unless ``use_mass_matrix`` is off."""
 
     def __init__(self, M, use_mass_matrix=True):
         self.M = M
@@ -474,103 +606,167 @@ class StateSpaceIdentityOperator:
     def init_vector(self, v, dim):
         return self.M.init_vector(v, dim)
 
+    @staticmethod
+    def _copy(src, dst):
+        dst.zero()
+        dst.axpy(1.0, src)
+
     def mult(self, u, y):
-        y.zero()
-        y.axpy(1.0, u)
+        self._copy(u, y)
 
     def transpmult(self, x, p):
-        if self.use_mass_matrix:
-            self.M.transpmult(x, p) if hasattr(self.M, "transpmult") else self.M.mult(x, p)   # M is symmetric
+        if not self.use_mass_matrix:
+            self._copy(x, p)
         else:
-            p.zero()
-            p.axpy(1.0, x)
+            getattr(self.M, "transpmult", self.M.mult)(x, p)          # M is symmetric
 
 
-class JTJ:
-    """J^T J of a Jacobian-protocol object (``mult`` domain -> range, ``transpmult`` range -> domain,
-    ``init_vector(x, dim)``; jacobian.py:142-166).  With a block-capable Jacobian (``DenseJacobianOperator``) the
-    block form ``matMvMult`` runs as two tall-skinny contractions."""
+class ObservableJacobian:
+    """Matrix-free Jacobian of the parameter-to-observable map at the observable's current linearisation point
+    (jacobian.py:62-139), through the reference's own calls: ``mult`` is ``applyC -> solveFwdIncremental -> applyB`` and a
+    sign, ``transpmult`` is ``applyBt -> solveAdjIncremental -> applyCt`` and a sign.  Everything stays on the host, in
+    vectors the observable generated."""
+
+    def __init__(self, observable):
+        self.observable = observable
+        self.ncalls = 0
+        gen = observable.generate_vector
+        self._rhs = {False: gen(H.STATE), True: gen(H.ADJOINT)}         # right-hand side of the incremental solve
+        self._inc = {False: gen(H.STATE), True: gen(H.ADJOINT)}         # its solution
+        q_like = H.new_host_vector(self.mpi_comm())
+        observable.B.init_vector(q_like, 0)
+        self.shape = (len(q_like.get_local()), len(gen(H.PARAMETER).get_local()))
+
+    def mpi_comm(self):
+        return self.observable.B.mpi_comm()
+
+    def init_vector(self, x, dim):
+        if dim not in (0, 1):
+            raise ValueError("dim must be 0 (observable space) or 1 (parameter space)")
+        self.observable.init_vector(x, dim)
+
+    def _through(self, adjoint, into_rhs, solve, out_of_solution, x, y):
+        into_rhs(x, self._rhs[adjoint])
+        solve(self._inc[adjoint], self._rhs[adjoint])
+        out_of_solution(self._inc[adjoint], y)
+        y *= -1.0
+        self.ncalls += 1
+
+    def mult(self, x, y):
+        obs = self.observable
+        assert hasattr(obs, 'applyB'), 'LinearObservable must have attribute applyB'
+        self._through(False, obs.applyC, obs.solveFwdIncremental, obs.applyB, x, y)
+
+    def transpmult(self, x, y):
+        obs = self.observable
+        assert hasattr(obs, 'applyBt'), 'LinearObservable must have attribute applyBt'
+        self._through(True, obs.applyBt, obs.solveAdjIncremental, obs.applyCt, x, y)
+
+    def rows(self, out=None):
+        """The Jacobian as a dense (q, N) array, one adjoint solve per row (J^T e_i): how a sample's linearisation is
+        materialised for the device when q is below the number of operator applications it would otherwise cost."""
+        q, n = self.shape
+        out = np.empty((q, n)) if out is None else out
+        e, row = H.shape_with(self.init_vector, 0, self.mpi_comm()), H.shape_with(self.init_vector, 1, self.mpi_comm())
+        unit = np.zeros(q)
+        for i in range(q):
+            unit[i] = 1.0
+            e.set_local(unit)
+            e.apply("")
+            unit[i] = 0.0
+            self.transpmult(e, row)
+            out[i] = row.get_local()
+        return out
+
+
+class _NormalOperator:
+    """J^T J or J J^T of a Jacobian-protocol object (``mult`` parameter -> observable, ``transpmult`` back,
+    ``init_vector(x, dim)``); jacobian.py:142-193.  With a block-capable Jacobian (``DenseJacobianOperator``) the block
+    form is two tall-skinny contractions."""
+
+    inner_dim = None       # the space the intermediate vector lives in: 0 observable (JTJ), 1 parameter (JJT)
 
     def __init__(self, J):
         self.J = J
-        self.vector_help = Vector(ctx=getattr(J, "ctx", None))
-        self.J.init_vector(self.vector_help, 0)
+        self.vector_help = _scratch(J.init_vector, self.inner_dim, getattr(J, "ctx", None))
+
+    def _steps(self, block=False):
+        first, second = ("matMvMult", "matMvTranspmult") if block else ("mult", "transpmult")
+        fs = (getattr(self.J, first), getattr(self.J, second))
+        return fs if self.inner_dim == 0 else fs[::-1]
 
     def mult(self, x, y):
-        self.J.mult(x, self.vector_help)
-        self.J.transpmult(self.vector_help, y)
+        _run_chain(list(self._steps()), x, y, [self.vector_help])
 
     def init_vector(self, x, dim=None):
-        self.J.init_vector(x, 1)
+        self.J.init_vector(x, 1 - self.inner_dim)
 
     def matMvMult(self, X, Y):
-        """Y = J^T (J X) (overwrites Y, the semantics of hp.MatMvMult on an operator without a block form)."""
+        """Y = op X (overwrites Y, the semantics of hp.MatMvMult on an operator without a block form)."""
         if hasattr(self.J, "matMvMult") and hasattr(self.J, "matMvTranspmult"):
-            tmp = MultiVector(self.vector_help, X.nvec())
-            self.J.matMvMult(X, tmp)
-            self.J.matMvTranspmult(tmp, Y)
+            _run_chain(list(self._steps(block=True)), X, Y, [MultiVector(self.vector_help, X.nvec())])
         else:
             for j in range(X.nvec()):
                 self.mult(X[j], Y[j])
 
 
-class JJT:
+class JTJ(_NormalOperator):
+    """J^T J (jacobian.py:142-166)."""
+    inner_dim = 0
+
+
+class JJT(_NormalOperator):
     """J J^T (jacobian.py:169-193)."""
+    inner_dim = 1
 
-    def __init__(self, J):
-        self.J = J
-        self.vector_help = Vector(ctx=getattr(J, "ctx", None))
-        self.J.init_vector(self.vector_help, 1)
 
-    def mult(self, x, y):
-        self.J.transpmult(x, self.vector_help)
-        self.J.mult(self.vector_help, y)
-
-    def init_vector(self, x, dim=None):
-        self.J.init_vector(x, 0)
-
-    def matMvMult(self, X, Y):
-        if hasattr(self.J, "matMvMult") and hasattr(self.J, "matMvTranspmult"):
-            tmp = MultiVector(self.vector_help, X.nvec())
-            self.J.matMvTranspmult(X, tmp)
-            self.J.matMvMult(tmp, Y)
-        else:
-            for j in range(X.nvec()):
-                self.mult(X[j], Y[j])
+def default_jacobian_factory(observable):
+    """What ``SeriallySampledJacobianOperator`` linearises with: the reference hard-wires ``ObservableJacobian``
+    (activeSubspaceProjector.py:178-181); observables that hold their Jacobian in HBM offer ``jacobian()``."""
+    if hasattr(observable, "jacobian"):
+        return observable.jacobian()
+    return ObservableJacobian(observable)
 
 
 class SeriallySampledJacobianOperator:
     """Sample-by-sample accumulation of J^T J (or J J^T) over prior draws (activeSubspaceProjector.py:98-257).
 
-    Protocol-level mirror: the PDE work stays behind the duck-typed ``observable`` exactly as in the reference
-    (``solveFwd(u, x)``, ``setLinearizationPoint(x)``, ``generate_vector``), and the linearised map is whatever
-    ``jacobian_factory(observable)`` returns -- the reference hard-wires ``ObservableJacobian(observable)``
-    (:178-181); a stored / dense Jacobian enters through ``DenseJacobianOperator``.  ``matMvMult`` ACCUMULATES into y
-    (:214-221, :242-248): callers pass a zeroed block, as ``MatrixMultCollectiveOperator`` does.  Per sample the whole
-    probe block goes through ``JTJ.matMvMult`` (two contractions) instead of the reference's column loop."""
+    The PDE work stays behind the duck-typed ``observable`` exactly as in the reference: per sample ``noise`` is drawn,
+    ``prior.sample(noise, m)``, the control (if any), ``solveFwd``, ``setLinearizationPoint``; then the linearised map
+    ``jacobian_factory(observable)`` is applied to the whole probe block.  ``matMvMult`` ACCUMULATES into y (:214-221,
+    :242-248): callers hand it a zeroed block, as ``MatrixMultCollectiveOperator`` + ``doublePass`` do.  A failing
+    forward solve is answered with a fresh draw, as upstream (:180-211, whose ``while not solved`` has no exit) -- at most
+    ``max_solver_retries`` times per sample here.
+
+    Called with DEVICE blocks and a host observable, each sample's Jacobian is materialised row by row
+    (``ObservableJacobian.rows``: q adjoint solves instead of the 2 k incremental solves of the column loop) into a pinned
+    buffer, shipped to HBM on the ingest stream and contracted there while the host solves the next sample
+    (``materialize`` = None: whenever q <= 2 k; True / False force it)."""
 
     def __init__(self, observable, noise, prior, control_distribution=None, operation='JTJ', nsamples=None, ms=None, zs=None,
-                 communicator=None, average=True, jacobian_factory=None):
+                 communicator=None, average=True, jacobian_factory=None, materialize=None):
         assert operation in ['JTJ', 'JJT']
         assert (nsamples is not None) or (ms is not None)
-        self.observable = observable
-        self.noise = noise
-        self.prior = prior
+        self.observable, self.noise, self.prior = observable, noise, prior
         self.control_distribution = control_distribution
         self.operation = operation
         self.nsamples = nsamples
         self.average = average
         self.ms = ms
-        if zs is not None:
-            self.zs = zs
-        else:
-            self.zs = len(self.ms) * [None] if type(self.ms) is list else zs
-        self.jacobian_factory = jacobian_factory or (lambda obs: obs.jacobian())
+        self.zs = zs if zs is not None else (len(ms) * [None] if type(ms) is list else None)
+        self.jacobian_factory = jacobian_factory or default_jacobian_factory
+        self.materialize = materialize
         self.max_solver_retries = 100         # fresh draws per sample before a failing forward solve is reported
         self.solver_failures = 0              # failed forward solves so far (each was followed by a fresh draw)
-        self.u = observable.generate_vector(0) if hasattr(observable, "generate_vector") else None
-        self.m = observable.generate_vector(1) if hasattr(observable, "generate_vector") else None
-        self.z = None if control_distribution is None else observable.generate_vector(3)
+        self.samples_linearized = 0
+        gen = getattr(observable, "generate_vector", None)
+        projected = hasattr(getattr(observable, "problem", None), 'parameter_projection')
+        self.u = gen(H.STATE) if gen else None
+        if gen and projected:                 # the sample lives on the prior's space and is projected for the PDE (:131-137)
+            self.m = H.shape_with(prior.init_vector, 0, communicator)
+        else:
+            self.m = gen(H.PARAMETER) if gen else None
+        self.z = None if control_distribution is None else gen(H.CONTROL)
 
     def init_vector(self, x, dim=None):
         if self.operation == 'JJT':
@@ -580,99 +776,170 @@ class SeriallySampledJacobianOperator:
         else:
             self.observable.init_vector(x, 1)
 
-    def _operator(self):
-        J = self.jacobian_factory(self.observable)
-        return JTJ(J) if self.operation == 'JTJ' else JJT(J)
+    # ---- one linearisation point
+    def _linearize(self, m, z):
+        point = [self.u, m, None] if z is None else [self.u, m, None, z]
+        problem = getattr(self.observable, "problem", None)
+        if hasattr(problem, 'parameter_projection') and m is self.m:
+            point[1] = problem.parameter_projection(m)
+        self.observable.solveFwd(self.u, point)
+        self.observable.setLinearizationPoint(point)
+        self.samples_linearized += 1
 
-    def _accumulate(self, x, y, weight):
-        op = self._operator()
-        tmp = MultiVector(y)
-        op.matMvMult(x, tmp)
-        y.axpy(weight, tmp)
-
-    def matMvMult(self, x, y):
-        assert x.nvec() == y.nvec(), "x and y have non-matching number of vectors"
+    def _draw_and_linearize(self):
         from .randomized import parRandom
+        last = None
+        for _ in range(self.max_solver_retries + 1):
+            self.m.zero()
+            self.noise.zero()
+            parRandom.normal(1, self.noise)
+            self.prior.sample(self.noise, self.m)
+            if self.control_distribution is not None:
+                self.z.zero()
+                self.control_distribution.sample(self.z)
+            try:
+                return self._linearize(self.m, self.z)
+            except Exception as exc:          # noqa: BLE001 -- any solver failure means "draw again", as upstream
+                self.solver_failures += 1
+                last = exc
+        raise RuntimeError("forward solve failed for %d consecutive draws of one sample (last error: %r)"
+                           % (self.max_solver_retries + 1, last)) from last
+
+    def _points(self):
+        """One linearisation per item: fresh draws, or the given ``ms`` (the reference's unit-test path, :223-248)."""
         if self.ms is None:
             for _ in range(self.nsamples):
-                # the reference re-draws the sample when the forward solve fails (activeSubspaceProjector.py:180-211: a bare
-                # try / except around sampling + solveFwd inside `while not solved`); its loop has no exit -- this one gives
-                # up after max_solver_retries fresh draws and says which sample could not be solved
-                for attempt in range(self.max_solver_retries + 1):
-                    self.m.zero()
-                    self.noise.zero()
-                    parRandom.normal(1, self.noise)
-                    self.prior.sample(self.noise, self.m)
-                    linearization_x = [self.u, self.m, None]
-                    if self.control_distribution is not None:
-                        self.z.zero()
-                        self.control_distribution.sample(self.z)
-                        linearization_x.append(self.z)
-                    try:
-                        self.observable.solveFwd(self.u, linearization_x)
-                        self.observable.setLinearizationPoint(linearization_x)
-                        break
-                    except Exception as exc:          # noqa: BLE001 -- any solver failure means "draw again", as upstream
-                        self.solver_failures += 1
-                        if attempt == self.max_solver_retries:
-                            raise RuntimeError("forward solve failed for %d consecutive draws of one sample (last error: %r)"
-                                               % (self.max_solver_retries + 1, exc)) from exc
-                self._accumulate(x, y, 1.0 / self.nsamples if self.average else 1.0)
+                self._draw_and_linearize()
+                yield
         else:
-            nsamples = len(self.ms)
             for m, z in zip(self.ms, self.zs):
-                linearization_x = [self.u, m, None] if z is None else [self.u, m, None, z]
-                self.observable.solveFwd(self.u, linearization_x)
-                self.observable.setLinearizationPoint(linearization_x)
-                self._accumulate(x, y, 1.0 / nsamples if self.average else 1.0)
+                self._linearize(m, z)
+                yield
+
+    # ---- the accumulation
+    def matMvMult(self, x, y):
+        assert x.nvec() == y.nvec(), "x and y have non-matching number of vectors"
+        count = self.nsamples if self.ms is None else len(self.ms)
+        weight = 1.0 / count if self.average else 1.0
+        normal = JTJ if self.operation == 'JTJ' else JJT
+        on_device = isinstance(x, MultiVector)
+        J = None
+        stager = None
+        for _ in self._points():
+            J = self.jacobian_factory(self.observable) if (J is None or not isinstance(J, ObservableJacobian)) else J
+            if on_device and isinstance(J, ObservableJacobian):
+                if stager is None:
+                    stager = _JacobianStager(J, x.ctx, self.materialize, x.nvec())
+                stager.accumulate(normal, x, y, weight)
+                continue
+            op = normal(J)
+            if on_device:
+                tmp = MultiVector(y)
+                op.matMvMult(x, tmp)
+                y.axpy(weight, tmp)
+            else:                             # host column lists: the reference's loop (:214-221)
+                tmp = H._copy_vector(y[0])
+                for j in range(x.nvec()):
+                    tmp.zero()
+                    op.mult(x[j], tmp)
+                    y[j].axpy(weight, tmp)
+        if stager is not None:
+            stager.finish()
+
+
+class _JacobianStager:
+    """Device accumulation of w J^T J X (or w J J^T X) for a HOST Jacobian.  Materialising route: the q rows of J go
+    through one of two pinned buffers to a (q x N) block in HBM on the ingest stream, and the two contractions run on
+    the device while the host works on the next sample.  Column route (q > 2 k): the probe block is downloaded once
+    and each column goes through ``mult`` / ``transpmult`` on host vectors."""
+
+    def __init__(self, J, ctx, materialize, k):
+        self.J, self.ctx = J, ctx
+        q, n = J.shape
+        self.q, self.n = q, n
+        self.materialize = (q <= 2 * k) if materialize is None else bool(materialize)
+        self._i = 0
+        if self.materialize:
+            self._pinned = [L.pinned_empty((q, n)) for _ in range(2)]
+            self._blocks = [MultiVector(n, q, ctx=ctx) for _ in range(2)]
+            self._tickets = [None, None]
+        else:
+            self._x_host = None
+
+    def accumulate(self, normal, X, Y, weight):
+        if not self.materialize:
+            return self._columns(normal, X, Y, weight)
+        b = self._i % 2
+        self._i += 1
+        if self._tickets[b] is not None:
+            self.ctx.ingest_wait(self._tickets[b])
+            self.ctx.synchronize()            # the contraction that read this block two samples ago has finished
+        self.J.rows(self._pinned[b])
+        self._tickets[b] = self._blocks[b].upload_async(self._pinned[b])
+        self.ctx.ingest_fence()
+        rows = DenseJacobianOperator(self._blocks[b])
+        tmp = MultiVector(Y)
+        normal(rows).matMvMult(X, tmp)
+        Y.axpy(weight, tmp)
+
+    def _columns(self, normal, X, Y, weight):
+        op = normal(self.J)
+        if self._x_host is None:
+            self._x_host = X.to_vectors()
+        dim_in = 1 if normal is JTJ else 0
+        xin = H.shape_with(self.J.init_vector, dim_in, self.J.mpi_comm())
+        yout = H.shape_with(self.J.init_vector, dim_in, self.J.mpi_comm())
+        out = np.empty_like(self._x_host)
+        for j in range(self._x_host.shape[0]):
+            xin.set_local(self._x_host[j])
+            xin.apply("")
+            op.mult(xin, yout)
+            out[j] = yout.get_local()
+        Y.axpy(weight, MultiVector.from_vectors(out, ctx=self.ctx))
+
+    def finish(self):
+        if self.materialize:
+            for t in self._tickets:
+                if t is not None:
+                    self.ctx.ingest_wait(t)
+            self.ctx.synchronize()
 
 
 class PriorPreconditionedProjector:
-    """y = U U^T C^{-1} x (priorPreconditionedProjector.py:19-55)."""
+    """x -> U U^T C^{-1} x (priorPreconditionedProjector.py:19-55)."""
 
     def __init__(self, U, Cinv, my_init_vector):
-        self.U = U
-        self.Cinv = Cinv
+        self.U, self.Cinv = U, Cinv
         self.my_init_vector = my_init_vector
-        self.Cinvx = Vector(ctx=U.ctx)
-        self.my_init_vector(self.Cinvx, 0)
+        self.Cinvx = _scratch(my_init_vector, 0, getattr(U, "ctx", None))
 
     def init_vector(self, x, dim):
         self.my_init_vector(x, dim)
 
     def mult(self, x, y):
         self.Cinv.mult(x, self.Cinvx)
-        UtCinvx = self.U.dot_v(self.Cinvx)
-        y.zero()
-        self.U.reduce(y, UtCinvx)
+        _low_rank_apply(self.U, None, self.U, self.Cinvx, y)
 
 
 class LowRankRectangularOperator:
-    """A = U s V^T (lowRankRectangularOperator.py:17-66)."""
+    """U diag(s) V^T and its transpose (lowRankRectangularOperator.py:17-66)."""
 
     def __init__(self, U, s, V, U_init_vector=None, V_init_vector=None):
         self.U, self.s, self.V = U, np.asarray(s, dtype=np.float64), V
+        self._shapers = (U_init_vector, V_init_vector)
         self.U_init_vector, self.V_init_vector = U_init_vector, V_init_vector
 
     def init_vector(self, x, dim):
-        if dim == 0:
-            assert self.U_init_vector is not None
-            self.U_init_vector(x)
-        elif dim == 1:
-            assert self.V_init_vector is not None
-            self.V_init_vector(x)
-        else:
+        if dim not in (0, 1):
             raise ValueError("dim must be 0 or 1")
+        assert self._shapers[dim] is not None
+        self._shapers[dim](x)
 
     def mult(self, x, y):
-        Vtx = self.V.dot_v(x)
-        y.zero()
-        self.U.reduce(y, self.s * Vtx)
+        _low_rank_apply(self.U, self.s, self.V, x, y)
 
     def transpmult(self, x, y):
-        Utx = self.U.dot_v(x)
-        y.zero()
-        self.V.reduce(y, self.s * Utx)
+        _low_rank_apply(self.V, self.s, self.U, x, y)
 
 
 # the reference's name for the dense-array operator wrapper (operatorWrappers.py:19-52)

@@ -7,18 +7,18 @@ names, return tuples, stored attributes and saved-file names as the reference:
   PODProjector / PODParameterList                         hippyflow/modeling/PODProjector.py:35-49,52-389
   PODProjectorFromData                                    hippyflow/modeling/PODProjector.py:666-852
 
-FEniCS/hIPPYlib PDE work stays a host black box.  What the reference obtains by PDE solves is
-supplied here through small duck-typed hooks on the ``observable`` / ``prior`` arguments:
+FEniCS/hIPPYlib PDE work stays a host black box, reached through the REFERENCE'S OWN protocols: an ``observable``
+with ``generate_vector / init_vector / solveFwd / evalu / setLinearizationPoint / applyC / solveFwdIncremental / applyB`` and
+their adjoint counterparts (modeling/observable.py:66-323), a ``prior`` with ``init_vector(x, "noise")``,
+``sample(noise, m)``, ``mean``, ``R`` / ``Rsolver`` (or ``Hlr``), ``M`` / ``Msolver`` -- all on dolfin-like host vectors
+(``hostvec.new_host_vector``).  The sampling loops of the reference run as they are written there
+(PODProjector.py:343-357, activeSubspaceProjector.py:163-248,347-397); what they produce is streamed into HBM through
+pinned buffers (``ingest_stream`` / ``upload_async``) and contracted on the device.
 
-* snapshots (POD):  ``observable.sample_observables(n, prior, noise)`` -> (n, N) array (or a
-  MultiVector with one snapshot per vector) -- the loop of PODProjector.py:343-357;
-* Jacobians (AS):   ``observable.jacobian_data(n)`` -> (n, q, N) array or (MultiVector, n, q) of this
-  rank's linearised samples (the materialised form of Js, activeSubspaceProjector.py:389),
-  or ``observable.jtj_host_operator()`` / ``jjt_host_operator()`` -> a host operator
-  (``matMvMult_np``) for the serialized black-box route (:163-248);
-* prior:            ``R`` (sparse matrix or operator) and ``Rsolver`` (``solve(y, x)``), or ``Hlr``;
-                    ``M`` (sparse), optional ``Msolver``; for KLE either ``Rsolver`` or an explicit
-                    covariance operator ``C``.
+Observables that already hold their data on the device may short-cut the loops with optional hooks:
+``sample_observables(n, prior, noise)`` / ``observable_stream(n, prior, noise)`` (snapshots), ``jacobian_data(n)`` /
+``jacobian_stream(n)`` (stored Jacobians), ``jtj_host_operator()`` / ``jjt_host_operator()`` (a ready host operator); a
+prior may offer ``sample_block(n)`` and an explicit covariance ``C``.
 """
 import os
 import time
@@ -27,10 +27,11 @@ import numpy as np
 
 from . import _lib as L
 from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
+from . import hostvec as H
 from .multivector import ingest_stream, MatMvMult, MultiVector, Vector
 from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
-                        MeanJJTfromDataOperator, MeanJTJfromDataOperator, SnapshotGramOperator, Solver2Operator,
-                        as_device_operator)
+                        MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableJacobian, SeriallySampledJacobianOperator,
+                        SnapshotGramOperator, Solver2Operator, as_device_operator, csr_from_matrix)
 from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
 from .utilities import mv_to_dense
 
@@ -137,26 +138,92 @@ def _save(directory, name, array):
 
 def _draw_omega(N, nvec, collective, ctx, stored=None):
     """Probe block.  The reference draws on rank 0 and broadcasts k vectors of length N
-    (activeSubspaceProjector.py:433-443,536-551).  Here rank 0's generator state (seed, stream) -- 16 bytes -- is
-    what is broadcast; every rank then regenerates the same counter-based Philox block in its own HBM from a
-    TEMPORARY generator holding that state.  The process-wide ``parRandom`` of the other ranks is left alone, as in
-    the reference (hp.parRandom is rank-split and only Omega travels): per-rank sample draws that follow -- the noise
-    of the serialized-sampling Jacobian operator, ``normal_perturb`` -- stay distinct when the ranks were seeded
-    differently.  Rank 0's generator advances by the one stream the draw consumed.  A stored Omega (unit-test path)
-    is broadcast from rank 0 as a block."""
+    (activeSubspaceProjector.py:433-443,536-551).  Here rank 0's SHARED generator state (seed, shared stream) -- 16 bytes
+    -- is what is broadcast; every rank then regenerates the same counter-based Philox block in its own HBM and EVERY
+    rank moves on to the next shared stream.  Shared draws live under their own Philox key (namespace 0,
+    ``randomized._ParRandom``), disjoint from the per-rank private streams the sampling loops draw their noise from, so a
+    probe can never coincide with a Monte-Carlo sample on any rank.  A stored Omega (unit-test path) is broadcast from
+    rank 0 as a block."""
     if stored is not None:
         Omega = MultiVector(stored)
         collective.bcast(Omega, root=0)
         return Omega
-    state = np.array([parRandom.seed & (2 ** 64 - 1), parRandom.stream & 0xFFFFFFFF], dtype=np.uint64)
+    state = np.array([parRandom.seed & 0xFFFFFFFF, parRandom.shared_stream & 0xFFFFFFFF], dtype=np.uint64)
     state = collective.bcast(state, root=0)
     draw = type(parRandom)(int(state[0]))
-    draw.stream = int(state[1])
+    draw.shared_stream = int(state[1])
     Omega = MultiVector(int(N), int(nvec), ctx=ctx)
-    draw.normal(1., Omega)
-    if _is_root(collective):
-        parRandom.stream += 1
+    draw.normal(1., Omega, shared=True)
+    parRandom.shared_stream = int(state[1]) + 1
     return Omega
+
+
+def _speaks_reference_protocol(observable):
+    """An observable of the reference (modeling/observable.py): PDE solves behind solveFwd / setLinearizationPoint."""
+    return hasattr(observable, "solveFwd") and hasattr(observable, "generate_vector")
+
+
+def _operator_size(op, dim=0):
+    """Length of the vectors an operator acts on: ``shape`` of a device operator, else whatever its ``init_vector`` makes."""
+    if hasattr(op, "shape"):
+        return int(op.shape[0])
+    return int(H.shape_with(op.init_vector, dim).size())
+
+
+def _prior_draws(prior, noise, m, n):
+    """n prior samples as numpy rows, by the reference's loop: hp.parRandom.normal(1, noise); prior.sample(noise, m)."""
+    for _ in range(n):
+        parRandom.normal(1, noise)
+        prior.sample(noise, m)
+        yield m.get_local()
+
+
+def _prior_sample_block(prior, n, noise=None, observable=None):
+    """n prior draws for the projection-error tests: ``prior.sample_block(n)`` when the prior offers it, else the
+    reference's loop (KLEProjector.py:222-231, activeSubspaceProjector.py:1075-1090) over host vectors."""
+    if hasattr(prior, "sample_block"):
+        return prior.sample_block(n)
+    if noise is None:
+        noise = H.new_host_vector()
+        prior.init_vector(noise, "noise")
+    if observable is not None and hasattr(observable, "generate_vector"):
+        m = observable.generate_vector(H.PARAMETER)
+    else:
+        m = H.shape_with(prior.init_vector, 0)
+    return np.stack(list(_prior_draws(prior, noise, m, n)))
+
+
+def _observable_draws(observable, prior, control_distribution, n, noise):
+    """The reference's snapshot loop (PODProjector.py:343-357), one observable per item: noise, prior.sample, control,
+    forward solve, ``evalu``."""
+    u = observable.generate_vector(H.STATE)
+    m = observable.generate_vector(H.PARAMETER)
+    z = None if control_distribution is None else observable.generate_vector(H.CONTROL)
+    for _ in range(n):
+        parRandom.normal(1, noise)
+        prior.sample(noise, m)
+        point = [u, m, None]
+        if control_distribution is not None:
+            z.zero()
+            control_distribution.sample(z)
+            point.append(z)
+        observable.solveFwd(u, point)
+        yield observable.evalu(u).get_local()
+
+
+def _observable_samples(observable, prior, control_distribution, n, noise, ctx):
+    """n observable samples in HBM (one per vector): the observable's own bulk hooks if it has them, else the
+    reference's loop with each result on its way to the device while the next PDE is being solved."""
+    if hasattr(observable, 'observable_stream'):
+        return ingest_stream(observable.observable_stream(n, prior, None), n, 1, observable.output_dimension(), ctx=ctx)
+    if hasattr(observable, 'sample_observables'):
+        X = observable.sample_observables(n, prior, None)
+        return X if isinstance(X, MultiVector) else MultiVector.from_vectors(X, ctx=ctx)
+    if noise is None:
+        noise = H.new_host_vector(observable.mpi_comm() if hasattr(observable, "mpi_comm") else None)
+        prior.init_vector(noise, "noise")
+    q = H.shape_with(observable.init_vector, 0).size()
+    return ingest_stream(_observable_draws(observable, prior, control_distribution, n, noise), n, 1, q, ctx=ctx)
 
 
 # =====================================================================================
@@ -171,9 +238,17 @@ class ActiveSubspaceProjector:
         self.observable = observable
         self.prior = prior
         self.control_distribution = control_distribution
+        if mesh_constructor_comm is None and hasattr(observable, "mpi_comm"):
+            mesh_constructor_comm = observable.mpi_comm()                                   # :279-282
         self.mesh_constructor_comm = mesh_constructor_comm
         self.collective = collective
         self.ctx = ctx or L.Context.default()
+        self.noise = None
+        if _speaks_reference_protocol(observable) and hasattr(prior, "init_vector"):
+            self.noise = H.new_host_vector(mesh_constructor_comm)                           # :309-310
+            prior.init_vector(self.noise, "noise")
+        self.ms = None            # linearisation points: given by the caller (ms_given) or kept from the batched draw
+        self.zs = None
         self.Js = None            # (block, ndata, q) once materialised
         self.d_GN = None
         self.V_GN = None
@@ -184,16 +259,46 @@ class ActiveSubspaceProjector:
         self.U_NG = None
         self.Omega_GN = None
         self.Omega_NG = None
+        if self.parameters['initialize_samples'] and not self.parameters['serialized_sampling']:
+            self._initialize_batched_samples()                                              # :330-332
 
     # ---- data source -----------------------------------------------------------------
+    def _reference_jacobian_rows(self, n):
+        """The reference's batched initialisation (:347-397) with HBM as the store: per sample -- noise, prior.sample,
+        control, forward solve (a failing solve is answered with a fresh draw, as upstream), linearisation -- and then
+        the q rows of that sample's Jacobian (one adjoint solve each) as one item for the ingest stream.  One observable
+        serves every sample: what the reference keeps alive as ``samples_per_process`` FEniCS copies
+        (``observable_constructor``) is here a (q x N) slab per sample in device memory."""
+        sampler = SeriallySampledJacobianOperator(self.observable, self.noise, self.prior,
+                                                  control_distribution=self.control_distribution, operation='JTJ', nsamples=n,
+                                                  ms=self.ms if self.parameters['ms_given'] else None, zs=self.zs,
+                                                  jacobian_factory=ObservableJacobian)
+        J = None
+        kept = []
+        for _ in sampler._points():
+            J = J or ObservableJacobian(self.observable)
+            if not self.parameters['ms_given']:
+                kept.append(sampler.m.get_local())
+            yield J.rows()
+        if kept:
+            self.ms = kept
+
     def _initialize_batched_samples(self):
         """Materialise this rank's Jacobians in HBM (counterpart of :347-397)."""
         n = self.parameters['samples_per_process']
         if hasattr(self.observable, 'jacobian_stream'):
-            # the reference's loop (one Jacobian per host PDE solve, :178-221): sample i + 1 is produced while sample i is
-            # on its way to HBM through a pinned buffer (multivector.ingest_stream)
+            # one Jacobian per host PDE solve (:178-221): sample i + 1 is produced while sample i is on its way to HBM
+            # through a pinned buffer (multivector.ingest_stream)
             q, dM = self.observable.jacobian_shape()
             block = ingest_stream(self.observable.jacobian_stream(n), n, q, dM, ctx=self.ctx)
+            self.Js = (block, int(n), int(q))
+            return
+        if not hasattr(self.observable, 'jacobian_data') and _speaks_reference_protocol(self.observable):
+            if self.parameters['ms_given']:
+                assert self.ms is not None
+                n = len(self.ms)
+            q, dM = ObservableJacobian(self.observable).shape
+            block = ingest_stream(self._reference_jacobian_rows(n), n, q, dM, ctx=self.ctx)
             self.Js = (block, int(n), int(q))
             return
         data = self.observable.jacobian_data(n)
@@ -206,14 +311,46 @@ class ActiveSubspaceProjector:
         assert ndata == n, "observable returned %d samples, samples_per_process is %d" % (ndata, n)
         self.Js = (block, int(ndata), int(q))
 
+    def _linearize_at_mean_if_needed(self):
+        """:523-541 -- the incremental blocks of the PDE problem exist only after a first linearisation."""
+        problem = getattr(self.observable, "problem", None)
+        if problem is None or getattr(problem, "C", True) is not None:
+            return
+        m_mean = self.prior.mean
+        if hasattr(problem, 'parameter_projection'):
+            m_mean = problem.parameter_projection(m_mean)
+        point = [problem.generate_state(), m_mean, None]
+        if self.control_distribution is not None:
+            if hasattr(self.control_distribution, 'mean'):
+                point.append(self.control_distribution.mean)
+            else:
+                z = self.observable.generate_vector(H.CONTROL)
+                self.control_distribution.sample(z)
+                point.append(z)
+        problem.solveFwd(point[0], point)
+        self.observable.setLinearizationPoint(point)
+
     def _local_operator(self, operation):
-        """The per-rank averaged operator.  Batched: device kernels over stored Jacobians.
-        Serialized: the observable's host black box, re-applied every pass."""
-        if self.parameters['serialized_sampling'] and not self.parameters['ms_given'] and \
-                hasattr(self.observable, 'jtj_host_operator'):
-            host = self.observable.jtj_host_operator() if operation == 'JTJ' else self.observable.jjt_host_operator()
-            n = self.observable.input_dimension() if operation == 'JTJ' else self.observable.output_dimension()
-            return HostCallbackOperator(host, n, ctx=self.ctx)
+        """The per-rank averaged operator.  Batched: device kernels over stored Jacobians.  Serialized: the reference's
+        ``SeriallySampledJacobianOperator`` over the observable's own PDE calls, re-sampled on every application."""
+        if self.parameters['serialized_sampling']:
+            if not self.parameters['ms_given'] and hasattr(self.observable, 'jtj_host_operator'):
+                host = self.observable.jtj_host_operator() if operation == 'JTJ' else self.observable.jjt_host_operator()
+                n = self.observable.input_dimension() if operation == 'JTJ' else self.observable.output_dimension()
+                return HostCallbackOperator(host, n, ctx=self.ctx)
+            if _speaks_reference_protocol(self.observable) and not hasattr(self.observable, 'jacobian_data'):
+                if self.parameters['ms_given']:                                           # :504-511
+                    assert self.ms is not None
+                    if self.control_distribution is not None:
+                        assert self.zs is not None and self.zs[0] is not None
+                    op = SeriallySampledJacobianOperator(self.observable, self.noise, self.prior, operation=operation,
+                                                         ms=self.ms, zs=self.zs)
+                else:
+                    op = SeriallySampledJacobianOperator(self.observable, self.noise, self.prior,
+                                                         control_distribution=self.control_distribution, operation=operation,
+                                                         nsamples=self.parameters['samples_per_process'])
+                self._linearize_at_mean_if_needed()
+                return op
         if self.Js is None:
             self._initialize_batched_samples()
         block, ndata, q = self.Js
@@ -249,7 +386,7 @@ class ActiveSubspaceProjector:
         local_op = self._local_operator(operation)
         # This averaging assumes every process has an equal number of samples (reference :429-430,509-510)
         average_op = wrapper(local_op, self.collective, mpi_op='avg')
-        N = local_op.shape[0]
+        N = _operator_size(local_op)
         nvec = self.parameters['rank'] + self.parameters['oversampling']
         stored = self.Omega_GN if operation == 'JTJ' else self.Omega_NG
         Omega = _draw_omega(N, nvec, self.collective, self.ctx, stored=stored)
@@ -347,7 +484,7 @@ class ActiveSubspaceProjector:
                     self.parameters['rank'] = max(self.parameters['rank'], want)
                 self.construct_input_subspace()
             if samples is None:
-                samples = self.prior.sample_block(self.parameters['error_test_samples'])
+                samples = _prior_sample_block(self.prior, self.parameters['error_test_samples'], self.noise, self.observable)
             B = self.prior.R if self.prior_preconditioned else None
             _, avg, std = projection_error_test(self.V_GN, samples, ranks, B=B, d=self.d_GN, cut_off=cut_off,
                                                 collective=self.collective)
@@ -358,7 +495,8 @@ class ActiveSubspaceProjector:
                     self.parameters['rank'] = max(self.parameters['rank'], want)
                 self.construct_output_subspace()
             if output_samples is None:
-                output_samples = self.observable.sample_observables(self.parameters['error_test_samples'], self.prior, None)
+                output_samples = _observable_samples(self.observable, self.prior, self.control_distribution,
+                                                     self.parameters['error_test_samples'], self.noise, self.ctx)
             _, avg, std = projection_error_test(self.U_NG, output_samples, ranks, d=self.d_NG, cut_off=cut_off,
                                                 collective=self.collective)
             results += [avg, std]
@@ -378,20 +516,29 @@ class KLEProjector:
         self.parameters = parameters
         self.ctx = ctx or L.Context.default()
         self.noise = None
+        # the mass matrix: assembled matrices (scipy / PETSc / dolfin) go to HBM as CSR; anything else stays a host
+        # operator behind the vector protocol, its size read off the vectors its own init_vector makes
         self.M = as_device_operator(prior.M, ctx=self.ctx)
         self.N = self.M.shape[0]
         if hasattr(prior, "C") and prior.C is not None:
             self.C = as_device_operator(prior.C, self.N, self.ctx)          # explicit covariance (config 2)
         else:
-            self.C = as_device_operator(Solver2Operator(prior.Rsolver), self.N, self.ctx)   # :103
+            shaper = H.find_init_vector(prior.Rsolver) or H.find_init_vector(getattr(prior, "R", None)) or H.find_init_vector(prior.M)
+            self.C = as_device_operator(Solver2Operator(prior.Rsolver, mpi_comm=mesh_constructor_comm, init_vector=shaper),
+                                        self.N, self.ctx)                   # :103
         self.d_KLE = None
         self.V_KLE = None
         self.M_orthogonal = None
 
     def _Msolver(self):
+        """M^-1 for the M-orthogonal double pass.  With M in HBM as CSR the solve is a device Jacobi-PCG to 1e-13 (tighter
+        than the host Krylov solver hippylib builds for ``prior.Msolver``); a mass matrix that could only be wrapped as a
+        host operator keeps the prior's own solver."""
+        if isinstance(self.M, CsrOperator) and not isinstance(getattr(self.prior, "Msolver", None), DeviceOperator):
+            return CsrPCGSolver(self.M.csr, ctx=self.ctx)
         ms = getattr(self.prior, "Msolver", None)
         if ms is None:
-            ms = CsrPCGSolver(self.M.csr, ctx=self.ctx)
+            raise ValueError("KLEProjector: prior.Msolver is needed when prior.M is not an assembled matrix")
         return ms
 
     def random_input_projector(self):
@@ -441,7 +588,7 @@ class KLEProjector:
                 self.parameters['rank'] = max(self.parameters['rank'], want)
             self.construct_input_subspace()
         if samples is None:
-            samples = self.prior.sample_block(self.parameters['error_test_samples'])
+            samples = _prior_sample_block(self.prior, self.parameters['error_test_samples'])
         _, avg, std = projection_error_test(self.V_KLE, samples, ranks, B=self.M if self.M_orthogonal else None,
                                             d=self.d_KLE, cut_off=cut_off, collective=self.collective)
         return avg, std
@@ -517,26 +664,47 @@ class PODProjector:
         self.observable = observable
         self.prior = prior
         self.control_distribution = control_distribution
+        if mesh_constructor_comm is None and hasattr(observable, "mpi_comm"):
+            mesh_constructor_comm = observable.mpi_comm()                               # :66-69
         self.mesh_constructor_comm = mesh_constructor_comm
         self.collective = collective if collective is not None else NullCollective()   # the reference forgets the import (:77)
         self.ctx = ctx or L.Context.default()
+        self.noise = None
+        if _speaks_reference_protocol(observable) and hasattr(prior, "init_vector"):
+            self.noise = H.new_host_vector(mesh_constructor_comm)                       # :84-85
+            prior.init_vector(self.noise, "noise")
         self.d = None
         self.U_MV = None
+        self.u_at_mean = None
         self.LocalObservables = None
 
     def set_snapshots(self, snapshots):
         """Precomputed local snapshots: (n, N) array (q_data layout, :224-225) or a MultiVector."""
         self.LocalObservables = snapshots if isinstance(snapshots, MultiVector) else MultiVector.from_vectors(snapshots, ctx=self.ctx)
 
+    def solve_at_mean(self):
+        """The forward solve at the prior mean (:99-113): sets up a nonlinear problem before the sampling loop."""
+        problem = getattr(self.observable, "problem", None)
+        if problem is None or not hasattr(self.prior, "mean"):
+            return
+        self.u_at_mean = problem.generate_state()
+        point = [self.u_at_mean, self.prior.mean, None]
+        if self.control_distribution is not None:
+            if hasattr(self.control_distribution, 'mean'):
+                point.append(self.control_distribution.mean)
+            else:
+                z_mean = self.observable.generate_vector(H.CONTROL)
+                self.control_distribution.sample(z_mean)
+                point.append(z_mean)
+        problem.solveFwd(self.u_at_mean, point)
+
     def construct_subspace(self):
         t0 = time.time()
         if self.LocalObservables is None:
-            n = self.parameters['sample_per_process']
-            if hasattr(self.observable, 'observable_stream'):                               # the loop at :343-357, overlapped
-                self.LocalObservables = ingest_stream(self.observable.observable_stream(n, self.prior, None), n, 1,
-                                                      self.observable.output_dimension(), ctx=self.ctx)
-            else:
-                self.set_snapshots(self.observable.sample_observables(n, self.prior, None))
+            if _speaks_reference_protocol(self.observable):
+                self.solve_at_mean()                                                          # :336
+            self.LocalObservables = _observable_samples(self.observable, self.prior, self.control_distribution,
+                                                        self.parameters['sample_per_process'], self.noise, self.ctx)   # :343-357
         X = self.LocalObservables
         LocalPODOperator = SnapshotGramOperator(X, scale=1.0 / X.nvec())                      # :359-361
         GlobalPODOperator = CollectiveOperator(LocalPODOperator, self.collective, mpi_op='avg')  # :363
@@ -556,7 +724,8 @@ class PODProjector:
         if self.d is None or self.U_MV is None:
             self.construct_subspace()
         if samples is None:
-            samples = self.observable.sample_observables(self.parameters['sample_per_process'], self.prior, None)
+            samples = _observable_samples(self.observable, self.prior, self.control_distribution,
+                                          self.parameters['sample_per_process'], self.noise, self.ctx)
         _, avg, std = projection_error_test(self.U_MV, samples, ranks, d=self.d, cut_off=cut_off, collective=self.collective)
         return avg, std
 

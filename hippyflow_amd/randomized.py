@@ -16,35 +16,71 @@ Two execution routes, same arithmetic:
   (MatMvMult, (B-)orthogonalize, dot_mv, small eigensolve, MvDSmatMult) are each a C-ABI call.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _lib as L
+from . import hostvec as H
 from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NativeCollective, NullCollective
 from .multivector import MatMvMult, MultiVector, MvDSmatMult, Vector
 from .operators import DeviceOperator, Solver2Operator, as_device_operator
 
 
 class _ParRandom:
-    """hp.parRandom stand-in: counter-based Philox4x32-10 + Box-Muller on the device.  The state is
-    (seed, stream); every ``normal`` call consumes one stream, so that all ranks that make the same
-    sequence of calls draw identical numbers (no broadcast needed)."""
+    """hp.parRandom stand-in: counter-based Philox4x32-10 + Box-Muller on the device (hfmi_randn_fill).
 
-    def __init__(self, seed=1):
+    hp.parRandom is seeded per process and only Omega, drawn on rank 0, travels (activeSubspaceProjector.py:433-443).
+    Here the Philox key is (seed, namespace) and there are two families of streams:
+
+    * SHARED draws (namespace 0, counter ``shared_stream``): every rank that makes the same sequence of calls gets the
+      same numbers, so a probe block needs no broadcast.  Default for blocks (``MultiVector``).
+    * PRIVATE draws (namespace rank + 1, counter ``stream``): distinct on every rank and disjoint from every shared
+      draw -- the Monte-Carlo noise of the sampling loops.  Default for vectors, device or host.
+
+    A host (dolfin-like) vector is filled through a device block of its length and ``set_local``."""
+
+    def __init__(self, seed=1, rank=None):
         self.seed = int(seed)
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.stream = 0
+        self.shared_stream = 0
 
     def reseed(self, seed, stream=0):
-        self.seed, self.stream = int(seed), int(stream)
+        self.seed, self.stream, self.shared_stream = int(seed), int(stream), int(stream)
 
-    def normal(self, sigma, out):
-        mv = out._mv if isinstance(out, Vector) else out
-        L.call("hfmi_randn_fill", mv.handle, C.c_uint64(self.seed & (2 ** 64 - 1)), C.c_uint32(self.stream & 0xFFFFFFFF), float(sigma))
-        self.stream += 1
+    def split(self, rank):
+        """Re-key the private draws for this rank of a sample-parallel run (done by the collectives' constructors)."""
+        self.rank = int(rank)
+
+    def key(self, shared):
+        return (self.seed & 0xFFFFFFFF) | ((0 if shared else (self.rank + 1) & 0xFFFFFFFF) << 32)
+
+    def normal(self, sigma, out, shared=None):
+        host = H.is_host_vector(out)
+        if shared is None:
+            shared = isinstance(out, MultiVector)
+        if shared:
+            stream, self.shared_stream = self.shared_stream, self.shared_stream + 1
+        else:
+            stream, self.stream = self.stream, self.stream + 1
+        if host:
+            mv = MultiVector(int(len(out.get_local())), 1)
+        else:
+            mv = out._mv if isinstance(out, Vector) else out
+        L.call("hfmi_randn_fill", mv.handle, C.c_uint64(self.key(shared)), C.c_uint32(stream & 0xFFFFFFFF), float(sigma))
+        if host:
+            out.set_local(mv.to_vectors()[0])
+            out.apply("")
 
     def normal_perturb(self, sigma, out):
+        if H.is_host_vector(out):
+            tmp = H._copy_vector(out)
+            self.normal(sigma, tmp)
+            out.axpy(1.0, tmp)
+            return
         tmp = MultiVector(out._mv if isinstance(out, Vector) else out)
-        self.normal(sigma, tmp)
+        self.normal(sigma, Vector(ctx=tmp.ctx, _mv=tmp) if isinstance(out, Vector) else tmp)
         (out._mv if isinstance(out, Vector) else out).axpy(1.0, tmp)
 
 
@@ -152,7 +188,9 @@ def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, 
         return _fused(A_dev, coll, mpi_op, None, None, Omega, k, s, sort_by_abs, use_mgs, literal_T)
     Q = MultiVector(Omega)
     Y = MultiVector(Omega.size(), nvec, ctx=Omega.ctx)
-    for _ in range(s):
+    for i in range(s):
+        if i:
+            Y.zero()          # block operators of the reference accumulate into y (activeSubspaceProjector.py:214-221)
         MatMvMult(A, Q, Y)
         Q.swap(Y)
     Q.orthogonalize(L.QR_MGS if use_mgs else L.QR_AUTO)
@@ -166,12 +204,19 @@ def doublePass(A, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, 
     return d, U
 
 
-def _as_solver_operator(Binv, N, ctx):
+def _as_solver_operator(Binv, N, ctx, B=None):
     """B^-1 as an operator.  An object that is both the operator and its own solver (``prior.Hlr``: ``mult`` applies B,
-    ``solve`` applies B^-1; activeSubspaceProjector.py:455-459) contributes its ``inverse()``."""
+    ``solve`` applies B^-1; activeSubspaceProjector.py:455-459) contributes its ``inverse()``.  A host solver whose
+    vectors cannot be shaped from the solver itself borrows ``B.init_vector`` (hippylib wraps it the same way)."""
     if isinstance(Binv, DeviceOperator) and hasattr(Binv, "inverse"):
         return Binv.inverse()
-    return as_device_operator(Binv, N, ctx)
+    shaper = None
+    if not isinstance(Binv, DeviceOperator) and H.find_init_vector(Binv) is None and B is not None:
+        if not isinstance(B, DeviceOperator):
+            shaper = H.find_init_vector(B)
+        else:
+            shaper = getattr(B, "_shaper", None)          # a host operator already wrapped: the init_vector it was wrapped with
+    return as_device_operator(Binv, N, ctx, init_vector=shaper)
 
 
 def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_mgs=False, fused=True, literal_T=False):
@@ -183,14 +228,16 @@ def doublePassG(A, B, Binv, Omega, k, s=1, check=False, sort_by_abs=False, use_m
     A_dev, coll, mpi_op = _unwrap_collective(A)
     if fused and A_dev is not None:
         B_dev = as_device_operator(B, N, Omega.ctx)
-        Binv_dev = _as_solver_operator(Binv, N, Omega.ctx)
+        Binv_dev = _as_solver_operator(Binv, N, Omega.ctx, B)
         return _fused(A_dev, coll, mpi_op, B_dev, Binv_dev, Omega, k, s, sort_by_abs, use_mgs, literal_T)
     # B^{-1}: a device operator / solver as is; a host solver object (solve(y, x) on numpy arrays, like the
     # PETSc solvers of the reference) is reached through a host-callback operator
-    Binv_op = _as_solver_operator(Binv, N, Omega.ctx)
+    Binv_op = _as_solver_operator(Binv, N, Omega.ctx, B)
     Ybar = MultiVector(N, nvec, ctx=Omega.ctx)
     Q = MultiVector(Omega)
-    for _ in range(s):
+    for i in range(s):
+        if i:
+            Ybar.zero()
         MatMvMult(A, Q, Ybar)
         MatMvMult(Binv_op, Ybar, Q)
     Q.Borthogonalize(B, L.QR_MGS if use_mgs else L.QR_AUTO)

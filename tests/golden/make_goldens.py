@@ -27,6 +27,17 @@ reference's own code, unchanged:
 * ``PriorPreconditionedProjector.mult``        (modeling/priorPreconditionedProjector.py:19-55)
 * ``LowRankRectangularOperator.mult/transpmult`` (modeling/lowRankRectangularOperator.py:17-66)
 
+* section 7 (``protocol.npz``): the reference's OWN sampling loops and operator chains over a numpy PDE
+  (tests/helpers/fake_pde.py) wrapped in the reference's ``LinearStateObservable``:
+  ``PODProjector.construct_subspace``                       (modeling/PODProjector.py:331-389)
+  ``ObservableJacobian.mult / transpmult``, ``JTJ.mult``     (modeling/jacobian.py:62-166)
+  ``ActiveSubspaceProjector`` batched and serialized routes (modeling/activeSubspaceProjector.py:163-248,347-620)
+  ``KLEProjector.construct_input_subspace``                 (modeling/KLEProjector.py:136-199)
+  with ``hp.doublePass[G]`` stood in by a recorder that runs oracle/hippylib_restated.py over the reference's
+  operator objects and keeps every block that went in and came out, and ``hp.parRandom`` by the Philox map of
+  oracle/philox.py under the key / stream convention of ``hippyflow_amd.randomized._ParRandom`` (hippylib's own
+  mt19937 stream cannot be reproduced outside hippylib)
+
 Only INPUTS and OUTPUTS are stored (data, not source).  Nothing from the
 reference or from the stand-ins is written into the repository.
 """
@@ -39,6 +50,9 @@ import scipy.sparse as sp
 
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(OUT))
+sys.path.insert(0, ROOT)                                   # oracle/
+sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))  # fake_pde
 
 
 # --------------------------------------------------------------------------
@@ -112,6 +126,9 @@ class _Vector:
         self._a *= s
         return self
 
+    def size(self):
+        return self._a.shape[0]
+
 
 class _MultiVector:
     """Column list with the members hippyflow touches (dot_v / reduce / [])."""
@@ -141,6 +158,126 @@ class _MultiVector:
         for a, c in zip(alpha, self.cols):
             y.axpy(float(a), c)
 
+    def dense(self):
+        return np.asfortranarray(np.stack([c.get_local() for c in self.cols], axis=1))
+
+    @classmethod
+    def from_dense(cls, A):
+        v = _Vector()
+        v.init(A.shape[0])
+        mv = cls(v, A.shape[1])
+        for j in range(A.shape[1]):
+            mv[j].set_local(A[:, j])
+        return mv
+
+
+class _PhiloxParRandom:
+    """hp.parRandom stand-in producing the numbers hippyflow_amd's device generator produces: Philox key
+    (seed, namespace), blocks from the shared namespace 0 / counter ``shared_stream``, vectors from the private namespace
+    rank + 1 / counter ``stream`` (hippyflow_amd/randomized.py)."""
+
+    def __init__(self, seed=1, rank=0):
+        self.seed, self.rank, self.stream, self.shared_stream = seed, rank, 0, 0
+
+    def reseed(self, seed):
+        self.seed, self.stream, self.shared_stream = seed, 0, 0
+
+    def normal(self, sigma, out):
+        from oracle import philox
+        if isinstance(out, _MultiVector):
+            key = self.seed & 0xFFFFFFFF
+            Z = philox.randn_block(out[0].size(), out.nvec(), key, self.shared_stream, sigma)
+            self.shared_stream += 1
+            for j in range(out.nvec()):
+                out[j].set_local(Z[:, j])
+        else:
+            key = (self.seed & 0xFFFFFFFF) | ((self.rank + 1) << 32)
+            out.set_local(philox.randn_block(out.size(), 1, key, self.stream, sigma)[:, 0])
+            self.stream += 1
+
+
+class _LowRankOperator:
+    """hp.LowRankOperator(d, U, init_vector): y = U diag(d) U^T x (dot_v, scale, reduce)."""
+
+    def __init__(self, d, U, my_init_vector=None):
+        self.d, self.U, self.my_init_vector = d, U, my_init_vector
+
+    def init_vector(self, x, dim):
+        self.my_init_vector(x, dim)
+
+    def mult(self, x, y):
+        y.zero()
+        self.U.reduce(y, self.d * self.U.dot_v(x))
+
+
+class _Solver2Operator:
+    def __init__(self, S, mpi_comm=None, init_vector=None):
+        self.S = S
+        self.my_init_vector = init_vector or getattr(S, "init_vector", None)
+
+    def init_vector(self, x, dim):
+        self.my_init_vector(x, dim)
+
+    def mult(self, x, y):
+        self.S.solve(y, x)
+
+
+def _MatMvMult(A, x, y):
+    assert x.nvec() == y.nvec()
+    if hasattr(A, "matMvMult"):
+        A.matMvMult(x, y)
+    else:
+        for i in range(x.nvec()):
+            A.mult(x[i], y[i])
+
+
+class _Recorder:
+    """Stands in for hp.doublePass / hp.doublePassG: runs the restated algorithm (oracle/hippylib_restated.py) over the
+    REFERENCE's operator objects and keeps Omega, every block handed to A and what A returned, d and U."""
+
+    def __init__(self):
+        self.calls = []
+
+    class _BlockAdapter:                 # reference operator on stand-in vectors -> the oracle's numpy block protocol
+        def __init__(self, A, log):
+            self.A, self.log = A, log
+
+        def matMvMult(self, X, Y):
+            Xs = _MultiVector.from_dense(X)
+            Ys = _MultiVector.from_dense(np.zeros_like(X))
+            _MatMvMult(self.A, Xs, Ys)
+            out = Ys.dense()
+            self.log.append((np.array(X), out))
+            Y += out
+
+    class _VecAdapter:
+        def __init__(self, op):
+            self.op = op
+
+        def mult(self, x, y):
+            xs, ys = vec(x), vec(np.zeros_like(x))
+            self.op.mult(xs, ys)
+            y[...] = ys.get_local()
+
+        def solve(self, y, x):
+            xs, ys = vec(x), vec(np.zeros_like(x))
+            self.op.solve(ys, xs)
+            y[...] = ys.get_local()
+
+    def doublePass(self, A, Omega, k, s=1, check=False):
+        from oracle import hippylib_restated as hp_o
+        log = []
+        d, U = hp_o.double_pass(self._BlockAdapter(A, log), Omega.dense(), k, s=s)
+        self.calls.append(dict(kind="doublePass", Omega=Omega.dense(), applications=log, d=d, U=U))
+        return d, _MultiVector.from_dense(U)
+
+    def doublePassG(self, A, B, Binv, Omega, k, s=1, check=False):
+        from oracle import hippylib_restated as hp_o
+        log = []
+        d, U = hp_o.double_pass_g(self._BlockAdapter(A, log), self._VecAdapter(B), self._VecAdapter(Binv), Omega.dense(), k, s=s)
+        self.calls.append(dict(kind="doublePassG", Omega=Omega.dense(), applications=log, d=d, U=U))
+        return d, _MultiVector.from_dense(U)
+
 
 class _ParameterList(dict):
     def __init__(self, data):
@@ -163,6 +300,13 @@ def _install_standins():
     hp.ParameterList = _ParameterList
     hp.MultiVector = _MultiVector
     hp.STATE, hp.PARAMETER, hp.ADJOINT = 0, 1, 2
+    hp.parRandom = _PhiloxParRandom()
+    hp.LowRankOperator = _LowRankOperator
+    hp.Solver2Operator = _Solver2Operator
+    hp.MatMvMult = _MatMvMult
+    hp.recorder = _Recorder()
+    hp.doublePass = hp.recorder.doublePass
+    hp.doublePassG = hp.recorder.doublePassG
     mpi4py = _Permissive("mpi4py")
     MPI = _Permissive("mpi4py.MPI")
     MPI.SUM = "sum"
@@ -392,7 +536,129 @@ def main():
         json.dump({"ActiveSubspaceParameterList": _plain(hf.ActiveSubspaceParameterList()),
                    "PODParameterList": _plain(hf.PODParameterList()),
                    "KLEParameterList": _plain(hf.KLEParameterList())}, f, indent=1, sort_keys=True)
+
+    # ---- 7. the reference's sampling loops and operator chains over a numpy PDE ----
+    protocol_fixtures(hf)
     print("goldens written to", OUT)
+
+
+def protocol_fixtures(hf):
+    import contextlib
+    import io
+    import tempfile
+
+    import hippylib as hp
+    import fake_pde as fp
+    pod_mod, as_mod, kle_mod = (sys.modules["hippyflow.modeling." + name]
+                                for name in ("PODProjector", "activeSubspaceProjector", "KLEProjector"))
+    from hippyflow.modeling.jacobian import JTJ, ObservableJacobian
+    from hippyflow.modeling.observable import LinearStateObservable
+
+    for mod in (pod_mod, as_mod, kle_mod):                      # FEniCS-only helpers of the constructors
+        mod.checkMeshConsistentPartitioning = lambda mesh, collective: True
+        mod.spectrum_plot = lambda *a, **k: None
+    S = fp.SIZES
+    n, q, ns, r, p, seed = S["n"], S["q"], S["n_samples"], S["rank"], S["oversampling"], S["seed"]
+    Bmat = fp.observation_matrix(q, n)
+    out = dict(n=n, q=q, n_samples=ns, rank=r, oversampling=p, seed=seed)
+    tmp = tempfile.mkdtemp() + "/"
+
+    def new_observable(mesh=None, **kwargs):
+        return LinearStateObservable(fp.NumpyProblem(n, _Vector), fp.MatrixOperator(Bmat))
+
+    def run(tag, body):
+        hp.parRandom.reseed(seed)
+        hp.recorder.calls.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            body()
+        for c, call in enumerate(hp.recorder.calls):
+            pre = "%s_call%d_" % (tag, c)
+            out[pre + "Omega"], out[pre + "d"], out[pre + "U"] = call["Omega"], call["d"], call["U"]
+            for a, (X, Y) in enumerate(call["applications"]):
+                out[pre + "app%d_in" % a], out[pre + "app%d_out" % a] = X, Y
+
+    # (i) POD: the snapshot loop, the low-rank snapshot-Gram operator, doublePass
+    def pod_body():
+        params = hf.PODParameterList()
+        params['sample_per_process'], params['rank'], params['oversampling'] = 4 * ns, r, p
+        params['output_directory'], params['verbose'] = tmp, False
+        pod = hf.PODProjector(new_observable(), fp.NumpyPrior(n, _Vector), collective=hf.NullCollective(), parameters=params)
+        pod.construct_subspace()
+        out["pod_saved_d"] = np.load(tmp + "POD_d.npy")
+        out["pod_saved_projector"] = np.load(tmp + "POD_projector.npy")
+    run("pod", pod_body)
+    # the snapshots themselves: the first application's operator is (1/n) X X^T; recover X by re-running the loop
+    hp.parRandom.reseed(seed)
+    obs, prior = new_observable(), fp.NumpyPrior(n, _Vector)
+    noise, u, m = vec(np.zeros(n)), obs.generate_vector(hp.STATE), obs.generate_vector(hp.PARAMETER)
+    snaps, ms_drawn = [], []
+    for _ in range(4 * ns):
+        hp.parRandom.normal(1, noise)
+        prior.sample(noise, m)
+        obs.solveFwd(u, [u, m, None])
+        snaps.append(obs.evalu(u).get_local())
+        ms_drawn.append(m.get_local())
+    out["pod_snapshots"], out["prior_draws"] = np.stack(snaps), np.stack(ms_drawn)
+
+    # (ii) ObservableJacobian / JTJ at the first prior draw
+    obs = new_observable()
+    m.set_local(ms_drawn[0])
+    obs.solveFwd(u, [u, m, None])
+    obs.setLinearizationPoint([u, m, None])
+    Jop = ObservableJacobian(obs)
+    xin, xq = np.cos(np.arange(n) * 0.3), np.sin(np.arange(q) * 0.7 + 0.2)
+    yq, yn, yjtj = vec(np.zeros(q)), vec(np.zeros(n)), vec(np.zeros(n))
+    Jop.mult(vec(xin), yq)
+    Jop.transpmult(vec(xq), yn)
+    JTJ(Jop).mult(vec(xin), yjtj)
+    out.update(jac_x=xin, jac_xq=xq, jac_mult=yq.get_local(), jac_transpmult=yn.get_local(), jac_jtj=yjtj.get_local(),
+               jac_dense=obs.problem.jacobian_dense(Bmat), jac_shape=np.array(Jop.shape))
+
+    # (iii) active subspace: batched / serialized, prior-preconditioned or not, input and output
+    def as_params(serialized, ms_given=False):
+        params = hf.ActiveSubspaceParameterList()
+        params['samples_per_process'], params['rank'], params['oversampling'] = ns, r, p
+        params['serialized_sampling'], params['ms_given'] = serialized, ms_given
+        params['observable_constructor'], params['observable_kwargs'] = new_observable, {}
+        params['output_directory'], params['verbose'], params['save_and_plot'] = tmp, False, False
+        params['store_Omega'] = False
+        return params
+
+    def as_body(serialized, prior_preconditioned, which="input", ms_given=False):
+        def body():
+            AS = hf.ActiveSubspaceProjector(new_observable(), fp.NumpyPrior(n, _Vector), collective=hf.NullCollective(),
+                                            parameters=as_params(serialized, ms_given))
+            if ms_given:
+                AS.ms = [vec(mi) for mi in ms_drawn[:ns]]
+                AS.zs = ns * [None]
+            if which == "input":
+                d, dec, enc = AS.construct_input_subspace(prior_preconditioned=prior_preconditioned)
+                out["%s_encoder" % body.tag] = enc.dense()
+            else:
+                d, dec, enc = AS.construct_output_subspace()
+        return body
+
+    for tag, args in (("as_batched_prior", (False, True)), ("as_batched_plain", (False, False)),
+                      ("as_serial_prior", (True, True)), ("as_serial_plain", (True, False)),
+                      ("as_batched_output", (False, False, "output")), ("as_serial_output", (True, False, "output")),
+                      ("as_serial_given", (True, True, "input", True))):
+        body = as_body(*args)
+        body.tag = tag
+        run(tag, body)
+
+    # (iv) KLE, mass-orthogonal and identity
+    def kle_body(orthogonality):
+        def body():
+            params = hf.KLEParameterList()
+            params['rank'], params['oversampling'], params['verbose'], params['save_and_plot'] = r, p, False, False
+            kle = hf.KLEProjector(fp.NumpyPrior(n, _Vector), mesh_constructor_comm=_FakeComm(), collective=hf.NullCollective(),
+                                  parameters=params)
+            d, dec, enc = kle.construct_input_subspace(orthogonality)
+            out["kle_%s_encoder" % orthogonality] = enc.dense()
+        return body
+    run("kle_mass", kle_body("mass"))
+    run("kle_identity", kle_body("identity"))
+    np.savez_compressed(os.path.join(OUT, "protocol.npz"), **out)
 
 
 if __name__ == "__main__":

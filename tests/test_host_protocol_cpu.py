@@ -1,0 +1,145 @@
+"""CPU suite: the host side of the reference's protocols (no GPU, no device call): dolfin-like host vectors, the
+``ObservableJacobian`` / ``JTJ`` / ``JJT`` chain on them against the reference-generated fixture, and the communicator
+helpers of collectives/comm_utils.py:19-75."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import hippyflow_amd as hf
+from hippyflow_amd import hostvec as H
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+import fake_pde as fp  # noqa: E402
+
+
+def hv(a):
+    v = hf.HostVector()
+    v.init(len(a))
+    v.set_local(a)
+    return v
+
+
+def test_host_vector_surface():
+    x, y = hv([1.0, 2.0, 3.0]), hv([0.5, 0.5, 0.5])
+    assert x.size() == x.local_size() == len(x) == 3 and x.mpi_comm().Get_size() == 1
+    x.axpy(2.0, y)
+    np.testing.assert_array_equal(x.get_local(), [2.0, 3.0, 4.0])
+    assert x.inner(y) == 4.5 and abs(x.norm("l2") - np.sqrt(29.0)) < 1e-15 and x.norm("linf") == 4.0
+    x *= 0.5
+    c = hf.HostVector(x)                       # dl.Vector(other): a copy
+    x.zero()
+    np.testing.assert_array_equal(c.get_local(), [1.0, 1.5, 2.0])
+    np.testing.assert_array_equal((c * y).get_local(), [0.5, 0.75, 1.0])       # u * indicator (observable.py:59)
+    with pytest.raises(ValueError):
+        x.set_local([1.0])
+    got = c.get_local()
+    got[0] = 99.0                              # get_local hands out a copy, as dolfin does
+    assert c.get_local()[0] == 1.0
+    mv = hf.HostMultiVector(c, 4)
+    assert mv.nvec() == 4 and mv[2].size() == 3 and not mv[2].get_local().any()
+    mv[1].set_local([1, 2, 3])
+    cp = hf.HostMultiVector(mv)
+    mv.zero()
+    assert cp[1].get_local()[2] == 3.0
+    assert H.is_host_vector(c) and not H.is_host_vector(np.zeros(3))
+    hf.set_host_vector_factory(lambda comm: "made")
+    try:
+        assert hf.new_host_vector() == "made"
+    finally:
+        hf.set_host_vector_factory(None)
+    assert isinstance(hf.new_host_vector(), hf.HostVector)        # no FEniCS in this image
+
+
+def test_shape_lookup_follows_solver2operator():
+    class WithOperator:
+        def operator(self):
+            return fp.MatrixOperator(np.eye(5))
+
+    class WithGetOperator:
+        def get_operator(self):
+            return fp.MatrixOperator(np.eye(7))
+
+    assert H.shape_with(H.find_init_vector(WithOperator()), 0).size() == 5
+    assert H.shape_with(H.find_init_vector(WithGetOperator()), 1).size() == 7
+    assert H.find_init_vector(object()) is None
+    assert H.shape_with(lambda x: x.init(3), 0).size() == 3          # init_vector(x) without a dim (activeSubspaceProjector.py:144)
+
+
+def test_jacobian_chain_on_host_vectors_matches_the_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "protocol.npz"))
+    n, q = int(g["n"]), int(g["q"])
+    obs = fp.ProtocolObservable(fp.NumpyProblem(n, hf.HostVector), fp.MatrixOperator(fp.observation_matrix(q, n)))
+    u, m = obs.generate_vector(hf.STATE), obs.generate_vector(hf.PARAMETER)
+    m.set_local(g["prior_draws"][0])
+    obs.solveFwd(u, [u, m, None])
+    obs.setLinearizationPoint([u, m, None])
+    J = hf.ObservableJacobian(obs)
+    assert tuple(J.shape) == (q, n)
+    yq, yn, yj, yjj = hv(np.zeros(q)), hv(np.zeros(n)), hv(np.zeros(n)), hv(np.zeros(q))
+    J.mult(hv(g["jac_x"]), yq)
+    J.transpmult(hv(g["jac_xq"]), yn)
+    jtj = hf.JTJ(J)
+    jtj.mult(hv(g["jac_x"]), yj)
+    hf.JJT(J).mult(hv(g["jac_xq"]), yjj)
+    np.testing.assert_allclose(yq.get_local(), g["jac_mult"], rtol=1e-12)
+    np.testing.assert_allclose(yn.get_local(), g["jac_transpmult"], rtol=1e-12)
+    np.testing.assert_allclose(yj.get_local(), g["jac_jtj"], rtol=1e-12)
+    Jd = g["jac_dense"]
+    np.testing.assert_allclose(yjj.get_local(), Jd @ (Jd.T @ g["jac_xq"]), rtol=1e-11)
+    np.testing.assert_allclose(J.rows(), Jd, rtol=1e-10, atol=1e-14)
+    v = hf.HostVector()
+    jtj.init_vector(v, 0)
+    assert v.size() == n
+    with pytest.raises(ValueError):
+        J.init_vector(v, 2)
+    # the mean of operators on host vectors (SummedListOperator), and the serialized accumulation on host column lists
+    ysum = hv(np.zeros(n))
+    hf.SummedListOperator([jtj, jtj], average=True).mult(hv(g["jac_x"]), ysum)
+    np.testing.assert_allclose(ysum.get_local(), g["jac_jtj"], rtol=1e-12)
+    prior = fp.NumpyPrior(n, hf.HostVector)
+    X, Y = hf.HostMultiVector(v, 2), hf.HostMultiVector(v, 2)
+    X[0].set_local(g["jac_x"])
+    X[1].set_local(np.ones(n))
+    given = hv(g["prior_draws"][0])
+    op = hf.SeriallySampledJacobianOperator(obs, None, prior, operation='JTJ', ms=[given, given], average=True)
+    op.matMvMult(X, Y)
+    np.testing.assert_allclose(Y[0].get_local(), g["jac_jtj"], rtol=1e-11)
+    np.testing.assert_allclose(Y[1].get_local(), Jd.T @ (Jd @ np.ones(n)), rtol=1e-11)
+
+
+class _MpiLikeComm:
+    def __init__(self, size=1, rank=0):
+        self._size, self._rank, self.splits = size, rank, []
+
+    def Get_size(self):
+        return self._size
+
+    def Get_rank(self):
+        return self._rank
+
+    def Split(self, color, key):
+        self.splits.append((color, key))
+        return ("split", color, key)
+
+    def bcast(self, obj, root=0):
+        return obj
+
+
+def test_split_communicators_without_mesh_partitioning(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    mesh_comm, coll_comm = hf.splitCommunicators(None, 1, 1)
+    assert mesh_comm.Get_size() == 1 and mesh_comm.rank == 0 and coll_comm is None
+    world = _MpiLikeComm(size=4, rank=3)
+    mesh_comm, coll_comm = hf.splitCommunicators(world, 1, 4)
+    assert world.splits == [(3, 0), (0, 3)]                       # color / key of comm_utils.py:35-39 for n_subdomain = 1
+    with pytest.raises(NotImplementedError):
+        hf.splitCommunicators(world, 2, 2)
+    with pytest.raises(AssertionError):
+        hf.splitCommunicators(world, 1, 3)
+    assert hf.checkMeshConsistentPartitioning(object(), hf.NullCollective()) is True
+    # a one-rank mpi communicator needs no device communicator at all
+    coll = hf.MultipleSerialPDEsCollective(_MpiLikeComm())
+    assert isinstance(coll, hf.NullCollective) and coll.size() == 1
+    assert hf.MultipleSamePartitioningPDEsCollective(coll) is coll
