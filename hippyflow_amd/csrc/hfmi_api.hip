@@ -81,9 +81,30 @@ static void* pool_take(hfmi_ctx* ctx, size_t bytes) {
   return nullptr;
 }
 
+void ctx_watch_comm(hfmi_ctx* ctx, hfmi_comm* c) {
+  if (ctx && c) ctx->watched_comms.push_back(c);
+}
+void ctx_unwatch_comm(hfmi_ctx* ctx, hfmi_comm* c) {
+  if (!ctx) return;
+  for (size_t i = 0; i < ctx->watched_comms.size(); ++i)
+    if (ctx->watched_comms[i] == c) {
+      ctx->watched_comms.erase(ctx->watched_comms.begin() + i);
+      return;
+    }
+}
+// after a host synchronisation: did a stream-ordered collective behind it give up?  (one read of pinned host memory per
+// communicator; no device call)
+int ctx_check_comm(hfmi_ctx* ctx) {
+  for (hfmi_comm* c : ctx->watched_comms) HFMI_TRY(comm_check_error(c));
+  return HFMI_OK;
+}
+
 int ctx_ws(hfmi_ctx* ctx, int slot, size_t bytes, void** out) {
   if (bytes > ctx->ws_bytes[slot]) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // buffers other streams work in: the panel reductions' staging area (auxiliary stream), the ingest buffer
+    if (slot == WS_COMM) HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+    if (slot == WS_INGEST) HIP_TRY(hipStreamSynchronize(ctx->ingest_stream));
     if (ctx->ws[slot]) HIP_TRY(hipFree(ctx->ws[slot]));
     ctx->ws[slot] = nullptr;
     ctx->ws_bytes[slot] = 0;
@@ -220,7 +241,7 @@ extern "C" int hfmi_ctx_get_stream(hfmi_ctx* ctx, void** hip_stream) {
 extern "C" int hfmi_ctx_synchronize(hfmi_ctx* ctx) {
   if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return HFMI_OK;
+  return ctx_check_comm(ctx);
 }
 extern "C" int hfmi_ctx_device_info(hfmi_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes) {
   if (!ctx) HFMI_FAIL(HFMI_ERR_INVALID, "null ctx");
@@ -478,7 +499,7 @@ extern "C" int hfmi_block_download(const hfmi_block* b, double* host, int layout
   } else {
     HFMI_FAIL(HFMI_ERR_INVALID, "block_download: unknown layout %d", layout);
   }
-  return HFMI_OK;
+  return ctx_check_comm(ctx);                 // the block may have come through a collective that gave up
 }
 extern "C" int hfmi_block_zero(hfmi_block* b) {
   if (!b) HFMI_FAIL(HFMI_ERR_INVALID, "null block");
@@ -503,6 +524,7 @@ static int read_back(hfmi_ctx* ctx, const double* dev, size_t count, double* hos
   HFMI_TRY(ctx_pinned(ctx, count * sizeof(double), &pin));
   HIP_TRY(hipMemcpyAsync(pin, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HFMI_TRY(ctx_check_comm(ctx));            // what was read may have come through a collective that gave up
   memcpy(host, pin, count * sizeof(double));
   return HFMI_OK;
 }
@@ -1070,6 +1092,9 @@ static int op_apply_raw(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, double 
       if (op->comm && g_comm_panels > 1 && beta == 0.0 && comm_transport(op->comm) != 0 && k <= 256) {
         void* sv = nullptr;
         HFMI_TRY(ctx_ws(ctx, WS_COMM, ((size_t)Y->ld + 16) * k * sizeof(double), &sv));
+        // the largest panel is at most the whole block: size the transport's staging area for that before the first panel is
+        // in flight on the auxiliary stream (regrowing it later would close peers' mappings under a running reduction)
+        HFMI_TRY(comm_reserve_stage(op->comm, ((size_t)Y->ld + 16) * k * sizeof(double)));
         panel_reduce pr = {op, 0, 0, (double*)sv, HFMI_OK};
         ctx->nn_hook = panel_reduce_hook;
         ctx->nn_hook_user = &pr;

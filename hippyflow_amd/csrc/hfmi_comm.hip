@@ -157,7 +157,8 @@ struct hfmi_comm {
   comm_shared* sh_dev;       // the segment as the GPU sees it (hipHostRegister), null = host-synchronised P2P
   bool sh_registered;
   unsigned long long seq;    // collectives issued on the stream-ordered path (identical on every rank)
-  int* dev_err;              // device word: a poll gave up (time-out)
+  int* dev_err;              // the error word as the GPU sees it: a poll gave up (time-out) or met a peer's poison
+  int* err_host;             // the same word from the host (pinned, mapped): read after any stream synchronisation, no copy
   bool distinct_devices;
   char why[256];             // how the transport was chosen (hfmi_comm_describe)
   // device scratch for host payloads on the RCCL-only route
@@ -297,7 +298,10 @@ static int p2p_alloc_stage(hfmi_comm* c, size_t want) {
 // Collective: every rank calls it with the same `bytes`.
 static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
   if (bytes <= c->stage_bytes) return HFMI_OK;
-  HIP_TRY(hipStreamSynchronize(c->ctx->stream));  // this rank's last copy out of the old buffer is complete
+  // this rank's last copy out of the old buffer is complete -- on BOTH streams collectives run on (row panels of an operator
+  // application are reduced on the auxiliary stream)
+  HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(c->ctx->aux_stream));
   HFMI_TRY(shm_barrier(c));                       // nobody is still reading the old buffers
   HFMI_TRY(p2p_close_peers(c));
   HFMI_TRY(shm_barrier(c));                       // every mapping of the old buffer is closed before it is freed
@@ -351,24 +355,30 @@ __global__ void __launch_bounds__(256) k_p2p_reduce(p2p_ptrs bufs, int nranks, i
     for (int p = 0; p < nranks; ++p) reinterpret_cast<d2*>(bufs.p[p])[i] = acc;
   }
 }
-// stream-ordered hand-shake through the host segment: one thread publishes this rank's sequence number ...
-__global__ void k_p2p_signal(comm_flag* flag, unsigned long long seq) {
+// stream-ordered hand-shake through the host segment: one thread publishes this rank's sequence number -- or, once this
+// rank has given up on a collective, the POISON value: every peer that waits on it raises its own error word, so a
+// time-out on one rank can never leave another rank with a silently unreduced block ...
+constexpr unsigned long long P2P_POISON = ~0ull;
+__global__ void k_p2p_signal(comm_flag* flag, unsigned long long seq, const int* dev_err) {
   __threadfence_system();
-  __hip_atomic_store(&flag->v, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long v = (*(volatile const int*)dev_err) ? P2P_POISON : seq;
+  __hip_atomic_store(&flag->v, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ... and one wave waits until every rank has published at least `seq` (lane p polls rank p).  wall_clock64 runs at a
-// constant 100 MHz: the poll gives up after `ticks` and raises dev_err instead of occupying the GPU for ever.
+// constant 100 MHz: the poll gives up after `ticks` and raises the error word instead of occupying the GPU for ever.
 __global__ void k_p2p_wait(const comm_flag* flags, int nranks, unsigned long long seq, long long ticks, int* dev_err) {
   const int p = threadIdx.x;
   if (p >= nranks) return;
   const long long t0 = wall_clock64();
-  while (__hip_atomic_load(&flags[p].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+  unsigned long long v;
+  while ((v = __hip_atomic_load(&flags[p].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < seq) {
     if (wall_clock64() - t0 > ticks || *(volatile int*)dev_err) {
-      atomicExch(dev_err, 1);
+      atomicExch_system(dev_err, 1);
       return;
     }
     __builtin_amdgcn_s_sleep(8);
   }
+  if (v == P2P_POISON) atomicExch_system(dev_err, 1);
 }
 
 static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, hipStream_t stream) {
@@ -388,10 +398,10 @@ static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, 
     // stream-ordered: no host synchronisation, no host barrier
     const unsigned long long seq = ++c->seq;
     const long long ticks = (long long)(comm_timeout_s() * 1e8);
-    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->arrive[c->rank], seq);
+    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->arrive[c->rank], seq, (const int*)c->dev_err);
     hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, stream, c->sh_dev->arrive, c->nranks, seq, ticks, c->dev_err);
     if (hi > lo) hipLaunchKernelGGL(k_p2p_reduce, dim3(blocks), dim3(256), 0, stream, bufs, c->nranks, lo, hi, scale, op, c->dev_err);
-    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->done[c->rank], seq);
+    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->done[c->rank], seq, (const int*)c->dev_err);
     hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, stream, c->sh_dev->done, c->nranks, seq, ticks, c->dev_err);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(data, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -412,14 +422,20 @@ static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, 
   // starts with a stream synchronise of its own copy-in, which is ordered behind this copy on the same stream
   return HFMI_OK;
 }
-// a poll that gave up leaves a flag on the device; the entry points that synchronise anyway look at it
-static int p2p_check_err(hfmi_comm* c) {
-  if (!c->dev_err) return HFMI_OK;
-  int e = 0;
-  HIP_TRY(hipMemcpy(&e, c->dev_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (e) HFMI_FAIL(HFMI_ERR_COMM, "rank %d: a peer rank did not reach a collective within %.0f s (stream-ordered p2p transport)", c->rank, comm_timeout_s());
+// A poll that gave up (or met a peer's poison) leaves a flag in pinned host memory.  Every host synchronisation that can
+// follow a collective looks at it (ctx_check_comm: read_back, block download, context synchronise, the barrier); the first
+// rank to see it also raises the segment's abort flag, which ends every later barrier of the peers.  The communicator is
+// unusable afterwards: the word is deliberately sticky.
+int comm_check_error(hfmi_comm* c) {
+  if (!c || !c->err_host) return HFMI_OK;
+  if (*(volatile int*)c->err_host) {
+    if (c->sh) c->sh->abort_flag.store(1, std::memory_order_relaxed);
+    HFMI_FAIL(HFMI_ERR_COMM, "rank %d: a peer rank did not reach a collective within %.0f s, or gave up on one (stream-ordered p2p transport); "
+              "the block it returned is NOT reduced and the communicator is unusable", c->rank, comm_timeout_s());
+  }
   return HFMI_OK;
 }
+static int p2p_check_err(hfmi_comm* c) { return comm_check_error(c); }
 
 static int p2p_bcast_dev(hfmi_comm* c, void* data, size_t bytes, int root) {
   hfmi_ctx* ctx = c->ctx;
@@ -496,8 +512,9 @@ extern "C" int hfmi_comm_decide_transport(int nranks, const int* has_device, con
 // ------------------------------------------------------------------ init / destroy
 static void comm_free(hfmi_comm* c) {
   if (!c) return;
+  if (c->ctx) ctx_unwatch_comm(c->ctx, c);
   if (c->sh_registered) (void)hipHostUnregister(c->sh);
-  if (c->dev_err) (void)hipFree(c->dev_err);
+  if (c->err_host) (void)hipHostFree(c->err_host);
   if (c->sh) munmap(c->sh, sizeof(comm_shared));
   delete c;
 }
@@ -511,13 +528,21 @@ static int p2p_enable_stream_order(hfmi_comm* c) {
     return HFMI_OK;                                         // stays host-synchronised
   }
   c->sh_registered = true;
-  void* dp = nullptr;
-  if (hipHostGetDevicePointer(&dp, c->sh, 0) != hipSuccess || hipMalloc((void**)&c->dev_err, sizeof(int)) != hipSuccess) {
+  void *dp = nullptr, *ep = nullptr;
+  if (hipHostGetDevicePointer(&dp, c->sh, 0) != hipSuccess || hipHostMalloc((void**)&c->err_host, 64, hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
     return HFMI_OK;
   }
-  HIP_TRY(hipMemset(c->dev_err, 0, sizeof(int)));
+  *c->err_host = 0;
+  if (hipHostGetDevicePointer(&ep, c->err_host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(c->err_host);
+    c->err_host = nullptr;
+    return HFMI_OK;
+  }
+  c->dev_err = (int*)ep;
   c->sh_dev = (comm_shared*)dp;
+  ctx_watch_comm(c->ctx, c);
   return HFMI_OK;
 }
 // the first all-reduce on a fresh RCCL communicator, with a time-out: 1 = right sum, 2 = anything else
@@ -644,7 +669,7 @@ static int comm_init_impl(hfmi_ctx* ctx, const void* id_bytes, int nranks, int r
     }
     c->transport = TRANSPORT_RCCL;
     snprintf(c->why, sizeof(c->why), "rccl requested (HFMI_COMM_TRANSPORT=rccl): no node segment, no fallback");
-    if (unlink_path) (void)unlink(unlink_path);   // peers that have not read it yet would time out: rccl-only launches should ship the id themselves
+    // the id file stays until ncclCommInitRank -- a rendezvous of all ranks -- has returned: every peer has read it by then
   }
 
   if (c->transport == TRANSPORT_RCCL) {
@@ -655,6 +680,7 @@ static int comm_init_impl(hfmi_ctx* ctx, const void* id_bytes, int nranks, int r
     static const char* inject = getenv("HFMI_COMM_INJECT");     // test hook: "init" / "first" make THIS path fail on every rank
     int r = (inject && !strcmp(inject, "init")) ? -1 : g_rccl.CommInitRank(&c->nccl, nranks, id.rccl, rank);
     if (!c->sh) {
+      if (rank == 0 && unlink_path) (void)unlink(unlink_path);
       if (r != 0) {
         comm_free(c);
         HFMI_FAIL(HFMI_ERR_COMM, "ncclCommInitRank failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "injected failure");
@@ -760,6 +786,10 @@ extern "C" int hfmi_comm_describe(const hfmi_comm* c, char* buf, int len) {
 }
 
 int comm_transport(const hfmi_comm* c) { return c ? c->transport : 0; }
+int comm_reserve_stage(hfmi_comm* c, size_t bytes) {
+  if (!c || c->transport != TRANSPORT_P2P || c->nranks == 1) return HFMI_OK;
+  return p2p_ensure_stage(c, bytes);
+}
 extern "C" int hfmi_comm_info(const hfmi_comm* c, int* nranks, int* rank, int* transport) {
   if (!c) HFMI_FAIL(HFMI_ERR_INVALID, "null communicator");
   if (nranks) *nranks = c->nranks;

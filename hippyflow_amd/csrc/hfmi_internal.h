@@ -60,6 +60,7 @@ struct hfmi_status_words {  // device-resident, read back by the host after smal
   long long tick[8];        // shader-clock section timings of the last small kernel (HFMI_DEBUG_TIMING=1 prints them)
 };
 
+struct hfmi_comm;
 struct hfmi_ctx {
   int device;
   hipStream_t stream;
@@ -106,6 +107,7 @@ struct hfmi_ctx {
   hipEvent_t ev_ingest[HFMI_INGEST_RING];
   int64_t ingest_seq;
   void* late_pinned;              // status words / R_jj table of an orthogonalisation pass taken on trust (hfmi_api.hip)
+  std::vector<hfmi_comm*> watched_comms;   // communicators whose device-side error word the host synchronisation points check
   void* pinned_cb;
   size_t pinned_cb_bytes;
   hipEvent_t ev_cb[4];            // D2H done x2, H2D done x2
@@ -163,6 +165,14 @@ struct hfmi_op {
 int comm_allreduce_device(hfmi_comm* c, double* data, int64_t count, int op);
 int comm_allreduce_device_on(hfmi_comm* c, double* data, int64_t count, int op, void* hip_stream /* null = the context's */);
 int comm_transport(const hfmi_comm* c);   // 0 host, 1 rccl, 2 p2p
+// HFMI_ERR_COMM if a stream-ordered collective of this communicator gave up (time-out) or met a peer that had; no device call
+int comm_check_error(hfmi_comm* c);
+// make the p2p staging buffer large enough for a collective of `bytes` NOW (a collective: every rank calls it with the same
+// size), so that it never regrows while row panels of an application are in flight on the auxiliary stream
+int comm_reserve_stage(hfmi_comm* c, size_t bytes);
+void ctx_watch_comm(hfmi_ctx* ctx, hfmi_comm* c);
+void ctx_unwatch_comm(hfmi_ctx* ctx, hfmi_comm* c);
+int ctx_check_comm(hfmi_ctx* ctx);        // comm_check_error over the watched communicators
 
 // ------------------------------------------------------------------ kernel launchers (hfmi_gemm.hip)
 // C (m x k) = scale * A^T B (+ beta * C); A: N x m, B: N x k column-major blocks.

@@ -14,6 +14,7 @@ factorisation whose operator spectrum is known in closed form:
 The latent factors are kept so that tests and bench.py can evaluate the SAME operator on the host in
 factored form (a few N x c products) -- that is what makes an oracle check affordable at full size.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -21,7 +22,6 @@ import numpy as np
 from . import _lib as L
 from .multivector import MultiVector, MvDSmatMult
 from .operators import CsrOperator, MeanJTJfromDataOperator, SnapshotGramOperator, npToDeviceOperator
-from .randomized import _ParRandom
 
 
 class Workload:
@@ -30,10 +30,8 @@ class Workload:
 
 def _orthonormal_block(N, c, seed, stream, ctx):
     """N x c block with orthonormal columns: device QR of a Philox Gaussian draw (c <= 256)."""
-    rnd = _ParRandom(seed)
-    rnd.stream = stream
     W = MultiVector(int(N), int(c), ctx=ctx)
-    rnd.normal(1.0, W)
+    L.call("hfmi_randn_fill", W.handle, C.c_uint64(int(seed) & 0xFFFFFFFF), C.c_uint32(int(stream)), 1.0)
     W.orthogonalize(L.QR_CHOL)
     return W
 
@@ -103,10 +101,8 @@ def as_workload(N, ns_local, q=100, latent=100, rate=0.06, seed=4, first_sample=
     wl.noise, wl.seed = float(noise), int(seed)
     if noise:
         E = MultiVector(int(N), int(q), ctx=ctx)
-        rnd = _ParRandom(seed)
-        for i in range(ns_local):
-            rnd.stream = NOISE_STREAM0 + first_sample + i
-            rnd.normal(1.0, E)
+        for i in range(ns_local):             # Philox key = seed, stream = NOISE_STREAM0 + global sample index (hfmi_randn_fill)
+            L.call("hfmi_randn_fill", E.handle, C.c_uint64(int(seed) & 0xFFFFFFFF), C.c_uint32(NOISE_STREAM0 + first_sample + i), 1.0)
             wl.J.view(i * q, q).axpy(float(noise), E)
     wl.operator = MeanJTJfromDataOperator.from_block(wl.J, ns_local, q, noise_cov_inv=noise_cov_inv)
     return wl

@@ -9,6 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "helpers", "gpu_comm_worker.py")
+WORKER2 = os.path.join(ROOT, "tests", "helpers", "gpu_comm_worker2.py")
 
 
 def test_one_rank_rccl_communicator_is_bit_transparent():
@@ -127,3 +128,36 @@ def test_row_panel_reduction_is_bit_identical_and_overlapped():
     np.testing.assert_array_equal(d0, out[4][0])
     np.testing.assert_array_equal(U0.to_dense(), out[4][1])
     coll.close()
+
+
+def test_a_late_rank_fails_every_rank_instead_of_returning_unreduced_data(tmp_path):
+    """Stream-ordered p2p: a poll that gives up (HFMI_COMM_TIMEOUT_S) skips the reduction.  The rank that gave up must see
+    HFMI_ERR_COMM at its next host synchronisation, and so must the rank that arrived late: it meets the poison value the
+    first rank published instead of a sequence number (hfmi_comm.hip k_p2p_signal / k_p2p_wait)."""
+    import json
+    from hippyflow_amd.launch import spawn_ranks
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="120", HFMI_TEST_TIMEOUT_S="1", HFMI_P2P_SYNC="stream", HFMI_TEST_LATE_S="4")
+    assert spawn_ranks([WORKER2, str(tmp_path), "late"], 2, env=env, timeout=300) == 0
+    for rank in (0, 1):
+        r = json.load(open(os.path.join(str(tmp_path), "late_rank%d.json" % rank)))
+        assert r["transport"] == "p2p" and r["p2p_sync"] == "stream"
+        assert r["outcome"] == "HfmiError", (rank, r)
+        assert "did not reach a collective" in r["message"] and "NOT reduced" in r["message"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_panels_across_real_peers_are_bit_identical(tmp_path, world):
+    """The panel hook of an operator application with REAL peers behind it (ranks sharing the GPU, stream-ordered p2p on the
+    auxiliary stream): 4 panels == one all-reduce after the product, bit for bit, on every rank, and every rank holds the
+    same eigenpairs."""
+    from hippyflow_amd.launch import spawn_ranks
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="120", HFMI_P2P_SYNC="stream")
+    assert spawn_ranks([WORKER2, str(tmp_path), "panels"], world, env=env, timeout=900) == 0
+    rs = [np.load(os.path.join(str(tmp_path), "panels_rank%d.npz" % r)) for r in range(world)]
+    for r in rs:
+        assert str(r["transport"]) == "p2p" and str(r["p2p_sync"]) == "stream"
+        np.testing.assert_array_equal(r["d0"], r["d4"])
+        np.testing.assert_array_equal(r["U0"], r["U4"])
+        assert float(r["overlapped0"]) == 0.0 and float(r["overlapped4"]) > 0.0
+        np.testing.assert_array_equal(r["d4"], rs[0]["d4"])
+        np.testing.assert_array_equal(r["U4"], rs[0]["U4"])
