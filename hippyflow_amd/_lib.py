@@ -72,6 +72,7 @@ SIGNATURES = {
     "hfmi_op_dense_sym": [_P, _P, _PP],
     "hfmi_op_csr": [_P, _P, _PP],
     "hfmi_op_csr_pcg": [_P, _P, C.c_double, C.c_int, _PP],
+    "hfmi_op_solver_info": [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "hfmi_op_compose3": [_P, _P, _P, _P, _PP],
     "hfmi_op_host_callback": [_P, HOST_APPLY_FN, _P, C.c_int64, _PP],
     "hfmi_op_host_set_chunk": [_P, C.c_int],

@@ -665,6 +665,24 @@ extern "C" int hfmi_csr_create(hfmi_ctx* ctx, int64_t nrows, int64_t ncols, int6
   m->ell_w = 0;
   m->ell_idx = nullptr;
   m->ell_val = nullptr;
+  m->gersh_lmax = m->cheb_lmin = m->cheb_lmax = 0.0;
+  m->cheb_state = 0;
+  if (nrows == ncols) {
+    // Gershgorin bound on the spectrum of D^-1 A: max_i sum_j |a_ij| / a_ii (used by the Chebyshev solve; 0 = no bound: a
+    // row without a positive diagonal entry)
+    double g = 0.0;
+    bool ok = true;
+    for (int64_t i = 0; i < nrows && ok; ++i) {
+      double dii = 0.0, sum = 0.0;
+      for (int64_t z = indptr[i]; z < indptr[i + 1]; ++z) {
+        if (indices[z] == i) dii += data[z];
+        sum += fabs(data[z]);
+      }
+      if (!(dii > 0.0)) ok = false;
+      else g = std::max(g, sum / dii);
+    }
+    m->gersh_lmax = ok ? g : 0.0;
+  }
   {
     // ELL image when the longest row is short and the padding stays below 1.5x (FEM mass / stiffness matrices)
     int64_t wmax = 0;
@@ -805,6 +823,14 @@ extern "C" int hfmi_op_csr_pcg(hfmi_ctx* ctx, const hfmi_csr* M, double rel_tol,
   *out = op;
   return HFMI_OK;
 }
+extern "C" int hfmi_op_solver_info(const hfmi_op* op, int* iterations, int* method, double* lmin, double* lmax) {
+  if (!op || op->kind != OP_CSR_PCG) HFMI_FAIL(HFMI_ERR_INVALID, "op_solver_info: not a sparse solver operator");
+  if (iterations) *iterations = op->last_iters;
+  if (method) *method = op->last_method;
+  if (lmin) *lmin = op->csr->cheb_state == 1 ? op->csr->cheb_lmin : 0.0;
+  if (lmax) *lmax = op->csr->cheb_state == 1 ? op->csr->cheb_lmax : 0.0;
+  return HFMI_OK;
+}
 extern "C" int hfmi_op_compose3(hfmi_ctx* ctx, hfmi_op* a, hfmi_op* b, hfmi_op* c, hfmi_op** out) {
   if (!ctx || !a || !b || !c || !out) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   hfmi_op* op = op_new(ctx, OP_COMPOSE3);
@@ -858,6 +884,177 @@ extern "C" int hfmi_op_destroy(hfmi_op* op) {
 
 // Y = M^{-1} W for an SPD CSR matrix: Jacobi-preconditioned CG run on all vectors at once (independent
 // recurrences, shared SpMM); per-vector scalars stay on the device, the host only polls convergence.
+static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y);
+
+// ---- spectrum of D^-1 A for the Chebyshev solve -------------------------------------------------------------------------
+// extreme eigenvalues of the symmetric tridiagonal matrix (a, b) by bisection on the Sturm count
+static int sturm_count(const std::vector<double>& a, const std::vector<double>& b, double x) {
+  int cnt = 0;
+  double q = a[0] - x;
+  if (q < 0) ++cnt;
+  for (size_t i = 1; i < a.size(); ++i) {
+    if (q == 0.0) q = 1e-300;
+    q = a[i] - x - b[i - 1] * b[i - 1] / q;
+    if (q < 0) ++cnt;
+  }
+  return cnt;
+}
+static void tridiag_extremes(const std::vector<double>& a, const std::vector<double>& b, double* smallest, double* largest) {
+  double lo = a[0], hi = a[0];
+  for (size_t i = 0; i < a.size(); ++i) {
+    const double rad = (i > 0 ? fabs(b[i - 1]) : 0.0) + (i + 1 < a.size() ? fabs(b[i]) : 0.0);
+    lo = std::min(lo, a[i] - rad);
+    hi = std::max(hi, a[i] + rad);
+  }
+  const int m = (int)a.size();
+  double l = lo, h = hi;
+  for (int it = 0; it < 200 && h - l > 1e-14 * std::max(fabs(l), fabs(h)); ++it) {   // smallest: first x with count >= 1
+    const double mid = 0.5 * (l + h);
+    if (sturm_count(a, b, mid) >= 1) h = mid; else l = mid;
+  }
+  *smallest = 0.5 * (l + h);
+  l = lo; h = hi;
+  for (int it = 0; it < 200 && h - l > 1e-14 * std::max(fabs(l), fabs(h)); ++it) {   // largest: last x with count < m
+    const double mid = 0.5 * (l + h);
+    if (sturm_count(a, b, mid) >= m) h = mid; else l = mid;
+  }
+  *largest = 0.5 * (l + h);
+}
+// One scalar Jacobi-CG run on a pseudo-random right-hand side, on the device, with its two inner products per iteration read
+// back: the CG coefficients are the Lanczos matrix of D^-1 A, whose extreme eigenvalues approach those of D^-1 A from inside.
+// Once per matrix (~40 iterations of one-vector kernels).
+static int cheb_estimate(hfmi_op* op) {
+  hfmi_ctx* ctx = op->ctx;
+  hfmi_csr* M = const_cast<hfmi_csr*>(op->csr);
+  const int64_t N = M->nrows;
+  M->cheb_state = -1;
+  if (!(M->gersh_lmax > 0.0)) return HFMI_OK;
+  hfmi_block *R, *Z, *P, *AP;
+  HFMI_TRY(ctx_tmp_block(ctx, 8, N, 1, &R));
+  HFMI_TRY(ctx_tmp_block(ctx, 9, N, 1, &Z));
+  HFMI_TRY(ctx_tmp_block(ctx, 10, N, 1, &P));
+  HFMI_TRY(ctx_tmp_block(ctx, 11, N, 1, &AP));
+  void* sc = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, 4 * sizeof(double), &sc));
+  double *rz = (double*)sc, *pap = rz + 1, *rz_new = rz + 2;
+  HFMI_TRY(launch_randn(ctx, R->p, N, 1, R->ld, 0x5eedc0deull, 77u, 1.0));
+  HFMI_TRY(launch_diag_scale(ctx, Z->p, Z->ld, R->p, R->ld, M->inv_diag, N, 1));
+  HFMI_TRY(launch_copy(ctx, P->p, P->ld, Z->p, Z->ld, N, 1));
+  HFMI_TRY(launch_col_dots(ctx, R->p, R->ld, Z->p, Z->ld, N, 1, rz));
+  double h_rz = 0, h_pap = 0, h_new = 0;
+  HFMI_TRY(read_back(ctx, rz, 1, &h_rz));
+  const double rz0 = h_rz;
+  std::vector<double> alpha, beta;
+  for (int it = 0; it < 60 && h_rz > 1e-28 * rz0; ++it) {
+    HFMI_TRY(launch_csr_spmm(ctx, M, P->p, P->ld, AP->p, AP->ld, 1, false));
+    HFMI_TRY(launch_col_dots(ctx, P->p, P->ld, AP->p, AP->ld, N, 1, pap));
+    HFMI_TRY(launch_col_axpy_dev(ctx, R->p, R->ld, AP->p, AP->ld, N, 1, rz, pap, -1.0));
+    HFMI_TRY(launch_diag_scale(ctx, Z->p, Z->ld, R->p, R->ld, M->inv_diag, N, 1));
+    HFMI_TRY(launch_col_dots(ctx, R->p, R->ld, Z->p, Z->ld, N, 1, rz_new));
+    HFMI_TRY(launch_col_xpby_dev(ctx, P->p, P->ld, Z->p, Z->ld, N, 1, rz_new, rz));
+    double two[3];
+    HFMI_TRY(read_back(ctx, rz, 3, two));
+    h_pap = two[1];
+    h_new = two[2];
+    if (!(h_pap > 0.0) || !std::isfinite(h_new)) return HFMI_OK;     // not SPD: leave the Chebyshev route off
+    alpha.push_back(h_rz / h_pap);
+    beta.push_back(h_new / h_rz);
+    HIP_TRY(hipMemcpyAsync(rz, rz_new, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    h_rz = h_new;
+  }
+  const size_t m = alpha.size();
+  if (m < 3) return HFMI_OK;
+  std::vector<double> a(m), b(m > 1 ? m - 1 : 0);
+  for (size_t i = 0; i < m; ++i) {
+    a[i] = 1.0 / alpha[i] + (i > 0 ? beta[i - 1] / alpha[i - 1] : 0.0);
+    if (i + 1 < m) b[i] = sqrt(beta[i]) / alpha[i];
+  }
+  double tmin, tmax;
+  tridiag_extremes(a, b, &tmin, &tmax);
+  if (!(tmin > 0.0) || !(tmax >= tmin)) return HFMI_OK;
+  // Ritz values lie inside the spectrum: widen them; never above Gershgorin's bound
+  M->cheb_lmin = 0.9 * tmin;
+  M->cheb_lmax = std::min(M->gersh_lmax, 1.05 * tmax);
+  if (M->cheb_lmax < tmax) M->cheb_lmax = tmax * (1.0 + 1e-9);
+  M->cheb_state = 1;
+  return HFMI_OK;
+}
+
+// Y = M^-1 W by Chebyshev iteration on row-major copies (hfmi_cheb.hip); *handled = false: the caller runs the block CG
+static int cheb_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, bool* handled) {
+  hfmi_ctx* ctx = op->ctx;
+  hfmi_csr* M = const_cast<hfmi_csr*>(op->csr);
+  const int64_t N = W->N;
+  const int k = W->nvec;
+  *handled = false;
+  static const bool off = getenv("HFMI_PCG") != nullptr;          // A/B switch: always the block CG
+  if (off || M->cheb_state < 0) return HFMI_OK;
+  if (M->cheb_state == 0) HFMI_TRY(cheb_estimate(op));
+  if (M->cheb_state != 1) return HFMI_OK;
+  const double lmin = M->cheb_lmin, lmax = M->cheb_lmax;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  hfmi_block *Bb, *X0b, *X1b;
+  HFMI_TRY(ctx_tmp_block(ctx, 8, N, k, &Bb));
+  HFMI_TRY(ctx_tmp_block(ctx, 9, N, k, &X0b));
+  HFMI_TRY(ctx_tmp_block(ctx, 10, N, k, &X1b));
+  double* B = Bb->p;                                                 // used as row-major N x k arrays (ld >= N: large enough)
+  double* X[2] = {X0b->p, X1b->p};
+  void* sc = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)2 * k * sizeof(double), &sc));
+  double* bb = (double*)sc;
+  double* rr = bb + k;
+  HFMI_TRY(launch_block_to_dense(ctx, W->p, W->ld, B, N, k));
+  HFMI_TRY(launch_rm_colsq(ctx, B, N, k, bb));
+  HFMI_TRY(launch_cheb_first(ctx, B, X[1], X[0], M->inv_diag, N, k, 1.0 / theta));     // x_0 = 0 in X[0], x_1 in X[1]
+  int steps = 1, cur = 1;                                            // X[cur] = x_steps, X[cur ^ 1] = x_{steps-1}
+  const bool spread = delta > 1e-12 * theta;                         // else D^-1 A is a multiple of the identity: x_1 is the answer
+  double rho = spread ? delta / theta : 0.0;                         // 1 / sigma
+  int planned = 1;
+  if (spread) {
+    const double sk = sqrt(lmax / lmin), c = (sk - 1.0) / (sk + 1.0);
+    planned = (int)ceil(log(2.0 / op->rel_tol) / -log(c)) + 1;
+  }
+  if (planned > op->max_iter || planned > 200) {
+    // a spectrum this wide needs more steps than CG's superlinear convergence would: leave this matrix to the block CG
+    M->cheb_state = -1;
+    return HFMI_OK;
+  }
+  std::vector<double> h(2 * (size_t)k);
+  int budget = planned - 1;
+  for (int round = 0; round < 4; ++round) {
+    for (int i = 0; i < budget; ++i, ++steps) {
+      const double rho_new = 1.0 / (2.0 * theta / delta - rho);
+      HFMI_TRY(launch_cheb_step(ctx, M, B, X[cur], X[cur ^ 1], k, rho_new * rho, 2.0 * rho_new / delta, false));
+      rho = rho_new;
+      cur ^= 1;
+    }
+    // the true residual b - A x into the spare array, its column norms against those of b
+    void* rs = nullptr;
+    HFMI_TRY(ctx_ws(ctx, WS_STAGE, (size_t)N * k * sizeof(double), &rs));
+    HFMI_TRY(launch_cheb_step(ctx, M, B, X[cur], (double*)rs, k, 0.0, 0.0, true));
+    HFMI_TRY(launch_rm_colsq(ctx, (const double*)rs, N, k, rr));
+    HFMI_TRY(read_back(ctx, bb, (size_t)2 * k, h.data()));
+    bool done = true;
+    for (int j = 0; j < k; ++j) {
+      if (!std::isfinite(h[k + j]) || !std::isfinite(h[j]))
+        HFMI_FAIL(HFMI_ERR_NUMERIC, "csr solve: non-finite residual in vector %d after %d Chebyshev steps (matrix not SPD, or non-finite input)", j, steps);
+      if (!(h[k + j] <= op->rel_tol * op->rel_tol * h[j])) done = false;
+    }
+    if (done) {
+      op->last_iters = steps;
+      op->last_method = 1;
+      HFMI_TRY(launch_dense_to_block(ctx, X[cur], Y->p, Y->ld, N, k));
+      *handled = true;
+      return HFMI_OK;
+    }
+    if (!spread) break;
+    budget = std::max(2, planned / 3);
+    if (steps + budget > op->max_iter) break;
+  }
+  M->cheb_state = -1;       // the bracket of the spectrum was not good enough: this matrix goes back to the block CG for good
+  return HFMI_OK;
+}
+
 static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
   hfmi_ctx* ctx = op->ctx;
   hfmi_csr* M = const_cast<hfmi_csr*>(op->csr);
@@ -867,6 +1064,11 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
   if (!M->inv_diag) {
     HIP_TRY(hipMalloc((void**)&M->inv_diag, (size_t)N * sizeof(double)));
     HFMI_TRY(launch_csr_diag_inv(ctx, M));
+  }
+  {
+    bool handled = false;
+    HFMI_TRY(cheb_solve(op, W, Y, &handled));
+    if (handled) return HFMI_OK;
   }
   hfmi_block *R, *Z, *P, *AP;
   HFMI_TRY(ctx_tmp_block(ctx, 8, N, k, &R));
@@ -934,6 +1136,7 @@ static int pcg_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y) {
     }
   }
   op->last_iters = it;
+  op->last_method = 0;
   if (!done) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "csr_pcg: no convergence to %.1e in %d iterations", op->rel_tol, op->max_iter);
   return HFMI_OK;
 }

@@ -134,6 +134,12 @@ struct hfmi_csr {
   int ell_w;
   int32_t* ell_idx;
   double* ell_val;
+  // spectrum of the Jacobi-scaled matrix D^-1 A for the Chebyshev solve (hfmi_cheb.hip): an upper bound from Gershgorin's
+  // circles (computed from the host arrays at creation), a lower bound from the Lanczos matrix of one scalar CG run on the
+  // device (lazily, first solve); cheb_state: 0 = not estimated yet, 1 = usable, -1 = do not use (estimate failed / a solve
+  // did not reach its tolerance)
+  double gersh_lmax, cheb_lmin, cheb_lmax;
+  int cheb_state;
 };
 
 enum hfmi_op_kind { OP_SNAPSHOT_GRAM, OP_JTJ, OP_JJT, OP_DENSE_SYM, OP_CSR, OP_CSR_PCG, OP_COMPOSE3, OP_HOST };
@@ -150,6 +156,7 @@ struct hfmi_op {
   double rel_tol;
   int max_iter;
   int last_iters;
+  int last_method;        // sparse solver: 0 = block CG, 1 = Chebyshev (hfmi_op_solver_info)
   hfmi_op *a, *b, *c;
   hfmi_host_apply_fn host_fn;
   void* host_user;
@@ -210,6 +217,11 @@ int launch_block_to_dense_ld(hfmi_ctx* ctx, const double* p, int64_t ld, double*
 int launch_csr_spmm(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec,
                     bool accumulate);
 int launch_csr_diag_inv(hfmi_ctx* ctx, hfmi_csr* M);
+// Chebyshev iteration on row-major (nrows x k) work arrays (hfmi_cheb.hip)
+int launch_cheb_first(hfmi_ctx* ctx, const double* B, double* X1, double* X0, const double* inv_diag, int64_t nrows, int k, double inv_theta);
+int launch_cheb_step(hfmi_ctx* ctx, const hfmi_csr* M, const double* B, const double* Xc, double* Xp, int k, double c1, double c2, bool resid);
+int launch_rm_colsq(hfmi_ctx* ctx, const double* A, int64_t nrows, int k, double* out);
+int launch_dots_final(hfmi_ctx* ctx, const double* part, int nchunks, int nvec, double* out);
 // Y = M X fused with the per-column dots dots[j] = <X_j, Y_j> (PCG: p . A p); needs the ELL image
 int launch_ell_spmm_dot(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nvec,
                         double* dots);

@@ -402,6 +402,11 @@ __global__ __launch_bounds__(64) void k_col_dots_final(const double* __restrict_
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (threadIdx.x == 0) out[j] = s;
 }
+int launch_dots_final(hfmi_ctx* ctx, const double* part, int nchunks, int nvec, double* out) {
+  hipLaunchKernelGGL(k_col_dots_final, dim3(nvec), dim3(64), 0, ctx->stream, part, nchunks, nvec, out);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
 int launch_col_dots(hfmi_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t N, int nvec, double* out) {
   if (nvec <= 0) return HFMI_OK;
   void* part = nullptr;

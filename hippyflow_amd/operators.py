@@ -230,8 +230,10 @@ class CsrOperator(DeviceOperator):
 
 
 class CsrPCGSolver(DeviceOperator):
-    """Solver object for an SPD sparse matrix (prior.Msolver): ``solve(y, x)`` gives y = M^{-1} x by
-    Jacobi-preconditioned CG on the device; as an operator it IS hp.Solver2Operator(Msolver)."""
+    """Solver object for an SPD sparse matrix (prior.Msolver): ``solve(y, x)`` gives y = M^{-1} x to a relative
+    residual ``rel_tol`` per vector, on the device; as an operator it IS hp.Solver2Operator(Msolver).  The work is done by a
+    Jacobi-preconditioned Chebyshev iteration (hfmi_cheb.hip) when the Jacobi-scaled spectrum is narrow -- mass matrices --
+    and by Jacobi-preconditioned block CG otherwise; ``info()`` tells which."""
 
     def __init__(self, M, rel_tol=1e-13, max_iter=500, ctx=None):
         ctx = ctx or L.Context.default()
@@ -241,6 +243,13 @@ class CsrPCGSolver(DeviceOperator):
 
     def solve(self, y, x):
         self.mult(x, y)
+
+    def info(self):
+        """Of the last solve: {'iterations', 'method' ('chebyshev' | 'cg'), 'spectrum' (bracket of D^-1 M in use, or None)}."""
+        it, method, lo, hi = C.c_int(0), C.c_int(0), C.c_double(0), C.c_double(0)
+        L.call("hfmi_op_solver_info", self._op, C.byref(it), C.byref(method), C.byref(lo), C.byref(hi))
+        return {"iterations": it.value, "method": "chebyshev" if method.value == 1 else "cg",
+                "spectrum": (lo.value, hi.value) if hi.value > 0 else None}
 
 
 class HostCallbackOperator(DeviceOperator):

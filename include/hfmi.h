@@ -151,9 +151,16 @@ int hfmi_op_jjt(hfmi_ctx* ctx, const hfmi_block* J, int ndata, int q, double sca
 int hfmi_op_dense_sym(hfmi_ctx* ctx, const hfmi_block* C, hfmi_op** out);
 /* a4/a9: sparse operator  Y = M W  (prior.M.mult, prior.R.mult; hp.MatMvMult(B, decoder, encoder)) */
 int hfmi_op_csr(hfmi_ctx* ctx, const hfmi_csr* M, hfmi_op** out);
-/*     solver object for an SPD CSR matrix: Y = M^{-1} W by Jacobi-preconditioned block CG
- *     (prior.Msolver behind hp.Solver2Operator, KLEProjector.py:163-164) */
+/*     solver object for an SPD CSR matrix: Y = M^{-1} W to a relative residual rel_tol per vector
+ *     (prior.Msolver behind hp.Solver2Operator, KLEProjector.py:163-164).  Jacobi-preconditioned
+ *     Chebyshev iteration on a row-major copy of the block (one kernel per step, no inner products;
+ *     the spectrum of D^-1 M is bracketed once per matrix: Gershgorin + the Lanczos matrix of one
+ *     scalar CG run); Jacobi-preconditioned block CG when that bracket is too wide or does not
+ *     deliver the tolerance. */
 int hfmi_op_csr_pcg(hfmi_ctx* ctx, const hfmi_csr* M, double rel_tol, int max_iter, hfmi_op** out);
+/*     what the last solve of such an operator did: steps taken, method (0 block CG, 1 Chebyshev),
+ *     and the bracket of the spectrum of D^-1 M in use (0, 0: none) */
+int hfmi_op_solver_info(const hfmi_op* op, int* iterations, int* method, double* lmin, double* lmax);
 /*     Y = c (b (a W))  (MassPreconditionedCovarianceOperator M C M, KLEProjector.py:47-69) */
 int hfmi_op_compose3(hfmi_ctx* ctx, hfmi_op* a, hfmi_op* b, hfmi_op* c, hfmi_op** out);
 /*     host black box (FEniCS PDE solves, sparse LU ...): W and Y in HFMI_LAYOUT_VECTORS

@@ -240,6 +240,38 @@ def test_csr_spmm_and_pcg(ctx, N, k):
     assert rel(Z.to_dense(), ref) < 1e-10
 
 
+@pytest.mark.parametrize("k", [1, 7, 84, 130, 300])
+def test_sparse_solver_chebyshev_and_cg_routes(ctx, k):
+    """M^-1 (prior.Msolver, KLEProjector.py:163-164).  A mass matrix has a narrow Jacobi-scaled spectrum ([1/2, 2] for P1
+    elements): the Chebyshev iteration (hfmi_cheb.hip) serves it -- wave-per-row kernel for even k <= 128, thread-per-entry
+    kernel otherwise -- with the step count its bracket predicts; a stiffness-dominated matrix (condition number ~1e4) is left
+    to the block CG.  Both reach the residual they were asked for."""
+    import scipy.sparse.linalg as spla
+    N = 6000
+    rng = np.random.default_rng(k)
+    M, K = _fem(N)
+    X = rng.standard_normal((N, k)) * np.exp(rng.standard_normal(k))[None, :]        # columns of very different size
+    X[:, k // 2] = 0.0                                                               # and a zero right-hand side
+    Xmv, Z = hf.MultiVector.from_dense(X), hf.MultiVector(N, k)
+    solver = hf.CsrPCGSolver(M, rel_tol=1e-13)
+    solver.matMvMult(Xmv, Z)
+    info = solver.info()
+    lo, hi = info["spectrum"]
+    assert info["method"] == "chebyshev" and 20 <= info["iterations"] <= 40
+    ev = np.linalg.eigvalsh((M.toarray() / M.diagonal()[:, None] ** 0.5) / M.diagonal()[None, :] ** 0.5)
+    assert lo <= ev[0] and ev[-1] <= hi * (1 + 1e-9) and lo > 0.8 * ev[0] and hi < 1.1 * ev[-1]      # a bracket, and a tight one
+    res = M @ Z.to_dense() - X
+    assert np.all(np.linalg.norm(res, axis=0) <= 2e-13 * np.linalg.norm(X, axis=0) + 1e-300)
+    assert not Z.to_dense()[:, k // 2].any()
+    assert rel(Z.to_dense(), spla.splu(M.tocsc()).solve(X)) < 1e-11
+    stiff = (M + 1e-4 * K).tocsr()
+    solver2 = hf.CsrPCGSolver(stiff, rel_tol=1e-12, max_iter=4000)
+    solver2.matMvMult(Xmv, Z)
+    assert solver2.info()["method"] == "cg" and solver2.info()["spectrum"] is None
+    res = stiff @ Z.to_dense() - X
+    assert np.all(np.linalg.norm(res, axis=0) <= 1e-10 * np.linalg.norm(X, axis=0) + 1e-300)
+
+
 @pytest.mark.parametrize("k", [1, 13, 84])
 def test_csr_irregular_rows_use_the_csr_kernel(ctx, k):
     """A matrix with one dense row and empty rows has no ELL image (padding > 1.5x): SpMM and PCG must take the
