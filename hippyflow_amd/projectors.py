@@ -730,6 +730,17 @@ class PODProjector:
         return avg, std
 
 
+    def input_output_error_test(self, V_MV, Cinv=None, rank_pairs=[None]):
+        """Input-output projection error test (PODProjector.py:541-655): the output basis is this projector's POD basis,
+        ``V_MV`` the input basis (an AS decoder with ``Cinv = prior.R``, a KLE decoder with ``Cinv = prior.M``, or a random
+        one), ``rank_pairs`` the (input rank, output rank) pairs.  Returns (global_avg_rel_errors, global_std_rel_errors)."""
+        from .errors import input_output_error_test
+        assert self.d is not None and self.U_MV is not None
+        return input_output_error_test(self.observable, self.prior, self.U_MV, V_MV, rank_pairs, self.parameters['sample_per_process'],
+                                       Cinv=Cinv, noise=self.noise, collective=self.collective,
+                                       control_distribution=self.control_distribution)
+
+
 def weighted_l2_norm_vector(x, W):
     """PODProjector.py:658-661."""
     Wx = W @ x
@@ -759,6 +770,25 @@ class PODProjectorFromData:
         self.M_csr = sp.csr_matrix(M_output)
         self.ctx = ctx or L.Context.default()
 
+    def _randomized(self, u_data, u_rank, oversampling=20):
+        """More than 4096 snapshots (the n x n eigensolve on the device stops there; the reference's :812-833 takes any n): the
+        same modes from the N-dimensional form of the problem, (1/n) M X X^T M phi = lambda M phi with phi^T M phi = 1, by the
+        randomized double pass this library is built around (``doublePassG`` with B = M, B^-1 = the device mass solve).  The
+        eigenpairs are those of the randomized method (oversampling 20, one pass): exact to rounding when the snapshots have
+        numerical rank <= u_rank + 20, otherwise as accurate as the decay of the spectrum beyond that allows."""
+        import warnings
+        from .operators import ComposedOperator
+        warnings.warn("PODProjectorFromData: %d snapshots > 4096 -- using the randomized double pass on the N-dimensional "
+                      "generalized problem instead of the n x n Gram eigensolve" % u_data.shape[0])
+        X = MultiVector.from_vectors(u_data, ctx=self.ctx)
+        Mop = CsrOperator(self.M_csr, ctx=self.ctx)
+        A = ComposedOperator(Mop, SnapshotGramOperator(X, scale=1.0 / X.nvec()), Mop)
+        Omega = _draw_omega(X.size(), min(u_rank + oversampling, X.size()), NullCollective(), self.ctx)
+        d, phi_mv = doublePassG(A, Mop, CsrPCGSolver(Mop.csr, ctx=self.ctx), Omega, u_rank, s=1)
+        Mphi_mv = MultiVector(phi_mv)
+        Mop.matMvMult(phi_mv, Mphi_mv)
+        return d, phi_mv.to_dense(), Mphi_mv.to_dense()
+
     def construct_subspace(self, u_data, u_rank, shifted=True, method='hep', verify=False):
         n_data, dim_u = u_data.shape
         assert u_rank <= n_data, "number of samples needs to be greater than rank of projector"
@@ -767,10 +797,9 @@ class PODProjectorFromData:
             u_data = u_data - u_shift
         else:
             u_shift = np.zeros(u_data.shape[1])
-        if method in ('hep', 'ghep', 'inverse_ghep'):
-            if n_data > 4096:
-                raise NotImplementedError("the device Gram route handles up to 4096 snapshots (n x n eigensolve on the device); "
-                                          "use PODProjector (randomized) for larger snapshot sets")
+        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > 4096:
+            d, phi, Mphi = self._randomized(u_data, u_rank)
+        elif method in ('hep', 'ghep', 'inverse_ghep'):
             X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector
             Mop = CsrOperator(self.M_csr, ctx=self.ctx)
             MX = MultiVector(X.size(), X.nvec(), ctx=self.ctx)

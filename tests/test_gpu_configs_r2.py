@@ -298,6 +298,29 @@ def test_low_rank_operator_with_a_general_diagonal(ctx):
     assert np.abs(Ud.T @ Bd @ Ud - np.eye(6)).max() < 1e-10
 
 
+def test_pod_from_data_beyond_4096_snapshots_goes_through_the_randomized_pass(ctx):
+    """The reference's deterministic POD takes any number of snapshots (PODProjector.py:812-833); beyond the 4096 of the
+    device's n x n eigensolve the same modes come from the N-dimensional generalized problem by doublePassG.  Snapshots of
+    numerical rank 30 <= rank + oversampling: the result equals the oracle's 'hep' to rounding."""
+    from hippyflow_amd import workloads
+    rng = np.random.default_rng(8)
+    n, nx, ny, r = 4200, 30, 20, 18
+    N = nx * ny
+    M = workloads.grid_mass_matrix(nx, ny)
+    W0, _ = np.linalg.qr(rng.standard_normal((N, 30)))
+    u_data = (rng.standard_normal((n, 30)) * np.exp(-0.3 * np.arange(30))) @ W0.T + 0.25
+    pod = hf.PODProjectorFromData(M_output=M)
+    with pytest.warns(UserWarning, match="randomized double pass"):
+        d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=True, method="hep")
+    d_o, phi_o, Mphi_o, shift_o = hf_o.pod_from_data(u_data.copy(), M, r, shifted=True, method="hep")
+    np.testing.assert_allclose(d, d_o, rtol=1e-8)
+    np.testing.assert_allclose(shift, shift_o, atol=1e-14)
+    sg = np.sign(np.sum(phi * (M @ phi_o), axis=0))
+    np.testing.assert_allclose(phi * sg, phi_o, atol=1e-6)
+    np.testing.assert_allclose(Mphi * sg, Mphi_o, atol=1e-6)
+    assert np.abs(phi.T @ Mphi - np.eye(r)).max() < 1e-9
+
+
 # ------------------------------------------------------------------ error behaviour of the round-2 entry points
 def test_round2_entry_points_reject_bad_arguments(ctx):
     import ctypes as C

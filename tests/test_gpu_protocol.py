@@ -75,6 +75,39 @@ def test_pod_projector_runs_the_reference_sampling_loop(ctx, g, tmp_path):
     # the projection-error test draws its samples through the same loop
     avg, std = pod.test_output_errors(ranks=[2, 5])
     assert avg[1] < avg[0] < 1.0
+    # input-output error test (PODProjector.py:541-655) with a prior-preconditioned input basis: against a plain numpy
+    # evaluation of the same definition on the same draws
+    import scipy.sparse.linalg as spla
+    n, ns = int(g["n"]), params['sample_per_process']
+    rng = np.random.default_rng(4)
+    Vd = rng.standard_normal((n, 8))
+    Rm = prior.Rmat.toarray()
+    Lc = np.linalg.cholesky(Vd.T @ Rm @ Vd)
+    Vd = Vd @ np.linalg.inv(Lc).T                                    # V^T R V = I
+    V = hf.MultiVector.from_dense(Vd)
+    hf.parRandom.reseed(77)
+    pairs = [(2, 2), (8, 6)]
+    n0 = obs.n_fwd_solve
+    avg, std = pod.input_output_error_test(V, Cinv=prior.R, rank_pairs=pairs)
+    assert obs.n_fwd_solve - n0 == ns * (1 + len(pairs))              # the reference's solve count
+    from oracle import philox
+    U = pod.U_MV.to_dense()
+    Bobs, prob = obs.B.A, obs.problem
+
+    def q_of(mvec):
+        return Bobs @ spla.spsolve(prob._operator(mvec), prob.f)
+
+    expect = []
+    ms = [prior.mean.get_local() + prior._Alu.solve(np.sqrt(prior.Ml) * philox.randn_block(n, 1, 77 | (1 << 32), i)[:, 0]) for i in range(ns)]
+    for s_in, r_out in pairs:
+        rel_errs = []
+        for mi in ms:
+            q = q_of(mi)
+            qr = q_of(Vd[:, :s_in] @ (Vd[:, :s_in].T @ (Rm @ mi)))
+            rel_errs.append(np.linalg.norm(q - U[:, :r_out] @ (U[:, :r_out].T @ qr)) / np.linalg.norm(q))
+        expect.append((np.mean(rel_errs), np.std(rel_errs)))
+    np.testing.assert_allclose(avg, [e[0] for e in expect], rtol=1e-9)
+    np.testing.assert_allclose(std, [e[1] for e in expect], rtol=1e-7)
 
 
 def test_observable_jacobian_is_the_reference_chain(ctx, g):
