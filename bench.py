@@ -664,8 +664,15 @@ def main():
                          "eigenvalue_range": [float(d[0]), float(d[-1])],
                          "relative_gap_below_leading_%d" % lead: float((d_ref[lead - 1] - d_ref[lead]) / d_ref[lead - 1]),
                          "oracle_seconds": time.perf_counter() - t0,
+                         "oracle_form": "double_pass_blas3",
                          "note": "oracle = CPU restatement of the reference path (oracle/) on the same Omega and the same operator data, "
-                                 "streamed from HBM to the host and applied densely there"}
+                                 "streamed from HBM to the host and applied densely there.  At this size the oracle leg is the BLAS-3 twin "
+                                 "(oracle/hippylib_restated.py double_pass_blas3: block applies, Householder QR with positive diagonal, "
+                                 "eigh) -- the thin QR with positive diagonal is unique, so Q, T, d and span(U) equal those of the "
+                                 "column-by-column MGS restatement (double_pass / double_pass_g) to round-off; the column form itself is what "
+                                 "the -m gpu tests and smoke() compare with at sizes it finishes in seconds.  Parity against hippylib "
+                                 "itself is unpinned (hippylib is absent from the reference tree); LAPACK fixtures "
+                                 "(tests/golden/independent_eig.npz) hold both the oracle and the device path to 1e-9"}
     if not args.no_cpu_baseline:
         # rank 0 alone (the other ranks have left the communicator): at N > 1 `wl` is rank 0's shard, the bounded sample is
         # drawn from it and scaled to the whole job exactly as at N = 1

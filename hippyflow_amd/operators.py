@@ -858,8 +858,9 @@ class SeriallySampledJacobianOperator:
 
 class _JacobianStager:
     """Device accumulation of w J^T J X (or w J J^T X) for a HOST Jacobian.  Materialising route: the q rows of J go
-    through one of two pinned buffers to a (q x N) block in HBM on the ingest stream, and the two contractions run on
-    the device while the host works on the next sample.  Column route (q > 2 k): the probe block is downloaded once
+    through one of two pinned buffers to a (q x N) block in HBM on the ingest stream, and the two contractions are enqueued
+    on the solve's stream as a one-sample ``hfmi_op_jtj`` / ``hfmi_op_jjt`` accumulating into Y -- nothing waits for them:
+    the host is already solving for the next sample's rows.  Column route (q > 2 k): the probe block is downloaded once
     and each column goes through ``mult`` / ``transpmult`` on host vectors."""
 
     def __init__(self, J, ctx, materialize, k):
@@ -872,6 +873,7 @@ class _JacobianStager:
             self._pinned = [L.pinned_empty((q, n)) for _ in range(2)]
             self._blocks = [MultiVector(n, q, ctx=ctx) for _ in range(2)]
             self._tickets = [None, None]
+            self._ops = [None, None]          # the operator reading block b: alive until its kernels have run
         else:
             self._x_host = None
 
@@ -881,15 +883,17 @@ class _JacobianStager:
         b = self._i % 2
         self._i += 1
         if self._tickets[b] is not None:
-            self.ctx.ingest_wait(self._tickets[b])
-            self.ctx.synchronize()            # the contraction that read this block two samples ago has finished
-        self.J.rows(self._pinned[b])
+            self.ctx.ingest_wait(self._tickets[b])   # the pinned buffer has been read
+            self.ctx.synchronize()                   # and the contraction that used this block two samples ago has run
+        self.J.rows(self._pinned[b])                 # q adjoint solves on the host
         self._tickets[b] = self._blocks[b].upload_async(self._pinned[b])
         self.ctx.ingest_fence()
-        rows = DenseJacobianOperator(self._blocks[b])
-        tmp = MultiVector(Y)
-        normal(rows).matMvMult(X, tmp)
-        Y.axpy(weight, tmp)
+        if normal is JTJ:
+            op = MeanJTJfromDataOperator.from_block(self._blocks[b], 1, self.q, scale=weight)
+        else:
+            op = MeanJJTfromDataOperator((self._blocks[b], 1, self.q), scale=weight)
+        op.matMvMult(X, Y, accumulate=True)
+        self._ops[b] = op
 
     def _columns(self, normal, X, Y, weight):
         op = normal(self.J)
@@ -912,6 +916,7 @@ class _JacobianStager:
                 if t is not None:
                     self.ctx.ingest_wait(t)
             self.ctx.synchronize()
+            self._ops = [None, None]
 
 
 class PriorPreconditionedProjector:
