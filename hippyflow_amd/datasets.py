@@ -137,3 +137,85 @@ def derivative_dataset(file_path, J, m_data=None, q_data=None, output_decoder=No
         out["U_data"], out["sigma_data"], out["V_data"] = jacobian_svds(blk, svd_rank, seed=seed)
         save_Jsvd_data(file_path, out["U_data"], out["sigma_data"], out["V_data"])
     return out
+
+
+# ------------------------------------------------------------------ (m, q) training pairs from the host PDE loop
+def generate_training_data(observable, prior, n_data, output_directory, noise=None, control_distribution=None, rank=0,
+                           check_for_data=True, sequential=True, compress_files=True, max_solver_retries=100, u_init=None):
+    """PODProjector.generate_training_data (modeling/PODProjector.py:118-297): ``n_data`` (parameter, observable) pairs of this
+    rank, drawn and solved by the reference's loop (noise -> ``prior.sample`` -> ``observable.solveFwd`` -> ``evalu``; a failing
+    solve is answered with a fresh draw), written in the reference's two on-disk forms and RESUMED from what is already there:
+
+    * ``sequential``: one ``m_sample_<i>.npy`` / ``q_sample_<i>.npy`` (+ ``z_sample_<i>.npy``) per pair under
+      ``data_on_rank_<rank>/``, then (``compress_files``) ``mq_on_rank<rank>.npz`` / ``mqz_on_rank<rank>.npz`` with keys
+      ``m_data``, ``q_data`` (, ``z_data``);
+    * otherwise growing arrays ``ms_on_rank_<rank>.npy`` / ``qs_on_rank_<rank>.npy`` (/ ``zs_...``), rewritten after every pair.
+
+    Nothing here touches the GPU: it is the producer side of the file formats the training scripts read.  Returns the
+    number of pairs generated in this call."""
+    from . import hostvec as H
+    os.makedirs(output_directory, exist_ok=True)
+    if noise is None:
+        noise = H.new_host_vector(observable.mpi_comm() if hasattr(observable, "mpi_comm") else None)
+        prior.init_vector(noise, "noise")
+    u, m = observable.generate_vector(H.STATE), observable.generate_vector(H.PARAMETER)
+    z = None if control_distribution is None else observable.generate_vector(H.CONTROL)
+    names = ("m", "q") if z is None else ("m", "q", "z")
+
+    def one_pair():
+        last = None
+        for _ in range(max_solver_retries + 1):
+            m.zero()
+            noise.zero()
+            parRandom.normal(1, noise)
+            prior.sample(noise, m)
+            point = [u, m, None]
+            if z is not None:
+                z.zero()
+                control_distribution.sample(z)
+                point.append(z)
+            if u_init is not None:               # the non-sequential form restarts every solve from the state at the mean (:268-269)
+                u.zero()
+                u.axpy(1.0, u_init)
+            try:
+                observable.solveFwd(u, point)
+            except Exception as exc:             # noqa: BLE001 -- "Issue with the forward solution, moving on." (:218)
+                last = exc
+                continue
+            pair = {"m": m.get_local(), "q": observable.evalu(u).get_local()}
+            if z is not None:
+                pair["z"] = z.get_local()
+            return pair
+        raise RuntimeError("forward solve failed for %d consecutive draws (last error: %r)" % (max_solver_retries + 1, last)) from last
+
+    made = 0
+    if sequential:
+        folder = os.path.join(output_directory, "data_on_rank_%d" % rank) + "/"
+        os.makedirs(folder, exist_ok=True)
+        done = 0
+        if check_for_data:                       # resume after the last index every kind of file has reached (:143-181)
+            have = {n: [int(f[len(n) + 8:-4]) for f in os.listdir(folder) if f.startswith(n + "_sample_") and f.endswith(".npy")] for n in names}
+            if all(have[n] for n in names):
+                done = min(max(v) for v in have.values())
+        for i in range(done, n_data):
+            pair = one_pair()
+            for n in names:
+                np.save(folder + "%s_sample_%d.npy" % (n, i), pair[n])
+            made += 1
+        if compress_files:
+            stacked = {n + "_data": np.stack([np.load(folder + "%s_sample_%d.npy" % (n, i)) for i in range(n_data)]) for n in names}
+            np.savez_compressed(os.path.join(output_directory, ("mq_on_rank%d.npz" if z is None else "mqz_on_rank%d.npz") % rank), **stacked)
+        return made
+    paths = {n: os.path.join(output_directory, "%ss_on_rank_%d.npy" % (n, rank)) for n in names}
+    rows = {n: [] for n in names}
+    if check_for_data and all(os.path.isfile(p) for p in paths.values()):
+        loaded = {n: np.load(paths[n]) for n in names}
+        keep = min(a.shape[0] for a in loaded.values())
+        rows = {n: list(loaded[n][:keep]) for n in names}
+    for _ in range(len(rows["m"]), n_data):
+        pair = one_pair()
+        for n in names:
+            rows[n].append(pair[n])
+            np.save(paths[n], np.array(rows[n]))
+        made += 1
+    return made

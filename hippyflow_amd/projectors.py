@@ -447,7 +447,25 @@ class ActiveSubspaceProjector:
         Returns (U_data, sigma_data, V_data)."""
         from .datasets import jacobian_svds
         n = self.parameters['jacobian_data_per_process']
-        data = self.observable.jacobian_data(n)
+        mq_pairs = None
+        if not hasattr(self.observable, 'jacobian_data') and _speaks_reference_protocol(self.observable):
+            # the reference's loop (:726-800): per sample draw, solve, linearise, keep (m, q), then the Jacobian -- here its q
+            # rows, streamed to HBM, instead of hp.accuracyEnhancedSVD applied to the matrix-free Jacobian on the host
+            sampler = SeriallySampledJacobianOperator(self.observable, self.noise, self.prior, operation='JTJ', nsamples=n,
+                                                      control_distribution=self.control_distribution, jacobian_factory=ObservableJacobian)
+            Jhost = ObservableJacobian(self.observable)
+            q, dM = Jhost.shape
+            ms, qs = [], []
+
+            def rows():
+                for _ in sampler._points():
+                    ms.append(sampler.m.get_local())
+                    qs.append(self.observable.evalu(sampler.u).get_local())
+                    yield Jhost.rows()
+            data = (ingest_stream(rows(), n, q, dM, ctx=self.ctx), n, q)
+            mq_pairs = (np.stack(ms), np.stack(qs))
+        else:
+            data = self.observable.jacobian_data(n)
         if isinstance(data, tuple):
             block, ndata, q = data
         else:
@@ -462,9 +480,10 @@ class ActiveSubspaceProjector:
             proc_id = int(self.collective.rank())
             np.savez_compressed(out + 'J_on_proc' + str(proc_id) + '.npz', U_data=U_data, sigma_data=sigma_data,
                                 V_data=V_data)                                                   # :877-878
-            if hasattr(self.observable, 'mq_data'):
-                m_data, q_data = self.observable.mq_data(ndata)
-                np.savez_compressed(out + 'mq_on_proc' + str(proc_id) + '.npz', m_data=m_data, q_data=q_data)   # :860
+            if mq_pairs is None and hasattr(self.observable, 'mq_data'):
+                mq_pairs = self.observable.mq_data(ndata)
+            if mq_pairs is not None:
+                np.savez_compressed(out + 'mq_on_proc' + str(proc_id) + '.npz', m_data=mq_pairs[0], q_data=mq_pairs[1])   # :860
         return U_data, sigma_data, V_data
 
     def test_errors(self, test_input=True, test_output=False, ranks=[None], cut_off=1e-12, samples=None,
@@ -729,6 +748,19 @@ class PODProjector:
         _, avg, std = projection_error_test(self.U_MV, samples, ranks, d=self.d, cut_off=cut_off, collective=self.collective)
         return avg, std
 
+
+    def generate_training_data(self, check_for_data=True, sequential=True, compress_files=True):
+        """``data_per_process`` (m, q) pairs of this rank in the reference's on-disk forms, resumable
+        (PODProjector.py:118-297; ``datasets.generate_training_data``)."""
+        from .datasets import generate_training_data
+        self.solve_at_mean()
+        t0 = time.time()
+        made = generate_training_data(self.observable, self.prior, self.parameters['data_per_process'], self.parameters['output_directory'],
+                                      noise=self.noise, control_distribution=self.control_distribution, rank=int(self.collective.rank()),
+                                      check_for_data=check_for_data, sequential=sequential, compress_files=compress_files,
+                                      u_init=None if sequential else self.u_at_mean)
+        self._data_generation_time = time.time() - t0
+        return made
 
     def input_output_error_test(self, V_MV, Cinv=None, rank_pairs=[None]):
         """Input-output projection error test (PODProjector.py:541-655): the output basis is this projector's POD basis,

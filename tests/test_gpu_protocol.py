@@ -294,3 +294,48 @@ def test_private_and_shared_random_streams(ctx):
     for a, b in ((draws[0][1], draws[1][1]), (draws[0][1], draws[0][0][:, 0]), (draws[1][1], draws[0][0][:, 0]),
                  (draws[0][1], draws[0][2]), (draws[0][2], draws[1][2])):
         assert abs(np.corrcoef(a, b)[0, 1]) < 0.08
+
+
+def test_training_data_and_low_rank_jacobians_from_a_reference_observable(ctx, g, tmp_path):
+    """The producers of the training files, driven by the reference's protocol only: (m, q) pairs in both on-disk forms with
+    resume (PODProjector.py:118-297) and the per-sample Jacobian SVDs + their (m, q) pairs (activeSubspaceProjector.py:690-900)."""
+    import scipy.sparse.linalg as spla
+    n, q = int(g["n"]), int(g["q"])
+    out = str(tmp_path) + "/"
+    obs, prior = setup(g)
+    params = hf.PODParameterList()
+    params['data_per_process'], params['output_directory'], params['verbose'] = 3, out, False
+    pod = hf.PODProjector(obs, prior, parameters=params)
+    assert pod.generate_training_data() == 3
+    first = [np.load(out + "data_on_rank_0/m_sample_%d.npy" % i) for i in range(3)]
+    params['data_per_process'] = 5
+    assert pod.generate_training_data() == 3          # resumes AT the last index found (it may have been half written), as upstream
+    f = np.load(out + "mq_on_rank0.npz")
+    assert sorted(f.files) == ["m_data", "q_data"] and f["m_data"].shape == (5, n) and f["q_data"].shape == (5, q)
+    np.testing.assert_array_equal(f["m_data"][:2], np.stack(first[:2]))
+    for mi, qi in zip(f["m_data"], f["q_data"]):
+        np.testing.assert_allclose(qi, obs.B.A @ spla.spsolve(obs.problem._operator(mi), obs.problem.f), rtol=1e-12)
+    assert pod.generate_training_data(sequential=False) == 5
+    ms = np.load(out + "ms_on_rank_0.npy")
+    assert ms.shape == (5, n) and np.load(out + "qs_on_rank_0.npy").shape == (5, q)
+    assert pod.generate_training_data(sequential=False) == 0                    # nothing left to do
+
+    obs, prior = setup(g)
+    asp = hf.ActiveSubspaceParameterList()
+    asp['jacobian_data_per_process'], asp['output_directory'], asp['verbose'] = 4, out, False
+    AS = hf.ActiveSubspaceProjector(obs, prior, parameters=asp)
+    U, sig, V = AS.construct_low_rank_Jacobians()
+    assert U.shape == (4, q, q) and sig.shape == (4, q) and V.shape == (4, n, q) and obs.n_fwd_solve == 4
+    mq = np.load(out + "mq_on_proc0.npz")
+    jf = np.load(out + "J_on_proc0.npz")
+    assert sorted(jf.files) == ["U_data", "V_data", "sigma_data"]
+    u = obs.generate_vector(hf.STATE)
+    m = obs.generate_vector(hf.PARAMETER)
+    for i in range(4):
+        m.set_local(mq["m_data"][i])
+        obs.solveFwd(u, [u, m, None])
+        obs.setLinearizationPoint([u, m, None])
+        Jd = obs.problem.jacobian_dense(obs.B.A)
+        np.testing.assert_allclose(np.sort(sig[i])[::-1], np.linalg.svd(Jd, compute_uv=False), rtol=1e-9)
+        assert rel((U[i] * sig[i]) @ V[i].T, Jd) < 1e-9
+        np.testing.assert_allclose(mq["q_data"][i], obs.B.A @ u.get_local(), rtol=1e-12)
