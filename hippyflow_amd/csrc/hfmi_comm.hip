@@ -373,12 +373,12 @@ __global__ void k_p2p_wait(const comm_flag* flags, int nranks, unsigned long lon
   unsigned long long v;
   while ((v = __hip_atomic_load(&flags[p].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < seq) {
     if (wall_clock64() - t0 > ticks || *(volatile int*)dev_err) {
-      atomicExch_system(dev_err, 1);
+      __hip_atomic_store(dev_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a plain store: the word lives in host memory, no PCIe atomic needed
       return;
     }
     __builtin_amdgcn_s_sleep(8);
   }
-  if (v == P2P_POISON) atomicExch_system(dev_err, 1);
+  if (v == P2P_POISON) __hip_atomic_store(dev_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a plain store: the word lives in host memory, no PCIe atomic needed
 }
 
 static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, hipStream_t stream) {

@@ -318,11 +318,15 @@ __global__ __launch_bounds__(256) void k_ell_spmm(const int32_t* __restrict__ ei
 constexpr int SPMM_JB = 8;
 __global__ void k_csr_spmm(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                            const double* __restrict__ data, int64_t nrows, const double* __restrict__ X, int64_t ldx,
-                           double* __restrict__ Y, int64_t ldy, int nvec, int accumulate) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                           double* __restrict__ Y, int64_t ldy, int nvec, int accumulate, int gx8, int gy) {
+  // XCD-aware row bands, as in k_ell_spmm: 1-D grid of gx8 * gy workgroups, XCD x (= blockIdx.x % 8) owns the x-th band of rows
+  const int per = gx8 >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rb = xcd * per + slot % per, yg = slot / per;
+  const int64_t row = (int64_t)rb * blockDim.x + threadIdx.x;
   if (row >= nrows) return;
   const int64_t b = indptr[row], e = indptr[row + 1];
-  for (int j0 = blockIdx.y * SPMM_JB; j0 < nvec; j0 += gridDim.y * SPMM_JB) {
+  for (int j0 = yg * SPMM_JB; j0 < nvec; j0 += gy * SPMM_JB) {
     double acc[SPMM_JB];
 #pragma unroll
     for (int jj = 0; jj < SPMM_JB; ++jj) acc[jj] = 0.0;
@@ -350,9 +354,9 @@ int launch_csr_spmm(hfmi_ctx* ctx, const hfmi_csr* M, const double* X, int64_t l
     HIP_TRY(hipGetLastError());
     return HFMI_OK;
   }
-  int gy = (nvec + SPMM_JB - 1) / SPMM_JB;
-  dim3 grid((unsigned)((M->nrows + 255) / 256), (unsigned)gy);
-  hipLaunchKernelGGL(k_csr_spmm, grid, dim3(256), 0, ctx->stream, M->indptr, M->indices, M->data, M->nrows, X, ldx, Y, ldy, nvec, accumulate ? 1 : 0);
+  const int gy = (nvec + SPMM_JB - 1) / SPMM_JB;
+  const int gx8 = (int)(((M->nrows + 255) / 256 + 7) / 8 * 8);
+  hipLaunchKernelGGL(k_csr_spmm, dim3((unsigned)(gx8 * gy)), dim3(256), 0, ctx->stream, M->indptr, M->indices, M->data, M->nrows, X, ldx, Y, ldy, nvec, accumulate ? 1 : 0, gx8, gy);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }
