@@ -185,6 +185,8 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   if (!ctx) return HFMI_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (hfmi_comm* c : ctx->watched_comms) comm_forget_ctx(c);    // a communicator destroyed after its context must not look for it
+  ctx->watched_comms.clear();
   for (hfmi_block* b : ctx->tmp_blocks)
     if (b) {
       if (b->owner && b->p) (void)hipFree(b->p);

@@ -436,6 +436,9 @@ int comm_check_error(hfmi_comm* c) {
   return HFMI_OK;
 }
 static int p2p_check_err(hfmi_comm* c) { return comm_check_error(c); }
+void comm_forget_ctx(hfmi_comm* c) {
+  if (c) c->ctx = nullptr;
+}
 
 static int p2p_bcast_dev(hfmi_comm* c, void* data, size_t bytes, int root) {
   hfmi_ctx* ctx = c->ctx;

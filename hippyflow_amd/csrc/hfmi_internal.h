@@ -177,6 +177,7 @@ int comm_check_error(hfmi_comm* c);
 // make the p2p staging buffer large enough for a collective of `bytes` NOW (a collective: every rank calls it with the same
 // size), so that it never regrows while row panels of an application are in flight on the auxiliary stream
 int comm_reserve_stage(hfmi_comm* c, size_t bytes);
+void comm_forget_ctx(hfmi_comm* c);        // the context is going away first: stop referring to it
 void ctx_watch_comm(hfmi_ctx* ctx, hfmi_comm* c);
 void ctx_unwatch_comm(hfmi_ctx* ctx, hfmi_comm* c);
 int ctx_check_comm(hfmi_ctx* ctx);        // comm_check_error over the watched communicators
