@@ -57,6 +57,9 @@ def _worker(rank, world, port, outdir):
         res["bad_type"] = False
     except NotImplementedError:
         res["bad_type"] = True
+    # a collective keys the process-wide generator's PRIVATE streams by its rank; SHARED streams (probe blocks) stay common
+    from hippyflow_amd.randomized import parRandom
+    res["random_rank"], res["key_private"], res["key_shared"] = parRandom.rank, parRandom.key(False), parRandom.key(True)
 
     # averaging identity with the workload's own sample keying (global sample index -> factor)
     ns_total, q, c, N, k, r = 8, 6, 6, 90, 7, 4
@@ -115,6 +118,7 @@ def test_two_rank_collective_and_averaging_identity(tmp_path):
         assert bool(r["arr_inplace"]) and bool(r["bad_op"]) and bool(r["bad_type"])
         np.testing.assert_array_equal(r["bcast"], np.full(4, 1.0))
         assert float(r["bcast_scalar"]) == 0.5
+        assert int(r["random_rank"]) == rank and int(r["key_private"]) >> 32 == rank + 1 and int(r["key_shared"]) >> 32 == 0
     # both ranks hold the same result, and it equals the single-rank solve over all samples
     np.testing.assert_array_equal(r0["d_par"], r1["d_par"])
     np.testing.assert_allclose(r0["d_par"], r0["d_ser"], rtol=1e-12)
