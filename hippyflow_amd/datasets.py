@@ -23,7 +23,6 @@ import os
 
 import numpy as np
 
-from . import _lib as L
 from .multivector import MultiVector, MvDSmatMult
 from .operators import DenseJacobianOperator
 from .randomized import accuracyEnhancedSVD, parRandom

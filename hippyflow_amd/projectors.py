@@ -28,10 +28,10 @@ import numpy as np
 from . import _lib as L
 from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
 from . import hostvec as H
-from .multivector import ingest_stream, MatMvMult, MultiVector, Vector
+from .multivector import ingest_stream, MatMvMult, MultiVector
 from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableJacobian, SeriallySampledJacobianOperator,
-                        SnapshotGramOperator, Solver2Operator, as_device_operator, csr_from_matrix)
+                        SnapshotGramOperator, Solver2Operator, as_device_operator)
 from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
 from .utilities import mv_to_dense
 

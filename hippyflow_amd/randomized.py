@@ -24,7 +24,7 @@ from . import _lib as L
 from . import hostvec as H
 from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NativeCollective, NullCollective
 from .multivector import MatMvMult, MultiVector, MvDSmatMult, Vector
-from .operators import DeviceOperator, Solver2Operator, as_device_operator
+from .operators import DeviceOperator, as_device_operator
 
 
 class _ParRandom:

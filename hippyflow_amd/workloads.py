@@ -15,7 +15,6 @@ The latent factors are kept so that tests and bench.py can evaluate the SAME ope
 factored form (a few N x c products) -- that is what makes an oracle check affordable at full size.
 """
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -354,7 +353,6 @@ class BiLaplacianPrior:
 def matern32_covariance(C, nx, ny, sigma=1.0, ell=0.1):
     """Fill the N x N block C (N = C.size() <= nx*ny grid nodes, row-major node numbering on the unit square) with the
     Matern-3/2 kernel sigma^2 (1 + sqrt(3) d / ell) exp(-sqrt(3) d / ell) of SURVEY section 8d's config 2, on the device."""
-    import ctypes as C_
     L.call("hfmi_block_fill_matern32", C.handle, int(nx), int(ny), float(sigma), float(ell))
     return C
 
