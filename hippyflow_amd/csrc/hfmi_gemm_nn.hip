@@ -9,6 +9,8 @@ static int g_nn_hybrid = 1;   // split only the row tiles beyond the last full r
 static int g_nn_tt = 0;       // A/B: force the nn wave-tile height (1 = tallest, 2, 3 = next smaller)
 static int g_rem4 = 1;        // last column tile of <= 12 columns in 4-column groups (4x4x4 MFMA)
 static int g_nn_res = 1;      // small matrix resident in LDS + persistent workgroups when it fits
+static int g_nn_halve_last = 0;   // overlapped rank reduction: last round of a 2-3 round product as two launches of half-height tiles
+                                  // (off: on one GPU the shorter tiles cost more than the smaller exposed panel saves, profiles/r04i_halve_last_ab.txt)
 static int g_nn_res_tt = 0;   // 0: tile height of nn_res by the round count (below); 1: always the table's; 2: always one less (A/B)
 int nn_tuning_set(const char* key, int value) {
   if (!strcmp(key, "rem4") && (value == 0 || value == 1)) g_rem4 = value;
@@ -16,6 +18,7 @@ int nn_tuning_set(const char* key, int value) {
   else if (!strcmp(key, "nn_tt") && value >= 0 && value <= 3) g_nn_tt = value;
   else if (!strcmp(key, "nn_hybrid") && (value == 0 || value == 1)) g_nn_hybrid = value;
   else if (!strcmp(key, "nn_res") && (value == 0 || value == 1)) g_nn_res = value;
+  else if (!strcmp(key, "nn_halve_last") && (value == 0 || value == 1)) g_nn_halve_last = value;
   else if (!strcmp(key, "nn_res_tt") && value >= 0 && value <= 2) g_nn_res_tt = value;
   else return 0;
   return 1;
@@ -576,17 +579,51 @@ static int nn_launch_inst(hfmi_ctx* ctx, const double* A, int64_t lda, int m, co
   };
   // Row panels for an overlapped rank reduction (ctx->nn_hook, set by hfmi_op_apply): whole rounds of tiles per launch, the
   // hook is told which rows are final after each.  Tiles keep the plan of the single launch, so the results are the same bits.
+  // A round's tiles finish together, so with R rounds the last panel is 1/R of the block and its reduction is exposed.  When
+  // every round already is its own panel and one more panel is allowed, the LAST round is issued as two launches of tiles of
+  // HALF the height (same reduction order per row: still the same bits): its first half is final -- and on its way through the
+  // fabric -- while the second half is computed, and only a quarter of a two-round product is left exposed.
   if (ctx->nn_hook) {
     const int whole_cnt = msplit > 1 ? full_tiles : ntiles;          // tiles computed in one piece
     const int rounds = whole_cnt / cus;
     if (rounds >= 2) {
       int panels = rounds < ctx->nn_hook_panels ? rounds : ctx->nn_hook_panels;
       if (panels < 1) panels = 1;
+      constexpr int TH = TT / 2;
+      static const int env_halve = getenv("HFMI_NN_HALVE_LAST") ? atoi(getenv("HFMI_NN_HALVE_LAST")) : -1;   // A/B switch: 1 on, 0 off
+      const bool halve = (env_halve >= 0 ? env_halve != 0 : g_nn_halve_last != 0) && (TT % 2 == 0) && TH >= 1 && panels == rounds && panels + 1 <= ctx->nn_hook_panels && panels + 1 <= 8;
       int base = 0;
       for (int p = 0; p < panels; ++p) {
         const bool last = p == panels - 1;
         const int cnt = last ? whole_cnt - base : (rounds / panels + (p < rounds % panels ? 1 : 0)) * cus;
         const int tl = (last && msplit > 1) ? tail_tiles : 0;
+        if (last && halve) {
+          if constexpr (TT % 2 == 0 && TT >= 2) {
+            auto kern_h = r4 == 1 ? k_tsgemm_nn<TH, NT, WAVES, 1> : r4 == 2 ? k_tsgemm_nn<TH, NT, WAVES, 2>
+                        : r4 == 3 ? k_tsgemm_nn<TH, NT, WAVES, 3> : k_tsgemm_nn<TH, NT, WAVES, 0>;
+            HIP_TRY(hipFuncSetAttribute((const void*)kern_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            const int cnt_a = cnt / 2, cnt_b = cnt - cnt_a;          // in tiles of the full height
+            // first half of the round: 2 cnt_a half-height tiles starting at half-tile 2 base
+            hipLaunchKernelGGL(kern_h, dim3((unsigned)(2 * cnt_a)), block, shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, 1, 1, mchunk,
+                               (int64_t)0, 2 * cnt_a, Y, ldy, 2 * base, 0);
+            HIP_TRY(hipGetLastError());
+            HFMI_TRY(ctx->nn_hook(ctx->nn_hook_user, Y, ldy, r, (int64_t)base * tile_rows, (int64_t)cnt_a * tile_rows));
+            // second half (the last half-height tile may be ragged: rows >= N are never stored), then the split tail tiles
+            hipLaunchKernelGGL(kern_h, dim3((unsigned)(2 * cnt_b)), block, shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, 1, 1, mchunk,
+                               (int64_t)0, 2 * cnt_b, Y, ldy, 2 * (base + cnt_a), 0);
+            HIP_TRY(hipGetLastError());
+            if (tl > 0) {
+              hipLaunchKernelGGL(kern, dim3((unsigned)(tl * msplit)), block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N, tl, msplit,
+                                 mchunk, pstride, 0, Y, ldy, base, full_tiles);
+              HIP_TRY(hipGetLastError());
+              HFMI_TRY(reduce_tail());
+            }
+            const int64_t row0 = (int64_t)(base + cnt_a) * tile_rows;
+            HFMI_TRY(ctx->nn_hook(ctx->nn_hook_user, Y, ldy, r, row0, N - row0));
+          }
+          base += cnt;
+          continue;
+        }
         if (msplit > 1)
           hipLaunchKernelGGL(kern, dim3((unsigned)(cnt + tl * msplit)), block, shmem, ctx->stream, A, lda, m, S, lds_, r, out, ldo, N,
                              tl > 0 ? tl : 1, msplit, mchunk, pstride, cnt, Y, ldy, base, full_tiles);

@@ -120,7 +120,17 @@ def test_row_panel_reduction_is_bit_identical_and_overlapped():
         d, U = hf.doublePass(A, Omega, r, s=1)
         ctx.profile_end()
         out[panels] = (d, U.to_dense(), ctx.profile_phases())
+    # the opt-in half-height last round (one more, smaller, panel; profiles/r04i_halve_last_ab.txt): still the same bits
     L.call("hfmi_tuning_set", b"comm_panels", 4)
+    L.call("hfmi_tuning_set", b"nn_halve_last", 1)
+    ctx.profile_begin()
+    d_h, U_h = hf.doublePass(A, Omega, r, s=1)
+    ctx.profile_end()
+    halved_phases = ctx.profile_phases()
+    L.call("hfmi_tuning_set", b"nn_halve_last", 0)
+    np.testing.assert_array_equal(d_h, out[4][0])
+    np.testing.assert_array_equal(U_h.to_dense(), out[4][1])
+    assert 0.0 < halved_phases["allreduce"] < out[4][2]["allreduce"]          # a smaller last panel is left exposed
     np.testing.assert_array_equal(out[0][0], out[4][0])
     np.testing.assert_array_equal(out[0][1], out[4][1])
     assert out[0][2]["allreduce_overlapped"] == 0.0 and out[4][2]["allreduce_overlapped"] > 0.0
