@@ -196,7 +196,9 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
 
   // reflector j from x = A[j][.] (the owner wave's copy of row j): -> s_v, s_tau now; Vh, tau, e[j], d[j] go to global memory
   // after the next barrier (pend_*): a global store costs ~50 issue cycles and five of them sat on the critical path
-  double pend_v[CJ], pend_beta = 0.0, pend_tau = 0.0, pend_d = 0.0;
+  // (the reflector itself is not held: it is flushed in iteration pend_j, where it is the current v the wave has loaded anyway)
+  // and its scalars wait in LDS: registers are what this kernel is short of)
+  __shared__ double s_pend[3];
   int pend_j = -1;
   auto form_reflector = [&](int j, const double (&x)[CJ]) {
     double xn2 = 0.0, alpha_l = 0.0, d_l = 0.0;
@@ -223,26 +225,28 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
       const int c = l + 64 * jj;
       const double v = (c == j + 1) ? 1.0 : ((c > j + 1 && c < n) ? x[jj] * scl : 0.0);
       s_v2[PRE ? 0 : (j & 1)][c] = v;
-      pend_v[jj] = v;
     }
-    if (l == 0) s_tau = tau;
-    pend_beta = beta;
-    pend_tau = tau;
-    pend_d = lane_get(d_l, j & 63);
+    const double dj = lane_get(d_l, j & 63);
+    if (l == 0) {
+      s_tau = tau;
+      s_pend[0] = dj;
+      s_pend[1] = beta;
+      s_pend[2] = tau;
+    }
     pend_j = j;
   };
-  auto flush_pending = [&]() {
+  auto flush_pending = [&](const double (&vcur)[CJ]) {      // vcur = v_{pend_j}: reflector j is flushed in iteration j
     if (pend_j >= 0) {
       asm volatile("");
 #pragma unroll
       for (int jj = 0; jj < CJ; ++jj) {
         const int c = l + 64 * jj;
-        if (c < ldv) Vh[(size_t)pend_j * ldv + c] = pend_v[jj];
+        if (c < ldv) Vh[(size_t)pend_j * ldv + c] = vcur[jj];
       }
-      if (l == 0) {
-        dvec[pend_j] = pend_d;
-        evec[pend_j] = pend_beta;
-        tauv[pend_j] = pend_tau;
+      if (l == 0) {      // (this wave wrote s_pend itself, and nobody rewrites it before the next reflector is formed)
+        dvec[pend_j] = s_pend[0];
+        evec[pend_j] = s_pend[1];
+        tauv[pend_j] = s_pend[2];
       }
       pend_j = -1;
     }
@@ -297,8 +301,10 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
 #pragma unroll
         for (int i = 0; i < RI; ++i) vr[i] = s_v[w + NW * i];
       }
-      flush_pending();
+      flush_pending(vc);
       {
+        // two accumulators per column group while the groups alone are too few independent chains for the FMA latency
+        constexpr int NA = 2;
         double acc[CJ][2];
 #pragma unroll
         for (int jj = 0; jj < CJ; ++jj) acc[jj][0] = acc[jj][1] = 0.0;
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
             for (int u = 0; u < 4; ++u) {
               const int i = 4 * ch + u;
 #pragma unroll
-              for (int jj = 0; jj < CJ; ++jj) acc[jj][u & 1] = fma(A[i][jj], v4[u], acc[jj][u & 1]);
+              for (int jj = 0; jj < CJ; ++jj) acc[jj][u & (NA - 1)] = fma(A[i][jj], v4[u], acc[jj][u & (NA - 1)]);
             }
           }
         }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
             asm volatile("");
             const double vri = s_v[r];
 #pragma unroll
-            for (int jj = 0; jj < CJ; ++jj) acc[jj][i2 & 1] = fma(s_dyn[(r - RREG) * LSTR + l + 64 * jj], vri, acc[jj][i2 & 1]);
+            for (int jj = 0; jj < CJ; ++jj) acc[jj][i2 & (NA - 1)] = fma(s_dyn[(r - RREG) * LSTR + l + 64 * jj], vri, acc[jj][i2 & (NA - 1)]);
           }
         }
 #pragma unroll
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
             for (int ww = 0; ww + st < NW; ww += 2 * st) q[ww] += q[ww + st];
           pc[jj] = (c > j && c < n) ? tau * q[0] : 0.0;
           dl = fma(pc[jj], vc[jj], dl);
+          if constexpr (!PRE) asm volatile("");       // one column group's slices in flight at a time (registers)
         }
         const double kk = 0.5 * tau * wave_sum(dl);
 #pragma unroll
@@ -366,23 +373,38 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
       }
       TRI_TICK(tk1);
       auto update_chunk = [&](int ch) {
-        double v4[4], w4[4];
+        if constexpr (PRE) {
+          double v4[4], w4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = 4 * ch + u;
-          if constexpr (PRE) {
-            v4[u] = vr[i];
-            w4[u] = wr[i];
-          } else {
-            v4[u] = s_v[w + NW * i];
-            w4[u] = lane_get(wc[(NW * i) / 64], (w + NW * i) & 63);
+          for (int u = 0; u < 4; ++u) {
+            v4[u] = vr[4 * ch + u];
+            w4[u] = wr[4 * ch + u];
           }
-        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = 4 * ch + u;
+          for (int u = 0; u < 4; ++u) {
+            const int i = 4 * ch + u;
 #pragma unroll
-          for (int jj = 0; jj < CJ; ++jj) A[i][jj] = fma(-w4[u], vc[jj], fma(-v4[u], wc[jj], A[i][jj]));
+            for (int jj = 0; jj < CJ; ++jj) A[i][jj] = fma(-w4[u], vc[jj], fma(-v4[u], wc[jj], A[i][jj]));
+          }
+        } else {
+          // two rows at a time: the four (v, w) pairs of a chunk held at once are eight registers this shape does not have
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double v2[2], w2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int i = 4 * ch + 2 * h + u;
+              v2[u] = s_v[w + NW * i];
+              w2[u] = lane_get(wc[(NW * i) / 64], (w + NW * i) & 63);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int i = 4 * ch + 2 * h + u;
+#pragma unroll
+              for (int jj = 0; jj < CJ; ++jj) A[i][jj] = fma(-w2[u], vc[jj], fma(-v2[u], wc[jj], A[i][jj]));
+            }
+            asm volatile("");
+          }
         }
       };
       auto update_lds_row = [&](int i2) {
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
         }
       }
     } else {
-      flush_pending();
+      flush_pending(vc);
       if (next_mine) {
         double x[CJ];
         pick_row(chn, j + 1, x);
@@ -442,7 +464,6 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
     __syncthreads();
     TRI_TICK(tk3);
   }
-  flush_pending();
   TRI_TICK_STORE;
   // the last two rows hold d[n-2], e[n-2], d[n-1]
 #pragma unroll
