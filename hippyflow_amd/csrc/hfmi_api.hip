@@ -568,7 +568,7 @@ static int read_status(hfmi_ctx* ctx, hfmi_status_words* out) {
   return HFMI_OK;
 }
 static void print_status_dbg(const hfmi_status_words* out) {
-  static const bool dbg = getenv("HFMI_DEBUG_TIMING") != nullptr;
+  static const bool dbg = env_flag("HFMI_DEBUG_TIMING");
   if (dbg)
     fprintf(stderr, "[hfmi timing] %s cycles: %lld %lld %lld %lld\n",
             out->tick[4] == 3 ? "chol-polish(load,-,-,out)" : out->tick[4] ? "jacobi(total,phase1,phase2,sweeps)" : "chol(load,chol,inv,out)",
@@ -989,7 +989,7 @@ static int cheb_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, bool* han
   const int64_t N = W->N;
   const int k = W->nvec;
   *handled = false;
-  static const bool off = getenv("HFMI_PCG") != nullptr;          // A/B switch: always the block CG
+  static const bool off = env_flag("HFMI_PCG");          // A/B switch: always the block CG
   if (off || M->cheb_state < 0) return HFMI_OK;
   if (M->cheb_state == 0) HFMI_TRY(cheb_estimate(op));
   if (M->cheb_state != 1) return HFMI_OK;

@@ -198,7 +198,7 @@ int launch_cheb_first(hfmi_ctx* ctx, const double* B, double* X1, double* X0, co
 }
 // one step (resid = false) or the residual B - A Xc into Xp (resid = true)
 int launch_cheb_step(hfmi_ctx* ctx, const hfmi_csr* M, const double* B, const double* Xc, double* Xp, int k, double c1, double c2, bool resid) {
-  static const bool thread_map = getenv("HFMI_CHEB_THREADMAP") != nullptr;      // A/B switch
+  static const bool thread_map = env_flag("HFMI_CHEB_THREADMAP");      // A/B switch
   if ((k & 1) == 0 && k <= 128 && !thread_map) {
     // rows per wave: 1 measured best on config 2 (53.5 us a step; 2: 54.4, 4: 63.0, 8: 104 -- profiles/r04c_cheb_unr.txt)
     static const int unr = getenv("HFMI_CHEB_UNR") ? atoi(getenv("HFMI_CHEB_UNR")) : 1;

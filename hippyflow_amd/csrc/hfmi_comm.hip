@@ -277,7 +277,7 @@ static int p2p_close_peers(hfmi_comm* c) {
 // the staging buffer: fine-grained device memory when the runtime grants it AND exports it (peer GPUs' kernel writes are then
 // visible to this GPU without relying on a kernel boundary flushing a remote L2), else ordinary device memory
 static int p2p_alloc_stage(hfmi_comm* c, size_t want) {
-  static const bool coarse = getenv("HFMI_P2P_COARSE") != nullptr;
+  static const bool coarse = env_flag("HFMI_P2P_COARSE");
   c->stage_fine = false;
   if (!coarse) {
     void* q = nullptr;

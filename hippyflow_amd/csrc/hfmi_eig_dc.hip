@@ -1305,7 +1305,7 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
   else BACK(16);
 #undef BACK
   HIP_TRY(hipGetLastError());
-  static const bool timing = getenv("HFMI_DC_TIMING") != nullptr;
+  static const bool timing = env_flag("HFMI_DC_TIMING");
   if (timing) {
     long long h[16];
     HIP_TRY(hipMemcpyAsync(h, ticks, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

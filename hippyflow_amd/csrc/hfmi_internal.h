@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -30,6 +31,11 @@ void hfmi_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// an A/B or diagnostic switch from the environment: on when set to anything but "" or "0"
+static inline bool env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] && !(e[0] == '0' && e[1] == 0);
+}
 
 // ------------------------------------------------------------------ objects
 enum { WS_PART = 0, WS_G, WS_STAGE, WS_MISC, WS_MGS, WS_COMM, WS_INGEST, WS_NSLOTS };

@@ -846,7 +846,7 @@ int launch_chol_inv(hfmi_ctx* ctx, int k, int slot_gram, int slot_r, int slot_ri
   const int use_lds = (k <= 139) ? 1 : 0;   // (32 + 3 * 256) * 8 + 139 * 139 * 8 = 160,968 bytes <= 160 KB (163,840)
   const size_t shmem = (32 + 3 * 256) * sizeof(double) + (use_lds ? (size_t)k * (k | 1) * sizeof(double) : 0);
   if (pivot_tol <= 0.0) pivot_tol = 64.0 * k * EPS_D;
-  static const bool chol_generic = getenv("HFMI_CHOL_GENERIC") != nullptr;   // A/B: the generic one-kernel path
+  static const bool chol_generic = env_flag("HFMI_CHOL_GENERIC");   // A/B: the generic one-kernel path
   if (use_lds && !chol_generic) {
     const int ept = (k * (k + 1) / 2 + CHOL_REG_THREADS - 1) / CHOL_REG_THREADS;   // <= 19 for k <= 139
     const size_t shm = (32 + 4 * 256) * sizeof(double) + (size_t)k * (k | 1) * sizeof(double);
@@ -1693,7 +1693,7 @@ int launch_jacobi_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dval
 #undef JAC_LAUNCH
 #undef JAC_LAUNCH2
   HIP_TRY(hipGetLastError());
-  static const bool replay_lds = getenv("HFMI_JACOBI_REPLAY_LDS") != nullptr;   // A/B: the LDS + barrier replay
+  static const bool replay_lds = env_flag("HFMI_JACOBI_REPLAY_LDS");   // A/B: the LDS + barrier replay
   if (n <= 128 && !replay_lds)
     hipLaunchKernelGGL(k_jacobi_vectors_wave, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, rotlog, k, ctx->status_dev, perm,
                        sm_ptr(ctx, slot_v), SM_LD);

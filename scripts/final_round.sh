@@ -1,17 +1,23 @@
 #!/bin/bash
-# Everything a round's evidence consists of, on ONE box and ONE build:  bash scripts/final_round.sh r04f
+# Everything a round's evidence consists of, on ONE box and ONE build:  bash scripts/final_round.sh r04j
 #   1. the -m gpu test suite                      -> <tag>_gputests.log
-#   2. un-profiled bench lines (configs 4 / 3 / 2, the 64-sample shard with and without a one-rank RCCL communicator,
-#      2 ranks sharing the GPU)                   -> <tag>_bench_*.json
-#   3. the un-profiled kernel point               -> <tag>_kernel_point.json
-#   4. kernel traces + PMC passes                 -> scripts/profile_round.sh, scripts/pmc_workload.sh
+#   2. kernel traces + PMC passes                 -> scripts/profile_round.sh, scripts/pmc_workload.sh; profiles/pmc_traffic.json of THIS
+#      build is made from them (gpurun_out/<tag>_pmc_traffic.json: copy it over profiles/pmc_traffic.json when the job is back)
+#   3. un-profiled bench lines (configs 4 / 3 / 2 with roofline.traffic from step 2, the 64-sample shard with and without a
+#      one-rank RCCL communicator, 2 ranks sharing the GPU)                   -> <tag>_bench_*.json
+#   4. the un-profiled kernel point               -> <tag>_kernel_point.json
 #   5. kernel timeline of the shard step          -> scripts/shard_profile.sh
+#   6. the eigensolve beyond the BASELINE sizes   -> scripts/eig_corner_trace.sh
 # Summaries land in gpurun_out/; copy what is to be judged into profiles/.
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out; mkdir -p $out
 cd $R
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_gputests.log
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_gputests.log
+bash scripts/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1
+for w in as pod kle; do MIN_MS=0.05 bash scripts/pmc_workload.sh $w $tag > $out/${tag}_pmc_$w.log 2>&1; done
+cd $R
+python profiles/make_pmc_traffic.py $tag $out > $out/${tag}_make_pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 for w in as pod kle; do
   timeout 900 python bench.py --workload $w > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err
 done
@@ -19,9 +25,9 @@ timeout 600 python bench.py --samples-total 64 --no-cpu-baseline > $out/${tag}_b
 timeout 600 python bench.py --samples-total 64 --no-cpu-baseline --dist-single > $out/${tag}_bench_as_shard64_dist1.json 2>/dev/null
 timeout 600 python bench.py --gpus 2 --samples-total 128 --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_as_2ranks_one_gpu.json 2>/dev/null
 timeout 600 python scripts/kernel_point.py > $out/${tag}_kernel_point.log 2>&1 && cp $out/kernel_point.json $out/${tag}_kernel_point.json
-bash scripts/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1
-for w in as pod kle; do MIN_MS=0.05 bash scripts/pmc_workload.sh $w $tag > $out/${tag}_pmc_$w.log 2>&1; done
 bash scripts/shard_profile.sh ${tag}_shard64 > $out/${tag}_shard64_timeline.txt 2>&1
 bash scripts/shard_profile.sh ${tag}_shard64_dist1 --samples-total 64 --dist-single > $out/${tag}_shard64_dist1_timeline.txt 2>&1
+bash scripts/eig_corner_trace.sh $tag 138 160 192 224 256 > $out/${tag}_eig_corner.txt 2>&1
+cd $R
 cat $out/${tag}_gputests.log
 ls $out | grep "^${tag}_" | wc -l
