@@ -8,12 +8,13 @@ raises if libhfmi.so or a GPU is missing.
 from ._lib import Context, HfmiError, build_tag, device_count, load, pinned_empty
 from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, MultipleSamePartitioningPDEsCollective,
                           MultipleSerialPDEsCollective, NativeCollective, NullCollective, TorchCollective,
-                          checkMeshConsistentPartitioning, splitCommunicators)
+                          checkFunctionSpaceConsistentPartitioning, checkMeshConsistentPartitioning, splitCommunicators)
 from .hostvec import ADJOINT, CONTROL, PARAMETER, STATE, HostMultiVector, HostVector, new_host_vector, set_host_vector_factory
 from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector, ingest_stream
 from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobianOperator, DeviceOperator, HostCallbackOperator,
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
-                        JJT, JTJ, MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableJacobian, PriorPreconditionedProjector,
+                        JJT, JTJ, Jacobian, MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableControlJacobian,
+                        ObservableJacobian, PriorPreconditionedProjector,
                         SeriallySampledJacobianOperator, StateSpaceIdentityOperator, npToDolfinOperator,
                         SnapshotGramOperator, Solver2Operator, SummedListOperator, as_device_operator, npToDeviceOperator)
 from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, BoundaryRestrictedKLEProjector,

@@ -463,6 +463,11 @@ def splitCommunicators(comm_world, n_subdomain, n_instances):
     return _SelfCommunicator(), comm_world
 
 
+def checkFunctionSpaceConsistentPartitioning(Vh, collective):
+    """comm_utils.py:43-60: the same question for a function space -- see ``checkMeshConsistentPartitioning``."""
+    return True
+
+
 def checkMeshConsistentPartitioning(mesh, collective):
     """comm_utils.py:63-75 asks whether every sampling instance partitioned its mesh the same way.  Without mesh
     partitioning (see ``splitCommunicators``) there is one partition: consistent by construction."""

@@ -630,29 +630,57 @@ class StateSpaceIdentityOperator:
             getattr(self.M, "transpmult", self.M.mult)(x, p)          # M is symmetric
 
 
-class ObservableJacobian:
+class Jacobian:
+    """The interface a Jacobian offers (jacobian.py:19-60): ``init_vector(x, dim)`` with dim 0 = range and 1 = domain,
+    ``mpi_comm()``, ``mult(x, y)``, ``transpmult(x, y)``.  A user-written Jacobian deriving from this plugs into ``JTJ`` / ``JJT``
+    and the projectors' ``jacobian_factory`` like ``ObservableJacobian`` does."""
+
+    def _missing(self, what):
+        raise NotImplementedError("%s.%s: a Jacobian implements init_vector, mpi_comm, mult and transpmult"
+                                  % (type(self).__name__, what))
+
+    def init_vector(self, x, dim):
+        self._missing("init_vector")
+
+    def mpi_comm(self):
+        self._missing("mpi_comm")
+
+    def mult(self, x, y):
+        self._missing("mult")
+
+    def transpmult(self, x, y):
+        self._missing("transpmult")
+
+
+class ObservableJacobian(Jacobian):
     """Matrix-free Jacobian of the parameter-to-observable map at the observable's current linearisation point
     (jacobian.py:62-139), through the reference's own calls: ``mult`` is ``applyC -> solveFwdIncremental -> applyB`` and a
     sign, ``transpmult`` is ``applyBt -> solveAdjIncremental -> applyCt`` and a sign.  Everything stays on the host, in
     vectors the observable generated."""
 
+    domain = H.PARAMETER                 # the variable the derivative is taken in
+    domain_dim = 1                       # what observable.init_vector calls that space
+    c_block = ("applyC", "applyCt")      # the observable's calls for d(residual)/d(domain variable) and its transpose
+
     def __init__(self, observable):
         self.observable = observable
+        for name in self.c_block:
+            assert hasattr(observable, name), "the observable must have attribute %s" % name
         self.ncalls = 0
         gen = observable.generate_vector
         self._rhs = {False: gen(H.STATE), True: gen(H.ADJOINT)}         # right-hand side of the incremental solve
         self._inc = {False: gen(H.STATE), True: gen(H.ADJOINT)}         # its solution
         q_like = H.new_host_vector(self.mpi_comm())
         observable.B.init_vector(q_like, 0)
-        self.shape = (len(q_like.get_local()), len(gen(H.PARAMETER).get_local()))
+        self.shape = (len(q_like.get_local()), len(gen(self.domain).get_local()))
 
     def mpi_comm(self):
         return self.observable.B.mpi_comm()
 
     def init_vector(self, x, dim):
         if dim not in (0, 1):
-            raise ValueError("dim must be 0 (observable space) or 1 (parameter space)")
-        self.observable.init_vector(x, dim)
+            raise ValueError("dim must be 0 (observable space) or 1 (the space of the derivative's variable)")
+        self.observable.init_vector(x, 0 if dim == 0 else self.domain_dim)
 
     def _through(self, adjoint, into_rhs, solve, out_of_solution, x, y):
         into_rhs(x, self._rhs[adjoint])
@@ -664,12 +692,12 @@ class ObservableJacobian:
     def mult(self, x, y):
         obs = self.observable
         assert hasattr(obs, 'applyB'), 'LinearObservable must have attribute applyB'
-        self._through(False, obs.applyC, obs.solveFwdIncremental, obs.applyB, x, y)
+        self._through(False, getattr(obs, self.c_block[0]), obs.solveFwdIncremental, obs.applyB, x, y)
 
     def transpmult(self, x, y):
         obs = self.observable
         assert hasattr(obs, 'applyBt'), 'LinearObservable must have attribute applyBt'
-        self._through(True, obs.applyBt, obs.solveAdjIncremental, obs.applyCt, x, y)
+        self._through(True, obs.applyBt, obs.solveAdjIncremental, getattr(obs, self.c_block[1]), x, y)
 
     def rows(self, out=None):
         """The Jacobian as a dense (q, N) array, one adjoint solve per row (J^T e_i): how a sample's linearisation is
@@ -686,6 +714,33 @@ class ObservableJacobian:
             self.transpmult(e, row)
             out[i] = row.get_local()
         return out
+
+    def dense(self):
+        """The same array by whichever side is shorter: rows (adjoint solves) or, for a small domain such as a control
+        variable, columns (one forward incremental solve each, J e_j)."""
+        q, n = self.shape
+        if q <= n:
+            return self.rows()
+        out = np.empty((q, n))
+        e, col = H.shape_with(self.init_vector, 1, self.mpi_comm()), H.shape_with(self.init_vector, 0, self.mpi_comm())
+        unit = np.zeros(n)
+        for j in range(n):
+            unit[j] = 1.0
+            e.set_local(unit)
+            e.apply("")
+            unit[j] = 0.0
+            self.mult(e, col)
+            out[:, j] = col.get_local()
+        return out
+
+
+class ObservableControlJacobian(ObservableJacobian):
+    """The same with respect to the CONTROL variable of a control problem (controlJacobian.py:21-95): ``applyCz`` /
+    ``applyCzt`` in place of ``applyC`` / ``applyCt``, vectors of the control space (``observable.init_vector(x, 3)``)."""
+
+    domain = H.CONTROL
+    domain_dim = 3
+    c_block = ("applyCz", "applyCzt")
 
 
 class _NormalOperator:

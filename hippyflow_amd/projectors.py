@@ -442,49 +442,101 @@ class ActiveSubspaceProjector:
         """Randomized SVDs of this rank's Jacobians for derivative-informed training
         (activeSubspaceProjector.py:690-900: ``hp.accuracyEnhancedSVD(J, Omega_m, parameter_rank, s=1)`` per sample,
         rank ``min(jacobian_rank, q, N)``, dumped as ``J_on_proc{rank}.npz`` with keys U_data / sigma_data / V_data and
-        the matching ``mq_on_proc{rank}.npz``).  The Jacobians come from ``observable.jacobian_data(n)`` with
-        ``n = jacobian_data_per_process``; the samples themselves from ``observable.mq_data(n)`` when it exists.
-        Returns (U_data, sigma_data, V_data)."""
-        from .datasets import jacobian_svds
-        n = self.parameters['jacobian_data_per_process']
-        mq_pairs = None
-        if not hasattr(self.observable, 'jacobian_data') and _speaks_reference_protocol(self.observable):
-            # the reference's loop (:726-800): per sample draw, solve, linearise, keep (m, q), then the Jacobian -- here its q
-            # rows, streamed to HBM, instead of hp.accuracyEnhancedSVD applied to the matrix-free Jacobian on the host
-            sampler = SeriallySampledJacobianOperator(self.observable, self.noise, self.prior, operation='JTJ', nsamples=n,
-                                                      control_distribution=self.control_distribution, jacobian_factory=ObservableJacobian)
-            Jhost = ObservableJacobian(self.observable)
-            q, dM = Jhost.shape
-            ms, qs = [], []
+        the matching ``mq_on_proc{rank}.npz`` -- ``mzq_on_proc{rank}.npz`` with ``z_data`` for a control problem).  An
+        observable speaking the reference's protocol is driven through the reference's loop; otherwise the Jacobians come
+        from ``observable.jacobian_data(n)`` with ``n = jacobian_data_per_process`` and the samples from
+        ``observable.mq_data(n)`` when it exists.  Returns (U_data, sigma_data, V_data)."""
+        return self._low_rank_jacobians(compress_files, parameter_jacobian=True, control_jacobian=False)[0]
 
-            def rows():
+    def construct_low_rank_control_Jacobians(self, check_for_data=True, compress_files=True):
+        """The same for the Jacobian with respect to the CONTROL variable (activeSubspaceProjector.py:682-688, serialized
+        sampling): rank ``min(control_jacobian_rank, q, dim z)``, ``Jz_on_proc{rank}.npz`` with keys Uz_data / sigmaz_data /
+        Vz_data next to ``mzq_on_proc{rank}.npz``.  Returns (Uz_data, sigmaz_data, Vz_data)."""
+        assert self.control_distribution is not None                                                  # :701
+        return self._low_rank_jacobians(compress_files, parameter_jacobian=False, control_jacobian=True)[1]
+
+    def _low_rank_jacobians(self, compress_files, parameter_jacobian, control_jacobian):
+        from .datasets import jacobian_svds
+        from .operators import ObservableControlJacobian
+        n = self.parameters['jacobian_data_per_process']
+        obs = self.observable
+        mq_pairs = z_data = data = control_data = None
+        if not hasattr(obs, 'jacobian_data') and _speaks_reference_protocol(obs):
+            # the reference's loop (:726-800): per sample draw, solve, linearise, keep (m, q[, z]), then the Jacobian(s) -- here
+            # as dense rows streamed to HBM, instead of hp.accuracyEnhancedSVD applied to the matrix-free Jacobian on the host
+            sampler = SeriallySampledJacobianOperator(obs, self.noise, self.prior, operation='JTJ', nsamples=n,
+                                                      control_distribution=self.control_distribution, jacobian_factory=ObservableJacobian)
+            Jhost = ObservableJacobian(obs) if parameter_jacobian else None
+            Jz = ObservableControlJacobian(obs) if control_jacobian else None
+            ms, qs, zs, Jz_rows = [], [], [], []
+
+            def points():
                 for _ in sampler._points():
                     ms.append(sampler.m.get_local())
-                    qs.append(self.observable.evalu(sampler.u).get_local())
-                    yield Jhost.rows()
-            data = (ingest_stream(rows(), n, q, dM, ctx=self.ctx), n, q)
+                    qs.append(obs.evalu(sampler.u).get_local())
+                    if self.control_distribution is not None:
+                        zs.append(sampler.z.get_local())
+                    if Jz is not None:
+                        Jz_rows.append(Jz.dense())
+                    yield Jhost.rows() if Jhost is not None else None
+
+            if Jhost is not None:
+                q, dM = Jhost.shape
+                data = (ingest_stream(points(), n, q, dM, ctx=self.ctx), n, q)
+            else:
+                for _ in points():
+                    pass
+            if Jz is not None:
+                control_data = np.stack(Jz_rows)
             mq_pairs = (np.stack(ms), np.stack(qs))
+            z_data = np.stack(zs) if zs else None
         else:
-            data = self.observable.jacobian_data(n)
-        if isinstance(data, tuple):
-            block, ndata, q = data
-        else:
-            data = np.asarray(data, dtype=np.float64)
-            ndata, q, dM = data.shape
-            block = MultiVector.from_vectors(data.reshape(ndata * q, dM), ctx=self.ctx)
-        parameter_rank = min(self.parameters['jacobian_rank'], q, block.size())                 # :724
-        U_data, sigma_data, V_data = jacobian_svds((block, ndata, q), parameter_rank)
+            if parameter_jacobian:
+                data = obs.jacobian_data(n)
+            if control_jacobian:
+                if not hasattr(obs, 'control_jacobian_data'):
+                    raise NotImplementedError("construct_low_rank_control_Jacobians: the observable offers neither the "
+                                              "reference's protocol (applyCz / applyCzt ...) nor control_jacobian_data(n)")
+                control_data = obs.control_jacobian_data(n)
+
+        def as_block(d):
+            if isinstance(d, tuple):
+                return d
+            d = np.asarray(d, dtype=np.float64)
+            nd, rows, cols = d.shape
+            return MultiVector.from_vectors(d.reshape(nd * rows, cols), ctx=self.ctx), nd, rows
+
         out = self.parameters['output_directory']
-        if compress_files and out is not None:
+        save = compress_files and out is not None
+        proc_id = int(self.collective.rank())
+        if save:
             os.makedirs(out, exist_ok=True)
-            proc_id = int(self.collective.rank())
-            np.savez_compressed(out + 'J_on_proc' + str(proc_id) + '.npz', U_data=U_data, sigma_data=sigma_data,
-                                V_data=V_data)                                                   # :877-878
-            if mq_pairs is None and hasattr(self.observable, 'mq_data'):
-                mq_pairs = self.observable.mq_data(ndata)
-            if mq_pairs is not None:
+        results = [None, None]
+        ndata = n
+        if parameter_jacobian:
+            block, ndata, q = as_block(data)
+            parameter_rank = min(self.parameters['jacobian_rank'], q, block.size())                 # :724
+            results[0] = jacobian_svds((block, ndata, q), parameter_rank)
+            if save:
+                np.savez_compressed(out + 'J_on_proc' + str(proc_id) + '.npz', U_data=results[0][0], sigma_data=results[0][1],
+                                    V_data=results[0][2])                                        # :877-878
+        if control_jacobian:
+            block, ndata, q = as_block(control_data)
+            wanted = self.parameters['control_jacobian_rank']
+            control_rank = min(q, block.size()) if wanted is None else min(wanted, q, block.size())      # :732
+            results[1] = jacobian_svds((block, ndata, q), control_rank)
+            if save:
+                np.savez_compressed(out + 'Jz_on_proc' + str(proc_id) + '.npz', Uz_data=results[1][0], sigmaz_data=results[1][1],
+                                    Vz_data=results[1][2])                                       # :896-897
+        if save:
+            if mq_pairs is None and hasattr(obs, 'mq_data'):
+                mq_pairs = obs.mq_data(ndata)
+            if mq_pairs is not None and z_data is not None:
+                np.savez_compressed(out + 'mzq_on_proc' + str(proc_id) + '.npz', m_data=mq_pairs[0], z_data=z_data,
+                                    q_data=mq_pairs[1])                                          # :864-865
+            elif mq_pairs is not None:
                 np.savez_compressed(out + 'mq_on_proc' + str(proc_id) + '.npz', m_data=mq_pairs[0], q_data=mq_pairs[1])   # :860
-        return U_data, sigma_data, V_data
+        return results
 
     def test_errors(self, test_input=True, test_output=False, ranks=[None], cut_off=1e-12, samples=None,
                     output_samples=None):

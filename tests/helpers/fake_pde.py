@@ -18,7 +18,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-STATE, PARAMETER, ADJOINT = 0, 1, 2
+STATE, PARAMETER, ADJOINT, CONTROL = 0, 1, 2, 3
 
 
 class _Comm:
@@ -132,7 +132,7 @@ class NumpyProblem:
         self.n_fwd += 1
         if self.fail_every and self.n_fwd % self.fail_every == 0:
             raise RuntimeError("Newton did not converge")
-        out.set_local(spla.spsolve(self._operator(x[PARAMETER].get_local()), self.f))
+        out.set_local(spla.spsolve(self._operator(x[PARAMETER].get_local()), self.forcing(x)))
 
     def setLinearizationPoint(self, x, gauss_newton_approx):
         u, m = x[STATE].get_local(), x[PARAMETER].get_local()
@@ -147,10 +147,56 @@ class NumpyProblem:
         assert (i, j) in ((ADJOINT, PARAMETER), (PARAMETER, ADJOINT))
         out.set_local(self._Cdiag * direction.get_local())          # C is diagonal: C and C^T coincide
 
+    def forcing(self, x):
+        return self.f
+
     def jacobian_dense(self, B):
         """-B A^{-1} C at the current linearisation point (for the checks, never used by a product path)."""
         AinvC = self._A.solve(np.diag(self._Cdiag))
         return -(B @ AinvC)
+
+
+class NumpyControlProblem(NumpyProblem):
+    """The same state equation with a control on the right-hand side:  (K + diag(exp(m))) u = f + G z,  z of length dz.
+    d(residual)/dz = Cz = -G, so the Jacobian with respect to the control is  Jz = -B A^{-1} Cz = B A^{-1} G.  Having ``Cz`` is
+    what makes a problem a control problem for the reference's observable (observable.py:79)."""
+
+    def __init__(self, n, dz, vector_class, seed=0):
+        super().__init__(n, vector_class, seed)
+        self.dz = dz
+        centres = (np.arange(dz) + 0.5) * n / dz
+        self.G = np.exp(-0.5 * ((np.arange(n)[:, None] - centres[None, :]) / 3.0) ** 2)
+        self.Cz = MatrixOperator(-self.G)
+
+    def generate_control(self):
+        v = self._vec()
+        v.init(self.dz)
+        return v
+
+    def forcing(self, x):
+        return self.f + self.G @ x[CONTROL].get_local()
+
+    def apply_ij(self, i, j, direction, out):
+        if (i, j) == (ADJOINT, CONTROL):
+            out.set_local(-self.G @ direction.get_local())
+        elif (i, j) == (CONTROL, ADJOINT):
+            out.set_local(-self.G.T @ direction.get_local())
+        else:
+            super().apply_ij(i, j, direction, out)
+
+    def control_jacobian_dense(self, B):
+        return B @ self._A.solve(self.G)
+
+
+class ControlDistribution:
+    """What the projectors ask of a control distribution: ``sample(z)`` (and optionally ``mean``)."""
+
+    def __init__(self, dz, seed=3):
+        self.rng = np.random.default_rng(seed)
+        self.dz = dz
+
+    def sample(self, z):
+        z.set_local(0.3 * self.rng.standard_normal(self.dz))
 
 
 def observation_matrix(q, n, seed=1):
@@ -205,13 +251,21 @@ class ProtocolObservable:
         self.problem = problem
         self.B = B
         self.n_fwd_solve = self.n_adj_solve = self.n_inc_solve = 0
+        self.is_control_problem = hasattr(problem, "Cz")
+        if self.is_control_problem:                   # (observable.py:299-323)
+            self.applyCz = lambda dz, out: self.problem.apply_ij(ADJOINT, CONTROL, dz, out)
+            self.applyCzt = lambda dp, out: self.problem.apply_ij(CONTROL, ADJOINT, dp, out)
 
     def mpi_comm(self):
         return self.B.mpi_comm()
 
     def generate_vector(self, component="ALL"):
         if component == "ALL":
-            return [self.problem.generate_state(), self.problem.generate_parameter(), self.problem.generate_state()]
+            x = [self.problem.generate_state(), self.problem.generate_parameter(), self.problem.generate_state()]
+            return x + [self.problem.generate_control()] if self.is_control_problem else x
+        if component == CONTROL:
+            assert self.is_control_problem, 'Assuming it is a control problem'
+            return self.problem.generate_control()
         return self.problem.generate_parameter() if component == PARAMETER else self.problem.generate_state()
 
     def init_vector(self, x, dim):
@@ -219,6 +273,9 @@ class ProtocolObservable:
             self.B.init_vector(x, 0)
         elif dim == 1:
             self.problem.C.init_vector(x, 1)
+        elif dim == 3:
+            assert self.is_control_problem, 'Assuming it is a control problem'
+            self.problem.Cz.init_vector(x, 1)
         else:
             raise ValueError(dim)
 

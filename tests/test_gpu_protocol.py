@@ -339,3 +339,56 @@ def test_training_data_and_low_rank_jacobians_from_a_reference_observable(ctx, g
         np.testing.assert_allclose(np.sort(sig[i])[::-1], np.linalg.svd(Jd, compute_uv=False), rtol=1e-9)
         assert rel((U[i] * sig[i]) @ V[i].T, Jd) < 1e-9
         np.testing.assert_allclose(mq["q_data"][i], obs.B.A @ u.get_local(), rtol=1e-12)
+
+
+def test_control_problem_low_rank_jacobians(ctx, tmp_path):
+    """A control problem (state equation with a control z on its right-hand side) driven through the reference's protocol:
+    the control is sampled next to the parameter, enters the forward solve, and construct_low_rank_control_Jacobians
+    (activeSubspaceProjector.py:682-688) dumps the SVDs of Jz = B A^-1 G per sample beside (m, z, q)."""
+    n, q, dz, nd = 40, 6, 4, 3
+    out = str(tmp_path) + "/"
+    prob = fp.NumpyControlProblem(n, dz, hf.HostVector)
+    obs = fp.ProtocolObservable(prob, fp.MatrixOperator(fp.observation_matrix(q, n)))
+    prior = fp.NumpyPrior(n, hf.HostVector)
+    hf.parRandom.reseed(4)
+    hf.parRandom.split(0)
+    asp = hf.ActiveSubspaceParameterList()
+    asp['jacobian_data_per_process'], asp['output_directory'], asp['verbose'] = nd, out, False
+    asp['control_jacobian_rank'], asp['jacobian_rank'] = 3, 5
+    AS = hf.ActiveSubspaceProjector(obs, prior, control_distribution=fp.ControlDistribution(dz), parameters=asp)
+    Uz, sz, Vz = AS.construct_low_rank_control_Jacobians()
+    assert Uz.shape == (nd, q, 3) and sz.shape == (nd, 3) and Vz.shape == (nd, dz, 3) and obs.n_fwd_solve == nd
+    jf = np.load(out + "Jz_on_proc0.npz")
+    assert sorted(jf.files) == ["Uz_data", "Vz_data", "sigmaz_data"]
+    mzq = np.load(out + "mzq_on_proc0.npz")
+    assert sorted(mzq.files) == ["m_data", "q_data", "z_data"] and mzq["z_data"].shape == (nd, dz)
+    assert not os.path.exists(out + "mq_on_proc0.npz") and not os.path.exists(out + "J_on_proc0.npz")
+    u, m, z = obs.generate_vector(hf.STATE), obs.generate_vector(hf.PARAMETER), obs.generate_vector(hf.CONTROL)
+    for i in range(nd):
+        m.set_local(mzq["m_data"][i])
+        z.set_local(mzq["z_data"][i])
+        obs.solveFwd(u, [u, m, None, z])
+        obs.setLinearizationPoint([u, m, None, z])
+        np.testing.assert_allclose(mzq["q_data"][i], obs.B.A @ u.get_local(), rtol=1e-12)
+        Jd = prob.control_jacobian_dense(obs.B.A)
+        sv = np.linalg.svd(Jd, compute_uv=False)
+        np.testing.assert_allclose(sz[i], sv[:3], rtol=1e-6)               # rank 3 of 4 by one randomized pass with s = 1
+        assert rel(Uz[i].T @ Uz[i], np.eye(3)) < 1e-10 and rel(Vz[i].T @ Vz[i], np.eye(3)) < 1e-10
+        assert rel(Uz[i].T @ Jd @ Vz[i], np.diag(sz[i])) < 1e-6
+    # the parameter Jacobians of the same control problem: (m, z, q) again, J taken at (m, z)
+    U, sig, V = AS.construct_low_rank_Jacobians()
+    assert U.shape == (nd, q, 5) and V.shape == (nd, n, 5) and os.path.exists(out + "J_on_proc0.npz")
+    mzq = np.load(out + "mzq_on_proc0.npz")
+    for i in range(nd):
+        m.set_local(mzq["m_data"][i])
+        z.set_local(mzq["z_data"][i])
+        obs.solveFwd(u, [u, m, None, z])
+        obs.setLinearizationPoint([u, m, None, z])
+        Jd = prob.jacobian_dense(obs.B.A)
+        assert rel(U[i].T @ Jd @ V[i], np.diag(sig[i])) < 1e-6
+    # full rank when no control rank is named
+    asp['control_jacobian_rank'] = None
+    Uz, sz, Vz = AS.construct_low_rank_control_Jacobians(compress_files=False)
+    assert sz.shape == (nd, dz)
+    with pytest.raises(AssertionError):
+        hf.ActiveSubspaceProjector(obs, prior, parameters=asp).construct_low_rank_control_Jacobians()

@@ -109,6 +109,45 @@ def test_jacobian_chain_on_host_vectors_matches_the_reference(golden_dir):
     np.testing.assert_allclose(Y[1].get_local(), Jd.T @ (Jd @ np.ones(n)), rtol=1e-11)
 
 
+def test_control_jacobian_chain_on_host_vectors():
+    """ObservableControlJacobian (controlJacobian.py:21-95) over a control problem: applyCz -> solveFwdIncremental -> applyB
+    and its transpose, against the dense Jz = B A^-1 G of the numpy problem; shapes through init_vector(x, 3)."""
+    n, q, dz = 40, 6, 4
+    prob = fp.NumpyControlProblem(n, dz, hf.HostVector)
+    obs = fp.ProtocolObservable(prob, fp.MatrixOperator(fp.observation_matrix(q, n)))
+    assert obs.is_control_problem and len(obs.generate_vector()) == 4
+    u, m, z = obs.generate_vector(hf.STATE), obs.generate_vector(hf.PARAMETER), obs.generate_vector(hf.CONTROL)
+    rng = np.random.default_rng(0)
+    m.set_local(0.3 * rng.standard_normal(n))
+    z.set_local(rng.standard_normal(dz))
+    x = [u, m, None, z]
+    obs.solveFwd(u, x)
+    obs.setLinearizationPoint(x)
+    Jz = hf.ObservableControlJacobian(obs)
+    assert isinstance(Jz, hf.Jacobian) and tuple(Jz.shape) == (q, dz)
+    Jd = prob.control_jacobian_dense(obs.B.A)
+    xz, xq = rng.standard_normal(dz), rng.standard_normal(q)
+    yq, yz = hv(np.zeros(q)), hv(np.zeros(dz))
+    Jz.mult(hv(xz), yq)
+    Jz.transpmult(hv(xq), yz)
+    np.testing.assert_allclose(yq.get_local(), Jd @ xz, rtol=1e-11)
+    np.testing.assert_allclose(yz.get_local(), Jd.T @ xq, rtol=1e-11)
+    np.testing.assert_allclose(Jz.dense(), Jd, rtol=1e-10, atol=1e-14)         # dz < q: by columns
+    np.testing.assert_allclose(Jz.rows(), Jd, rtol=1e-10, atol=1e-14)
+    v = hf.HostVector()
+    Jz.init_vector(v, 1)
+    assert v.size() == dz
+    Jz.init_vector(v, 0)
+    assert v.size() == q
+    # the control enters the forward solve: the parameter Jacobian is taken at (m, z)
+    J = hf.ObservableJacobian(obs)
+    np.testing.assert_allclose(J.dense(), prob.jacobian_dense(obs.B.A), rtol=1e-10, atol=1e-14)
+    with pytest.raises(AssertionError):            # not a control problem: no applyCz
+        hf.ObservableControlJacobian(fp.ProtocolObservable(fp.NumpyProblem(n, hf.HostVector), obs.B))
+    with pytest.raises(NotImplementedError):
+        hf.Jacobian().transpmult(None, None)
+
+
 class _MpiLikeComm:
     def __init__(self, size=1, rank=0):
         self._size, self._rank, self.splits = size, rank, []
