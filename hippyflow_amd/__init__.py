@@ -26,6 +26,7 @@ from .io_utils import get_projectors, modify_projectors
 from .datasets import (derivative_dataset, jacobian_svds, jacobian_times_input_basis,
                        jacobian_transpose_times_output_basis, save_JPsi_data, save_JstarPhi_data, save_Jsvd_data,
                        save_mq_data)
+from .datagen import DataGenerator, compress_dataset, data_generator_settings
 from .utilities import dense_to_mv_local, mv_to_dense, mv_to_dense_local
 
 __version__ = "0.1.0"

@@ -182,3 +182,41 @@ def test_split_communicators_without_mesh_partitioning(monkeypatch):
     coll = hf.MultipleSerialPDEsCollective(_MpiLikeComm())
     assert isinstance(coll, hf.NullCollective) and coll.size() == 1
     assert hf.MultipleSamePartitioningPDEsCollective(coll) is coll
+
+
+def test_compress_dataset_archives_and_keys(tmp_path):
+    """compress_dataset (dataGenerator.py:495-700) on per-sample files written by hand: which archives appear, their keys, what the
+    clean-up removes; no GPU involved."""
+    root = str(tmp_path) + "/"
+    rng = np.random.default_rng(0)
+    nd, dM, dQ, dZ, r = 3, 6, 4, 2, 2
+    for folder in ("mzq_data", "J_data", "Jz_data"):
+        os.makedirs(root + folder)
+    for i in range(nd):
+        np.save(root + "mzq_data/m_sample_%d.npy" % i, rng.standard_normal(dM))
+        np.save(root + "mzq_data/q_sample_%d.npy" % i, rng.standard_normal(dQ))
+        np.save(root + "mzq_data/z_sample_%d.npy" % i, rng.standard_normal(dZ))
+        np.save(root + "J_data/JstarPhi%d.npy" % i, rng.standard_normal((dM, r)))
+        np.save(root + "J_data/U_sample_%d.npy" % i, rng.standard_normal((dQ, r)))
+        np.save(root + "J_data/sigma_sample_%d.npy" % i, rng.standard_normal(r))
+        if i < nd - 1:                                   # an incomplete set: not archived
+            np.save(root + "J_data/V_sample_%d.npy" % i, rng.standard_normal((dM, r)))
+        for stem, shape in (("Uz_sample_%d", (dQ, r)), ("sigmaz_sample_%d", (r,)), ("Vz_sample_%d", (dZ, r))):
+            np.save(root + "Jz_data/" + stem % i + ".npy", rng.standard_normal(shape))
+    Phi = rng.standard_normal((dQ, r))
+    hf.compress_dataset(root, derivatives=(1, 1), clean_up=False, has_z_data=True, output_decoder=Phi, output_encoder=Phi)
+    assert sorted(f for f in os.listdir(root) if f.endswith(".npz")) == ["JstarPhi_data.npz", "Jzsvd_data.npz", "mzq_data.npz"]
+    f = np.load(root + "JstarPhi_data.npz")
+    assert sorted(f.files) == ["JstarPhi_data", "MPhi", "Phi"] and f["JstarPhi_data"].shape == (nd, dM, r)
+    np.testing.assert_array_equal(f["JstarPhi_data"][1], np.load(root + "J_data/JstarPhi1.npy"))
+    fz = np.load(root + "Jzsvd_data.npz")
+    assert sorted(fz.files) == ["Uz_data", "Vz_data", "sigmaz_data"] and fz["Vz_data"].shape == (nd, dZ, r)
+    assert np.load(root + "mzq_data.npz")["z_data"].shape == (nd, dZ)
+    os.remove(root + "mzq_data.npz")
+    hf.compress_dataset(root, derivatives=(1, 1), clean_up=True, has_z_data=True, derivatives_only=True)
+    assert not os.path.exists(root + "mzq_data.npz") and os.path.isdir(root + "mzq_data") and not os.path.exists(root + "J_data")
+    with pytest.raises(FileNotFoundError):
+        hf.compress_dataset(root + "nothing/")
+    with pytest.raises(AssertionError):
+        hf.compress_dataset(root, derivatives=(0, 1), has_z_data=False)
+    assert hf.data_generator_settings()["oversample"] == 10
