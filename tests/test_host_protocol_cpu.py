@@ -220,3 +220,48 @@ def test_compress_dataset_archives_and_keys(tmp_path):
     with pytest.raises(AssertionError):
         hf.compress_dataset(root, derivatives=(0, 1), has_z_data=False)
     assert hf.data_generator_settings()["oversample"] == 10
+
+
+def test_pde_side_names_are_forwarded_to_an_installed_reference_package(monkeypatch):
+    """`from hippyflow import *` -> `from hippyflow_amd import *`: the classes that BUILD the host objects (BiLaplacian2D,
+    LinearStateObservable, ...; confusion_problem_setup.py:94, confusion_linear_observable.py:148) are the reference
+    package's own, forwarded when it is installed and absent -- with an error that says why -- when it is not."""
+    import importlib
+    import importlib.machinery
+    import types
+
+    assert "BiLaplacian2D" not in hf.__all__ and "PODProjector" in hf.__all__ and "operators" not in hf.__all__
+    with pytest.raises(AttributeError, match="forwarded, not re-implemented"):
+        hf.BiLaplacian2D
+    with pytest.raises(AttributeError):
+        hf.no_such_name
+
+    def fake(name, **members):
+        mod = types.ModuleType(name)
+        mod.__spec__ = importlib.machinery.ModuleSpec(name, loader=None, is_package=True)
+        mod.__path__ = []
+        mod.__dict__.update(members)
+        monkeypatch.setitem(sys.modules, name, mod)
+        return mod
+
+    class BiLaplacian2D:            # stands for the reference's FEniCS-side class
+        pass
+
+    for name in ("dolfin", "hippylib", "hippyflow", "hippyflow.modeling"):
+        fake(name)
+    fake("hippyflow.modeling.maternPrior", BiLaplacian2D=BiLaplacian2D)
+    try:
+        assert hf._reference_package_importable()
+        assert hf.BiLaplacian2D is BiLaplacian2D              # first use imports the reference module ...
+        assert hf.__dict__["BiLaplacian2D"] is BiLaplacian2D  # ... and the name stays
+        with pytest.raises(AttributeError, match="hippyflow.modeling.observable"):
+            hf.LinearStateObservable                          # a reference install without that module: says which
+        ns = {}
+        importlib.reload(hf)
+        exec("from hippyflow_amd import *", ns)
+        assert ns["BiLaplacian2D"] is BiLaplacian2D and "PODProjector" in ns
+    finally:
+        hf.__dict__.pop("BiLaplacian2D", None)
+        monkeypatch.undo()
+        importlib.reload(hf)
+    assert "BiLaplacian2D" not in hf.__all__
