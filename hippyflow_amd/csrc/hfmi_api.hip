@@ -171,6 +171,7 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   c->nn_hook_user = nullptr;
   c->nn_hook_panels = 0;
   c->nn_hook_called = false;
+  c->nn_upper_hint = false;
   HIP_TRY(hipMalloc((void**)&c->small, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->small, 0, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double), c->stream));
   HIP_TRY(hipMalloc((void**)&c->status_dev, sizeof(hfmi_status_words)));
@@ -533,6 +534,15 @@ static int read_back(hfmi_ctx* ctx, const double* dev, size_t count, double* hos
 // Split read-back: `begin` snapshots the status words at the current point of the main stream (event + copy on the
 // auxiliary stream), `finish` waits for that copy only -- kernels queued on the main stream in between keep running
 // while the host looks at the words and decides what to launch next.
+// Y = A S with S upper triangular (R^-1 of a Cholesky-QR pass: every factorisation kernel writes its strict lower triangle as
+// zeros): the hint lets the resident-S kernel skip the structurally zero column tiles; any other route ignores it
+static int launch_nn_upper(hfmi_ctx* ctx, const double* A, int64_t lda, int m, const double* S, int ld, int r, double* Y, int64_t ldy,
+                           int64_t N) {
+  ctx->nn_upper_hint = true;
+  const int s = launch_tsgemm_nn(ctx, A, lda, m, S, ld, r, 1.0, 0.0, Y, ldy, N);
+  ctx->nn_upper_hint = false;
+  return s;
+}
 static int read_status_begin(hfmi_ctx* ctx) {
   HIP_TRY(hipEventRecord(ctx->ev_status, ctx->stream));
   HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_status, 0));
@@ -1493,13 +1503,13 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
         *deferred = true;
         break;
       }
-      HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
+      HFMI_TRY(launch_nn_upper(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, Q->p, Q->ld, N));
     } else {
       // snapshot the status words on the auxiliary stream and enqueue Q <- Q R^-1 BEFORE waiting for them: the host
       // round trip then overlaps the contraction.  If the factorisation failed, R^-1 was never written by this pass
       // and Q is about to be discarded anyway (the callers restore / recompute the block on HFMI_ERR_NUMERIC).
       HFMI_TRY(read_status_begin(ctx));
-      HFMI_TRY(launch_tsgemm_nn(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Q->p, Q->ld, N));
+      HFMI_TRY(launch_nn_upper(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, Q->p, Q->ld, N));
       HFMI_TRY(read_status_finish(ctx, &st));
       if (st.failed) HFMI_FAIL(HFMI_ERR_NUMERIC, "borth_qr: Gram matrix not positive definite even after shifting (pass %d)", passes + 1);
       if (passes == 0) first_pass_clean = !st.shifted;
@@ -1708,7 +1718,7 @@ static int op_rayleigh_quotient_gram(hfmi_op* A, const hfmi_block* Q, int slot_T
   double* Gc2 = gam ? Gc + ldm * k : Gc;
   HFMI_TRY(launch_tsgemm_tn(ctx, X.p, X.ld, m, Q->p, Q->ld, k, X.N, 1.0, 0.0, Gc, 1, ldm, 0));
   HFMI_TRY(launch_zero_pad(ctx, Gc, m, k, ldm));
-  if (fold_rinv) HFMI_TRY(launch_tsgemm_nn(ctx, Gc, ldm, k, sm_ptr(ctx, SM_RINV), SM_LD, k, 1.0, 0.0, Gc, ldm, m));
+  if (fold_rinv) HFMI_TRY(launch_nn_upper(ctx, Gc, ldm, k, sm_ptr(ctx, SM_RINV), SM_LD, k, Gc, ldm, m));
   if (gam) {
     HFMI_TRY(launch_gamma_apply_cm(ctx, Gc, Gc2, ldm, A->ndata, A->q, k, A->gamma_inv, (int)round_up(A->q, 16)));
     HFMI_TRY(launch_zero_pad(ctx, Gc2, m, k, ldm));

@@ -11,6 +11,7 @@ static int g_rem4 = 1;        // last column tile of <= 12 columns in 4-column g
 static int g_nn_res = 1;      // small matrix resident in LDS + persistent workgroups when it fits
 static int g_nn_halve_last = 0;   // overlapped rank reduction: last round of a 2-3 round product as two launches of half-height tiles
                                   // (off: on one GPU the shorter tiles cost more than the smaller exposed panel saves, profiles/r04i_halve_last_ab.txt)
+static int g_nn_upper = 1;    // Q R^-1: skip the structurally zero column tiles of the upper-triangular small matrix (A/B: "nn_upper")
 static int g_nn_res_tt = 0;   // 0: tile height of nn_res by the round count (below); 1: always the table's; 2: always one less (A/B)
 int nn_tuning_set(const char* key, int value) {
   if (!strcmp(key, "rem4") && (value == 0 || value == 1)) g_rem4 = value;
@@ -20,6 +21,7 @@ int nn_tuning_set(const char* key, int value) {
   else if (!strcmp(key, "nn_res") && (value == 0 || value == 1)) g_nn_res = value;
   else if (!strcmp(key, "nn_halve_last") && (value == 0 || value == 1)) g_nn_halve_last = value;
   else if (!strcmp(key, "nn_res_tt") && value >= 0 && value <= 2) g_nn_res_tt = value;
+  else if (!strcmp(key, "nn_upper") && (value == 0 || value == 1)) g_nn_upper = value;
   else return 0;
   return 1;
 }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
 template <int TT, int NT, int R4>
 __global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restrict__ A, int64_t lda, int m,
                                                           const double* __restrict__ S, int lds_, int r,
-                                                          double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles) {
+                                                          double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles, int upper) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* L = reinterpret_cast<double*>(smem);  // [round_up(m, 4)][SLD]
   constexpr int WAVES = 8;
@@ -367,16 +369,21 @@ __global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restri
   // one k-step; the small-matrix fragments are single-buffered: as soon as the MFMAs of column tile nt have issued,
   // its register is refilled with the fragment of k-step ksn and the other tiles' MFMAs cover the LDS latency
   SFrag sf;
-  auto mma = [&](const AFrag& a, int ksn) {
+  // upper != 0: S is upper triangular (S[i][j] = 0 for i > j: R^-1 of the QR).  At reduction step ks (rows 4 ks .. 4 ks + 3 of S)
+  // the column tiles nt < ks / 4 hold nothing but zeros: their MFMAs are skipped -- products with exact zeros, so the result
+  // has the same bits -- which is 45 % of the matrix instructions at k = 138 (wave-uniform test, one scalar branch per tile).
+  auto mma = [&](const AFrag& a, int ksn, int nt0) {
     const double* Ln = L + (ksn * 4 + kk) * SLD;
 #pragma unroll
     for (int nt = 0; nt < NTF; ++nt) {
+      if (nt >= nt0) {
 #pragma unroll
-      for (int tp = 0; tp < TP; ++tp) {
-        acc[2 * tp][nt] = MFMA_F64(sf.f[nt], a.p[tp].x, acc[2 * tp][nt]);
-        acc[2 * tp + 1][nt] = MFMA_F64(sf.f[nt], a.p[tp].y, acc[2 * tp + 1][nt]);
+        for (int tp = 0; tp < TP; ++tp) {
+          acc[2 * tp][nt] = MFMA_F64(sf.f[nt], a.p[tp].x, acc[2 * tp][nt]);
+          acc[2 * tp + 1][nt] = MFMA_F64(sf.f[nt], a.p[tp].y, acc[2 * tp + 1][nt]);
+        }
+        if (ODD) acc[TT - 1][nt] = MFMA_F64(sf.f[nt], a.s, acc[TT - 1][nt]);
       }
-      if (ODD) acc[TT - 1][nt] = MFMA_F64(sf.f[nt], a.s, acc[TT - 1][nt]);
       sf.f[nt] = Ln[nt * 16 + c16];
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restri
     for (int u = 0; u < RD; ++u) {
       if (q0 + u < total) {   // wave-uniform
         load_next(ring[(u + RD - 1) % RD]);
-        mma(ring[u], (cks + 1 == nk) ? 0 : cks + 1);
+        mma(ring[u], (cks + 1 == nk) ? 0 : cks + 1, upper ? (cks >> 2) : 0);
         if (++cks == nk) {
           store_tile(ctile);
           zero_acc();
@@ -692,7 +699,9 @@ static int nn_launch_res(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
   const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   const int grid = ntiles < cus ? ntiles : cus;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, ntiles);
+  static const bool env_off = getenv("HFMI_NN_UPPER") && atoi(getenv("HFMI_NN_UPPER")) == 0;   // A/B switch
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, ntiles,
+                     (ctx->nn_upper_hint && g_nn_upper && !env_off) ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }

@@ -107,6 +107,9 @@ struct hfmi_ctx {
   void* nn_hook_user;
   int nn_hook_panels;
   bool nn_hook_called;
+  // set around ONE launch_tsgemm_nn call by a caller that knows its small matrix is upper triangular (Q <- Q R^-1 of the QR):
+  // the resident-S kernel then skips the column tiles that are structurally zero at each reduction step (bit-identical results)
+  bool nn_upper_hint;
   hipEvent_t ev_panel[8], ev_join;
   // streaming ingest: uploads from pinned host memory on their own stream, a ring of completion events = tickets
   hipStream_t ingest_stream;

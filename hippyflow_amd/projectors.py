@@ -233,15 +233,17 @@ class ActiveSubspaceProjector:
     """Projectors from the sample-averaged GN Hessian E[J^T J] (input) and E[J J^T] (output)."""
 
     def __init__(self, observable, prior, control_distribution=None, mesh_constructor_comm=None,
-                 collective=NullCollective(), parameters=ActiveSubspaceParameterList(), ctx=None):
-        self.parameters = parameters
+                 collective=None, parameters=None, ctx=None):
+        # defaults made per instance: the reference's `parameters = ActiveSubspaceParameterList()` default is ONE list shared by every
+        # projector built without one (a rank raised by test_errors on one instance would leak into the next)
+        self.parameters = parameters if parameters is not None else ActiveSubspaceParameterList()
         self.observable = observable
         self.prior = prior
         self.control_distribution = control_distribution
         if mesh_constructor_comm is None and hasattr(observable, "mpi_comm"):
             mesh_constructor_comm = observable.mpi_comm()                                   # :279-282
         self.mesh_constructor_comm = mesh_constructor_comm
-        self.collective = collective
+        self.collective = collective if collective is not None else NullCollective()
         self.ctx = ctx or L.Context.default()
         self.noise = None
         if _speaks_reference_protocol(observable) and hasattr(prior, "init_vector"):
@@ -580,11 +582,11 @@ class ActiveSubspaceProjector:
 class KLEProjector:
     """Input subspace from the prior covariance alone (KLEProjector.py:72-199)."""
 
-    def __init__(self, prior, mesh_constructor_comm=None, collective=None, parameters=KLEParameterList(), ctx=None):
+    def __init__(self, prior, mesh_constructor_comm=None, collective=None, parameters=None, ctx=None):
         self.prior = prior
         self.mesh_constructor_comm = mesh_constructor_comm
         self.collective = collective if collective is not None else NullCollective()
-        self.parameters = parameters
+        self.parameters = parameters if parameters is not None else KLEParameterList()
         self.ctx = ctx or L.Context.default()
         self.noise = None
         # the mass matrix: assembled matrices (scipy / PETSc / dolfin) go to HBM as CSR; anything else stays a host
@@ -676,11 +678,11 @@ class BoundaryRestrictedKLEProjector:
     numerically zero.  ``B^-1`` is the reference's MUMPS LU (:360-361); on the device it is a Jacobi-PCG solve (B is
     a boundary mass matrix plus an identity block: well conditioned)."""
 
-    def __init__(self, prior, ds=None, parameters=KLEParameterList(), boundary_mass=None, ctx=None):
+    def __init__(self, prior, ds=None, parameters=None, boundary_mass=None, ctx=None):
         import scipy.sparse as sp
         self.prior = prior
         self.ds = ds
-        self.parameters = parameters
+        self.parameters = parameters if parameters is not None else KLEParameterList()
         self.ctx = ctx or L.Context.default()
         if boundary_mass is None:
             boundary_mass = getattr(prior, "M_boundary", None)
@@ -730,8 +732,8 @@ class PODProjector:
     double pass over the snapshot-Gram operator (PODProjector.py:331-389)."""
 
     def __init__(self, observable, prior, control_distribution=None, mesh_constructor_comm=None, collective=None,
-                 parameters=PODParameterList(), ctx=None):
-        self.parameters = parameters
+                 parameters=None, ctx=None):
+        self.parameters = parameters if parameters is not None else PODParameterList()
         self.observable = observable
         self.prior = prior
         self.control_distribution = control_distribution

@@ -358,6 +358,33 @@ def test_resident_nn_product_is_independent_of_the_tile_height(ctx):
         assert np.abs(outs[0] - ref).max() < 1e-12 * np.abs(ref).max() * m
 
 
+@pytest.mark.parametrize("N,k", [(4096, 17), (20000, 74), (50001, 138), (8192, 160), (30000, 33)])
+def test_triangular_skip_of_q_rinv_is_bit_identical(ctx, N, k):
+    """Q <- Q R^-1 of the Cholesky-QR: R^-1 is upper triangular, the resident-S kernel skips the column tiles that are structurally
+    zero at each reduction step (tuning key nn_upper).  Skipped products are with exact zeros, so Q and R must not change by a bit
+    -- with the blocked MFMA Cholesky and with the column-at-a-time kernels (both must leave the strict lower triangle of R^-1
+    as zeros), for a graded block that needs more than one pass."""
+    from hippyflow_amd import _lib as L
+    rng = np.random.default_rng(N + k)
+    Z = rng.standard_normal((N, k)) * np.exp(-0.08 * np.arange(k))
+    for chol in (0, 1):
+        got = {}
+        for upper in (0, 1):
+            L.call("hfmi_tuning_set", b"chol", chol)
+            L.call("hfmi_tuning_set", b"nn_upper", upper)
+            try:
+                Q = hf.MultiVector.from_dense(Z)
+                R = Q.orthogonalize()
+                got[upper] = (R, Q.to_dense(), Q.last_qr_passes)
+            finally:
+                L.call("hfmi_tuning_set", b"chol", 0)
+                L.call("hfmi_tuning_set", b"nn_upper", 1)
+        assert got[0][2] == got[1][2]
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), "chol=%d" % chol
+        Qd = got[1][1]
+        assert np.abs(Qd.T @ Qd - np.eye(k)).max() < 1e-14 * max(k, 8) and rel(Qd @ got[1][0], Z) < 1e-12
+
+
 # ------------------------------------------------------------------ QR (a7)
 @pytest.mark.parametrize("N,k,cond", [(300, 20, 1e0), (4225, 30, 1e3), (4225, 30, 1e9), (20000, 138, 1e5), (1000, 200, 1e2)])
 def test_orthogonalize_matches_reference_mgs(ctx, N, k, cond):

@@ -357,6 +357,17 @@ def test_pod_projector_class(ctx, tmp_path):
     np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "POD_d.npy")), pod.d)
 
 
+def test_projector_defaults_are_per_instance(ctx):
+    """The reference's `parameters = PODParameterList()` default argument is ONE list shared by every projector built without
+    one; here each instance gets its own (test_errors raises `rank` in place)."""
+    a, b = hf.PODProjector(object(), object(), ctx=ctx), hf.PODProjector(object(), object(), ctx=ctx)
+    a.parameters['rank'] = 7
+    assert b.parameters['rank'] == 20 and a.collective is not b.collective and a.collective.size() == 1
+    c, d = hf.ActiveSubspaceProjector(object(), object(), ctx=ctx), hf.ActiveSubspaceProjector(object(), object(), ctx=ctx)
+    c.parameters['rank'] = 9
+    assert d.parameters['rank'] == 128 and d.collective.rank() == 0
+
+
 def test_kle_projector_class(ctx):
     """The reference's KLE test, mass and identity modes (test_KLEProjector.py:80-217)."""
     N = 1200
