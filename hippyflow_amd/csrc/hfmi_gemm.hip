@@ -26,6 +26,12 @@
 // tsgemm_tn
 // =====================================================================================
 constexpr int TN_BK = 32;   // reduction indices per LDS stage
+// the streamed operand is read once by one workgroup: -DHFMI_TN_NT marks its loads non-temporal (A/B build, scripts/build_variant.sh)
+#ifdef HFMI_TN_NT
+#define TN_LOAD_A(p) __builtin_nontemporal_load(p)
+#else
+#define TN_LOAD_A(p) (*(p))
+#endif
 // the finely split tail of a launch (see the block mapping in k_tsgemm_tn); nrb = 0: none
 struct TnTail {
   int nrb, nsplit;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || MT * NT <= 20) ? 2 : 1) 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int h = 0; h < AH; ++h) dst[h][mt] = *reinterpret_cast<const d2*>(a_ptr[mt] + t + 2 * h);
+      for (int h = 0; h < AH; ++h) dst[h][mt] = TN_LOAD_A(reinterpret_cast<const d2*>(a_ptr[mt] + t + 2 * h));
   };
   // Full tiles: lane (r16, kk) reads column nt*16 + r16.  The fragments are SINGLE-buffered: the moment the MFMAs
   // of column tile nt have been issued, its registers are refilled with the next iteration's fragment, and the MFMAs of

@@ -30,6 +30,11 @@ int nn_tuning_set(const char* key, int value) {
 // tsgemm_nn
 // =====================================================================================
 constexpr int NN_KC = 32;  // reduction indices per LDS stage (8 MFMA k-steps)
+#ifdef HFMI_NN_NT
+#define NN_LOAD_A(p) __builtin_nontemporal_load(p)
+#else
+#define NN_LOAD_A(p) (*(p))
+#endif
 
 // Preconditions: lda multiple of 32 and >= round_up(N,32) (rows beyond N readable); S finite, ld even.
 // The reduction axis m may be split over gridDim-many workgroups (msplit > 1): each split writes a raw partial
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
     if (col > m - 1) col = m - 1;
     const double* p = A + (int64_t)col * lda;
 #pragma unroll
-    for (int tp = 0; tp < TP; ++tp) dst.p[tp] = *reinterpret_cast<const d2*>(p + toff[tp]);
-    if (ODD) dst.s = p[toff1];
+    for (int tp = 0; tp < TP; ++tp) dst.p[tp] = NN_LOAD_A(reinterpret_cast<const d2*>(p + toff[tp]));
+    if (ODD) dst.s = NN_LOAD_A(p + toff1);
   };
   struct SFrag {
     double f[NTA];   // full tiles: column nt*16 + c16
