@@ -402,8 +402,23 @@ def test_kle_projector_class(ctx):
     assert np.linalg.norm(V2.T @ V2 - np.eye(r)) / np.sqrt(r) < 1e-10             # :183-196
     CV = Cm @ V2
     assert np.linalg.norm(CV - V2 * d2) / np.linalg.norm(CV) < 1e-4               # :198-217
-    with pytest.raises(NotImplementedError):
-        kle.construct_input_subspace("prior")
+    # orthogonality='prior' (KLESubspaceConstructorSLEPc, KLEProjector.py:285-334): the eigenpairs of A v = mu M v scaled to
+    # decoder = v / mu, eigenvalues 1 / mu^2, encoder = R decoder = the dominant eigenpairs of M u = lambda R u, u^T R u = 1;
+    # here by the randomized generalized solve instead of Krylov-Schur
+    import scipy.linalg as sla
+    d3, dec3, enc3 = kle.construct_input_subspace("prior")
+    V3, E3 = dec3.to_dense(), enc3.to_dense()
+    assert kle.M_orthogonal is False and kle.R_orthogonal is True
+    # (R has entries of 2e6 and a condition number of ~1e9: V^T R V is orthonormal to eps * cond, not to 1e-10 as with B = M)
+    assert np.linalg.norm(V3.T @ (Rm @ V3) - np.eye(r)) / np.sqrt(r) < 1e-7
+    assert rel(E3, Rm @ V3) < 1e-10
+    lam = sla.eigh(M.toarray(), Rm, eigvals_only=True)[::-1][:r]
+    assert np.all(np.diff(d3) <= 0) and np.max(np.abs(d3[:10] - lam[:10]) / lam[:10]) < 1e-6
+    CMV3 = Cm @ (M @ V3)                                         # M u = lambda R u  <=>  C M u = lambda u
+    res3 = np.linalg.norm(CMV3 - V3 * d3) / np.linalg.norm(CMV3)
+    assert res3 < 1e-4, res3
+    mu = 1.0 / np.sqrt(d3)                                       # the reference's sqrt-precision eigenvalues: (v = mu u)^T M v = 1
+    assert np.abs(np.diag((V3 * mu).T @ (M @ (V3 * mu))) - 1.0).max() < 1e-3
     # projection-error test of the basis (KLEProjector.py:202-282) on prior-like samples x = C^{1/2}-ish noise
     kle.construct_input_subspace("mass")
     Xs = (np.linalg.cholesky(Cm + 1e-12 * np.eye(N)) @ np.random.default_rng(3).standard_normal((N, 12))).T
