@@ -187,8 +187,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
   stage_load(i_begin);
   stage_store(lds, i_begin);
   __syncthreads();
-  // register ring of 4 k-steps for the streamed operand (prefetch distance 3), ping-pong LDS fragments.  (A ring of 8 = a whole stage
-  // ahead was measured in round 4: +1.6 % on config 4's <6,5,4,3> without a spill, profiles/r04k_nt_ab.txt -- latency is not the limit.)
+  // register ring of 4 k-steps for the streamed operand (prefetch distance 3), ping-pong LDS fragments
   AFrag a0, a1, a2, a3;
   SFrag sf0, sf1;
   load_a(a0, i_begin);
