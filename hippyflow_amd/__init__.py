@@ -10,7 +10,8 @@ from .collectives import (CollectiveOperator, MatrixMultCollectiveOperator, Mult
                           MultipleSerialPDEsCollective, NativeCollective, NullCollective, TorchCollective,
                           checkFunctionSpaceConsistentPartitioning, checkMeshConsistentPartitioning, splitCommunicators)
 from .hostvec import ADJOINT, CONTROL, PARAMETER, STATE, HostMultiVector, HostVector, new_host_vector, set_host_vector_factory
-from .multivector import MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector, ingest_stream
+from .multivector import (MatMvMult, MatMvTranspmult, MultiVector, MvDSmatMult, Vector, dense_to_mv_local, ingest_stream, mv_to_dense,
+                          mv_to_dense_local)
 from .operators import (ComposedOperator, CsrOperator, CsrPCGSolver, DenseJacobianOperator, DeviceOperator, HostCallbackOperator,
                         LowRankOperator, LowRankRectangularOperator, MassPreconditionedCovarianceOperator,
                         JJT, JTJ, Jacobian, MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableControlJacobian,
@@ -27,7 +28,6 @@ from .datasets import (derivative_dataset, jacobian_svds, jacobian_times_input_b
                        jacobian_transpose_times_output_basis, save_JPsi_data, save_JstarPhi_data, save_Jsvd_data,
                        save_mq_data)
 from .datagen import DataGenerator, compress_dataset, data_generator_settings
-from .utilities import dense_to_mv_local, mv_to_dense, mv_to_dense_local
 
 __version__ = "0.1.0"
 

@@ -28,12 +28,11 @@ import numpy as np
 from . import _lib as L
 from .collectives import CollectiveOperator, MatrixMultCollectiveOperator, NullCollective
 from . import hostvec as H
-from .multivector import ingest_stream, MatMvMult, MultiVector
+from .multivector import ingest_stream, MatMvMult, MultiVector, mv_to_dense
 from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableJacobian, SeriallySampledJacobianOperator,
                         SnapshotGramOperator, Solver2Operator, as_device_operator)
 from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
-from .utilities import mv_to_dense
 
 
 class ParameterList(object):
