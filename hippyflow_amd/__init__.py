@@ -23,7 +23,7 @@ from .projectors import (ActiveSubspaceParameterList, ActiveSubspaceProjector, B
                          ParameterList, PODParameterList, PODProjector, PODProjectorFromData, weighted_l2_norm_vector)
 from .randomized import accuracyEnhancedSVD, doublePass, doublePassG, parRandom, svd_small, sym_eig_small
 from .errors import input_output_error_test, projection_error_test
-from .io_utils import get_projectors, modify_projectors
+from .io_utils import get_projectors, modify_projectors, spectrum_plot
 from .datasets import (derivative_dataset, jacobian_svds, jacobian_times_input_basis,
                        jacobian_transpose_times_output_basis, save_JPsi_data, save_JstarPhi_data, save_Jsvd_data,
                        save_mq_data)

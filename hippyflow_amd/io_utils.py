@@ -82,3 +82,31 @@ def modify_projectors(projectors, input_subspace, output_subspace, seed=0):
         output_projector = _orthonormalize(projectors['POD'] if output_subspace == 'pod' else projectors['AS_output'])
         output_projector = output_projector / np.linalg.norm(output_projector)
     return input_projector, output_projector
+
+
+def spectrum_plot(lambdas, axis_label=('i', r'$\lambda$', 'Spectrum'), ylims=None, out_name=None):
+    """The eigenvalue plot the reference's projectors leave next to their arrays (utilities/plotting.py:18-50: the values
+    above 1e-10 on a logarithmic axis, saved to ``out_name``).  Host-side cosmetics: drawn with matplotlib when it is
+    installed (headless ``Agg`` canvas), silently skipped -- ``None`` returned -- when it is not."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+    except Exception:          # noqa: BLE001 -- no matplotlib / no usable backend: the arrays are what matters
+        return None
+    lam = np.asarray(lambdas, dtype=np.float64)
+    lam = lam[lam > 1e-10]
+    fig, ax = plt.subplots(figsize=(10, 5))
+    ax.semilogy(np.arange(lam.size), lam)
+    ax.set_xlabel(axis_label[0], fontsize=30)
+    ax.set_ylabel(axis_label[1], fontsize=35)
+    ax.set_title(axis_label[2], fontsize=35)
+    if ylims is not None:
+        ax.set_ylim(ylims)
+    ax.tick_params(axis='both', which='both', labelsize=25)
+    for tick in ax.get_yticklabels():
+        tick.set_rotation(90)
+    if out_name is not None:
+        fig.savefig(out_name, bbox_inches='tight')
+    plt.close(fig)
+    return fig

@@ -135,6 +135,16 @@ def _save(directory, name, array):
     np.save(directory + name, array)
 
 
+def _plot_spectrum(directory, name, d, title):
+    """``<output_directory><name>.pdf`` next to the saved arrays, as the reference leaves it (activeSubspaceProjector.py:482-485,
+    KLEProjector.py:194-197, PODProjector.py:386-389); a no-op without matplotlib."""
+    from .io_utils import spectrum_plot
+    try:
+        spectrum_plot(d, axis_label=['i', r'$\lambda_i$', title], out_name=directory + name + '.pdf')
+    except Exception:          # noqa: BLE001 -- a plot must never fail a solve (fonts, mathtext, read-only directories ...)
+        pass
+
+
 def _draw_omega(N, nvec, collective, ctx, stored=None):
     """Probe block.  The reference draws on rank 0 and broadcasts k vectors of length N
     (activeSubspaceProjector.py:433-443,536-551).  Here rank 0's SHARED generator state (seed, shared stream) -- 16 bytes
@@ -430,12 +440,17 @@ class ActiveSubspaceProjector:
                 assert type(name_suffix) is str
                 name += name_suffix
             out = self.parameters['output_directory']
+            suffix, r_str = self.parameters['plot_label_suffix'], str(self.parameters['rank'])
             if operation == 'JTJ':
                 _save(out, name + self.parameters['input_decoder_name'], mv_to_dense(self.V_GN))
                 _save(out, name + '_d_GN', self.d_GN)
+                _plot_spectrum(out, name + '_input_eigenvalues_' + r_str, self.d_GN,
+                               r'Eigenvalues of $\mathbb{E}_{\nu}[C{\nabla} q^T {\nabla} q]$' + suffix)          # :482-485
             else:
                 _save(out, name + self.parameters['output_decoder_name'], mv_to_dense(self.U_NG))
                 _save(out, name + '_d_NG', self.d_NG)
+                _plot_spectrum(out, name + '_output_eigenvalues_' + r_str, self.d_NG,
+                               r'Eigenvalues of $\mathbb{E}_{\nu}[{\nabla} q {\nabla} q^T]$' + suffix)           # :668-671
         return result
 
     # ---- consumers of the subspaces --------------------------------------------------
@@ -663,6 +678,8 @@ class KLEProjector:
         if _is_root(self.collective) and self.parameters['save_and_plot'] and self.parameters['output_directory'] is not None:
             _save(self.parameters['output_directory'], self.parameters['input_decoder_name'], mv_to_dense(self.V_KLE))
             _save(self.parameters['output_directory'], 'KLE_d', self.d_KLE)
+            _plot_spectrum(self.parameters['output_directory'], 'KLE_eigenvalues_' + str(self.parameters['rank']), self.d_KLE,
+                           r'Eigenvalues of $C$' + self.parameters['plot_label_suffix'])                              # :194-197
         return self.d_KLE, kle_decoder, kle_encoder
 
 
@@ -805,6 +822,8 @@ class PODProjector:
         if _is_root(self.collective) and self.parameters['output_directory'] is not None:
             _save(self.parameters['output_directory'], 'POD_projector', mv_to_dense(self.U_MV))
             _save(self.parameters['output_directory'], 'POD_d', self.d)
+            _plot_spectrum(self.parameters['output_directory'], 'POD_eigenvalues_' + str(self.parameters['rank']), self.d,
+                           r'Eigenvalues of $\mathbb{E}_{\nu}[qq^T]$' + self.parameters['plot_label_suffix'])          # :386-389
 
     def test_output_errors(self, ranks=[None], cut_off=1e-10, samples=None):
         """Projection-error test on the output (PODProjector.py:392-478): relative error of projecting observable

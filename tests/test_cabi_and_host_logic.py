@@ -147,3 +147,19 @@ def test_prior_solver_process_pool_equals_in_process_solver():
     pool.Rsolver.close()
     if os.path.isdir("/dev/shm"):
         assert set(os.listdir("/dev/shm")) <= before
+
+
+def test_spectrum_plot_is_optional_cosmetics(tmp_path):
+    """utilities/plotting.py:18-50: eigenvalues above 1e-10 on a logarithmic axis, saved where the caller says; without matplotlib
+    the call is a no-op (the arrays are what matters)."""
+    import numpy as np
+    import hippyflow_amd as hf
+    out = os.path.join(str(tmp_path), "spectrum.pdf")
+    fig = hf.spectrum_plot(np.array([1.0, 1e-3, 1e-6, 1e-12, 0.0, -1.0]), axis_label=["i", r"$\lambda_i$", r"Eigenvalues of $C$"], out_name=out)
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        assert fig is None and not os.path.exists(out)
+        return
+    assert fig is not None and os.path.getsize(out) > 1000
+    assert len(fig.axes[0].lines[0].get_ydata()) == 3              # the entries <= 1e-10 are dropped, as in the reference

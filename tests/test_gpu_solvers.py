@@ -355,6 +355,11 @@ def test_pod_projector_class(ctx, tmp_path):
     assert saved.shape == (2500, 20)
     np.testing.assert_array_equal(saved, hf.mv_to_dense(pod.U_MV))
     np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "POD_d.npy")), pod.d)
+    try:                                               # the spectrum plot the reference leaves beside them (PODProjector.py:386-389)
+        import matplotlib  # noqa: F401
+        assert os.path.getsize(os.path.join(str(tmp_path), "POD_eigenvalues_20.pdf")) > 1000
+    except ImportError:
+        pass
 
 
 def test_projector_defaults_are_per_instance(ctx):
