@@ -50,6 +50,12 @@ _HOST_SIDE_NAMES = {
     "DomainRestrictedOperator": "hippyflow.modeling.observable",
     "hippylibModelLinearStateObservable": "hippyflow.modeling.observable",
     "read_serial_write_parallel_mesh": "hippyflow.utilities.mesh_utils",
+    # plotting helpers of `from hippyflow import *` (spectrum_plot has its own, matplotlib-only counterpart in io_utils)
+    "generic_semilogy_plot": "hippyflow.utilities.plotting",
+    "plot_accs_vs_data": "hippyflow.utilities.plotting",
+    "plot_singular_values_with_std": "hippyflow.utilities.plotting",
+    "subspace_angle_video": "hippyflow.utilities.plotting",
+    "plot_eigenvector": "hippyflow.utilities.plot_eigenvectors",
 }
 
 
