@@ -110,3 +110,28 @@ def spectrum_plot(lambdas, axis_label=('i', r'$\lambda$', 'Spectrum'), ylims=Non
         fig.savefig(out_name, bbox_inches='tight')
     plt.close(fig)
     return fig
+
+
+def singular_values_plot(s, s_std, title='Average singular values with std', outname='out_plot.pdf'):
+    """Mean singular values of the per-sample Jacobians with a band of one standard deviation, the PDF the reference writes next
+    to ``J_on_proc*.npz`` (utilities/plotting.py:135-160, called at activeSubspaceProjector.py:880-883, 898-901).  Optional
+    cosmetics like ``spectrum_plot``: ``None`` without matplotlib."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+    except Exception:          # noqa: BLE001
+        return None
+    s, s_std = np.asarray(s, dtype=np.float64), np.asarray(s_std, dtype=np.float64)
+    fig, ax = plt.subplots()
+    idx = np.arange(1, s.size + 1)
+    ax.semilogy(idx, s)
+    ax.fill_between(idx, s - s_std, s + s_std, alpha=0.2)
+    ax.set_xlabel('i', fontsize=20)
+    ax.set_ylabel(r'$\sigma_i$', fontsize=20)
+    ax.set_title(title, fontsize=20)
+    ax.grid()
+    fig.tight_layout()
+    fig.savefig(outname)
+    plt.close(fig)
+    return fig

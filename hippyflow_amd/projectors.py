@@ -145,6 +145,15 @@ def _plot_spectrum(directory, name, d, title):
         pass
 
 
+def _plot_singular_values(path, sigmas):
+    from .io_utils import singular_values_plot
+    try:
+        sigmas = np.asarray(sigmas)
+        singular_values_plot(np.mean(sigmas, axis=0), np.std(sigmas, axis=0), outname=path)
+    except Exception:          # noqa: BLE001 -- cosmetics never fail a run
+        pass
+
+
 def _draw_omega(N, nvec, collective, ctx, stored=None):
     """Probe block.  The reference draws on rank 0 and broadcasts k vectors of length N
     (activeSubspaceProjector.py:433-443,536-551).  Here rank 0's SHARED generator state (seed, shared stream) -- 16 bytes
@@ -536,6 +545,7 @@ class ActiveSubspaceProjector:
             if save:
                 np.savez_compressed(out + 'J_on_proc' + str(proc_id) + '.npz', U_data=results[0][0], sigma_data=results[0][1],
                                     V_data=results[0][2])                                        # :877-878
+                _plot_singular_values(out + 'jacobian_singular_values_' + str(parameter_rank) + '.pdf', results[0][1])   # :880-883
         if control_jacobian:
             block, ndata, q = as_block(control_data)
             wanted = self.parameters['control_jacobian_rank']
@@ -544,6 +554,7 @@ class ActiveSubspaceProjector:
             if save:
                 np.savez_compressed(out + 'Jz_on_proc' + str(proc_id) + '.npz', Uz_data=results[1][0], sigmaz_data=results[1][1],
                                     Vz_data=results[1][2])                                       # :896-897
+                _plot_singular_values(out + 'control_jacobian_singular_values_' + str(control_rank) + '.pdf', results[1][1])   # :898-901
         if save:
             if mq_pairs is None and hasattr(obs, 'mq_data'):
                 mq_pairs = obs.mq_data(ndata)

@@ -329,6 +329,11 @@ def test_training_data_and_low_rank_jacobians_from_a_reference_observable(ctx, g
     mq = np.load(out + "mq_on_proc0.npz")
     jf = np.load(out + "J_on_proc0.npz")
     assert sorted(jf.files) == ["U_data", "V_data", "sigma_data"]
+    try:                                       # the plot the reference leaves beside it (activeSubspaceProjector.py:880-883)
+        import matplotlib  # noqa: F401
+        assert os.path.getsize(out + "jacobian_singular_values_%d.pdf" % q) > 1000
+    except ImportError:
+        pass
     u = obs.generate_vector(hf.STATE)
     m = obs.generate_vector(hf.PARAMETER)
     for i in range(4):
