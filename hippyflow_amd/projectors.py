@@ -269,6 +269,8 @@ class ActiveSubspaceProjector:
             prior.init_vector(self.noise, "noise")
         self.ms = None            # linearisation points: given by the caller (ms_given) or kept from the batched draw
         self.zs = None
+        self.qs = None            # observables at the stored samples (batched route)
+        self._zs_kept = None
         self.Js = None            # (block, ndata, q) once materialised
         self.d_GN = None
         self.V_GN = None
@@ -294,14 +296,19 @@ class ActiveSubspaceProjector:
                                                   ms=self.ms if self.parameters['ms_given'] else None, zs=self.zs,
                                                   jacobian_factory=ObservableJacobian)
         J = None
-        kept = []
+        kept, qs, zs = [], [], []
         for _ in sampler._points():
             J = J or ObservableJacobian(self.observable)
             if not self.parameters['ms_given']:
                 kept.append(sampler.m.get_local())
+            qs.append(self.observable.evalu(sampler.u).get_local())       # q_i = B u_i of the stored sample (:989)
+            if self.control_distribution is not None and getattr(sampler, 'z', None) is not None:
+                zs.append(sampler.z.get_local())
             yield J.rows()
         if kept:
             self.ms = kept
+        self.qs = qs
+        self._zs_kept = zs or None
 
     def _initialize_batched_samples(self):
         """Materialise this rank's Jacobians in HBM (counterpart of :347-397)."""
@@ -471,7 +478,47 @@ class ActiveSubspaceProjector:
         observable speaking the reference's protocol is driven through the reference's loop; otherwise the Jacobians come
         from ``observable.jacobian_data(n)`` with ``n = jacobian_data_per_process`` and the samples from
         ``observable.mq_data(n)`` when it exists.  Returns (U_data, sigma_data, V_data)."""
+        if not self.parameters['serialized_sampling']:
+            return self._low_rank_jacobians_batched(check_for_data)                                      # :677-678
         return self._low_rank_jacobians(compress_files, parameter_jacobian=True, control_jacobian=False)[0]
+
+    def _low_rank_jacobians_batched(self, check_for_data=True):
+        """The batched form (activeSubspaceProjector.py:906-1045): the STORED samples of this rank (``samples_per_process`` of them,
+        the ones the subspaces were built from), rank ``min(rank, q, N)``, written as whole arrays into
+        ``<output_directory>jacobian_data/``: ``ms_on_proc_{id}.npy``, ``qs_on_proc_{id}.npy`` (``zs_...`` for a control problem),
+        ``Us_on_proc_{id}.npy``, ``sigmas_on_proc_{id}.npy``, ``Vs_on_proc_{id}.npy``; existing complete files are returned as they
+        are when ``check_for_data`` (the reference resumes sample by sample; here the batch is one device call)."""
+        from .datasets import jacobian_svds
+        if self.Js is None:
+            self._initialize_batched_samples()
+        block, ndata, q = self.Js
+        rank = min(self.parameters['rank'], q, block.size())                                            # :931
+        out = self.parameters['output_directory']
+        proc_id = int(self.collective.rank())
+        folder = None if out is None else out + 'jacobian_data/'
+        names = ('Us', 'sigmas', 'Vs')
+        if folder is not None and check_for_data and all(os.path.isfile(folder + n + '_on_proc_' + str(proc_id) + '.npy') for n in names):
+            got = tuple(np.load(folder + n + '_on_proc_' + str(proc_id) + '.npy') for n in names)
+            if got[0].shape == (ndata, q, rank) and got[1].shape == (ndata, rank):
+                return got
+        U, sigma, V = jacobian_svds((block, ndata, q), rank)
+        if folder is not None:
+            os.makedirs(folder, exist_ok=True)
+            ms, qs = self.ms, self.qs
+            if (ms is None or qs is None) and hasattr(self.observable, 'mq_data'):
+                ms, qs = self.observable.mq_data(ndata)
+            if ms is not None and qs is not None:
+                np.save(folder + 'ms_on_proc_' + str(proc_id) + '.npy', np.asarray(ms))                  # :994-995
+                np.save(folder + 'qs_on_proc_' + str(proc_id) + '.npy', np.asarray(qs))
+            zs = self._zs_kept if self._zs_kept is not None else self.zs
+            if self.control_distribution is not None and zs is not None and zs[0] is not None:
+                np.save(folder + 'zs_on_proc_' + str(proc_id) + '.npy',
+                        np.asarray([z.get_local() if hasattr(z, 'get_local') else z for z in zs]))       # :998
+            np.save(folder + 'Us_on_proc_' + str(proc_id) + '.npy', U)                                   # :1033-1035
+            np.save(folder + 'sigmas_on_proc_' + str(proc_id) + '.npy', sigma)
+            np.save(folder + 'Vs_on_proc_' + str(proc_id) + '.npy', V)
+            _plot_singular_values(out + 'jacobian_singular_values_' + str(rank) + '.pdf', sigma)          # :1041-1042
+        return U, sigma, V
 
     def construct_low_rank_control_Jacobians(self, check_for_data=True, compress_files=True):
         """The same for the Jacobian with respect to the CONTROL variable (activeSubspaceProjector.py:682-688, serialized

@@ -345,6 +345,27 @@ def test_training_data_and_low_rank_jacobians_from_a_reference_observable(ctx, g
         assert rel((U[i] * sig[i]) @ V[i].T, Jd) < 1e-9
         np.testing.assert_allclose(mq["q_data"][i], obs.B.A @ u.get_local(), rtol=1e-12)
 
+    # the batched form (activeSubspaceProjector.py:906-1045): the samples the subspace was built from, whole arrays under jacobian_data/
+    obs, prior = setup(g)
+    asp = hf.ActiveSubspaceParameterList()
+    asp['serialized_sampling'], asp['samples_per_process'], asp['rank'], asp['oversampling'] = False, 3, 4, 2
+    asp['output_directory'], asp['verbose'], asp['save_and_plot'] = out, False, False
+    AS = hf.ActiveSubspaceProjector(obs, prior, parameters=asp)
+    AS.construct_input_subspace(prior_preconditioned=False)
+    Ub, sb, Vb = AS.construct_low_rank_Jacobians()
+    r = min(4, q, n)
+    assert Ub.shape == (3, q, r) and sb.shape == (3, r) and Vb.shape == (3, n, r)
+    ms_b, qs_b = np.load(out + "jacobian_data/ms_on_proc_0.npy"), np.load(out + "jacobian_data/qs_on_proc_0.npy")
+    assert ms_b.shape == (3, n) and qs_b.shape == (3, q)
+    np.testing.assert_array_equal(np.load(out + "jacobian_data/sigmas_on_proc_0.npy"), sb)
+    for i in range(3):                                  # (m_i, q_i, J_i) belong together: the stored linearisation points
+        m.set_local(ms_b[i])
+        obs.solveFwd(u, [u, m, None])
+        obs.setLinearizationPoint([u, m, None])
+        np.testing.assert_allclose(qs_b[i], obs.B.A @ u.get_local(), rtol=1e-12)
+        Jd = obs.problem.jacobian_dense(obs.B.A)
+        assert rel(Ub[i].T @ Jd @ Vb[i], np.diag(sb[i])) < 1e-9 and np.all(sb[i] <= np.linalg.svd(Jd, compute_uv=False)[:r] * (1 + 1e-12))
+
 
 def test_control_problem_low_rank_jacobians(ctx, tmp_path):
     """A control problem (state equation with a control z on its right-hand side) driven through the reference's protocol:

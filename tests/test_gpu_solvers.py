@@ -980,6 +980,18 @@ def test_active_subspace_error_tests_and_low_rank_jacobians(ctx, tmp_path):
         assert abs(avg_in[i] - ref) < 1e-10 * max(ref, 1.0)
     only_in = asp.test_errors(ranks=[6], samples=Xs)
     assert len(only_in) == 2
+    # batched sampling (this projector): the STORED samples, rank = min(rank, q, N), whole arrays under jacobian_data/ (:906-1045)
+    Ub, sb, Vb = asp.construct_low_rank_Jacobians()
+    assert Ub.shape == (ns, q, 12) and sb.shape == (ns, 12) and Vb.shape == (ns, N, 12)
+    jd = str(tmp_path) + "/jacobian_data/"
+    for stem, arr in (("Us", Ub), ("sigmas", sb), ("Vs", Vb), ("ms", m_data), ("qs", q_data)):
+        np.testing.assert_array_equal(np.load(jd + stem + "_on_proc_0.npy"), arr)
+    np.testing.assert_allclose(sb[0][:3], np.linalg.svd(J[0], compute_uv=False)[:3], rtol=1e-6)
+    again = asp.construct_low_rank_Jacobians()                                 # check_for_data: complete files are returned as they are
+    np.testing.assert_array_equal(again[1], sb)
+    assert not os.path.exists(str(tmp_path) + "/J_on_proc0.npz")
+    # serialized sampling: fresh samples, rank = min(jacobian_rank, q, N), J_on_proc / mq_on_proc archives (:690-900)
+    params["serialized_sampling"] = True
     U_data, sigma, V_data = asp.construct_low_rank_Jacobians()
     assert U_data.shape == (ns, q, 6) and sigma.shape == (ns, 6) and V_data.shape == (ns, N, 6)
     f = np.load(str(tmp_path) + "/J_on_proc0.npz")
