@@ -66,6 +66,13 @@ def parse_args():
                          "the sharded path on a 1-GPU box")
     ap.add_argument("--dist-single", action="store_true",
                     help="exercise the multi-GPU code path (native communicator, all-reduce inside the fused solve) with one rank")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline workload: skip the extra evidence lines (kernel point, configs 3 and 2, the 64-sample "
+                         "shard step) that a default --gpus 1 run of config 4 appends as extra keys (A/B runs, profiling)")
+    ap.add_argument("--kernel-point", action="store_true",
+                    help="north-star kernel point instead of a solve: G = X^T Omega at N = 1e6, k = 138, n in {8 ... 2048}; one JSON line")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick"],
+                    help="quick: the host legs at all threads and at one socket's cores only (no single-thread legs)")
     return ap.parse_args()
 
 
@@ -214,6 +221,27 @@ def _cpu_model():
     return "unknown"
 
 
+def _cpu_topology():
+    """Hardware threads, physical cores and sockets of this host from /proc/cpuinfo ((physical id, core id) pairs)."""
+    cores, sockets = set(), set()
+    phys = core = None
+    try:
+        for line in list(open("/proc/cpuinfo")) + [""]:
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                    sockets.add(phys)
+                phys = core = None
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    return {"threads": threads, "physical_cores": len(cores) or threads, "sockets": len(sockets) or 1}
+
+
 def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
     """The reference's CPU path on the GPU box's host cores, on bounded samples scaled to the full workload (every
     scaling factor is stated).  Two legs, each at all threads and at one thread:
@@ -223,19 +251,27 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
                          numpy eigh, MvDSmatMult;
       blas3           -- the best-effort CPU form: block applies as threaded GEMMs, Householder QR."""
     from threadpoolctl import threadpool_limits
-    cores = os.cpu_count() or 1
+    topo = _cpu_topology()
+    cores = topo["threads"]
+    # BLAS thread counts: every hardware thread (what a default numpy does), the physical cores of ONE socket (level-1/2
+    # style loops like the reference's column-by-column MGS lose to their own fork/join and cross-socket traffic beyond that:
+    # 0.81 s at 256 threads against 0.027 s at one, BENCH_r04), and one thread.  The best of each leg is reported.
+    per_socket = max(1, min(cores, topo["physical_cores"] // max(1, topo["sockets"])))
+    settings = [("threads_all", cores), ("threads_one_socket_cores", per_socket)]
+    if args.cpu_baseline == "full":
+        settings.append(("threads_1", 1))
     k = Omega_host.shape[1]
     legs = {"reference_style": {}, "blas3": {}}
     notes = {}
-    for label, limit in (("threads_all", cores), ("threads_1", 1)):
+    for label, limit in settings:
         with threadpool_limits(limits=limit):
             # ------------------------------------------------------------ reference-style leg, on a reduced problem
-            N_s = max(1000, N // 8)
-            k_s = 4
+            N_s = max(1000, N // 4)
+            k_s = min(8, k)
             W_s = np.ascontiguousarray(Omega_host[:N_s, :k_s])
             Z = hp_o.as_block(Omega_host[:N_s])
             if args.workload == "as":
-                ns_s = max(1, min(4, wl.J.nvec() // wl.q))
+                ns_s = max(1, min(8, wl.J.nvec() // wl.q))
                 J_s = wl.J.view(0, ns_s * wl.q).to_vectors()[:, :N_s].reshape(ns_s, wl.q, N_s).copy()
                 op = hf_o.MeanJTJOperator(J_s)
                 units, units_s = wl.ns_total, ns_s
@@ -317,10 +353,18 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
             t_b = 2.0 * t_apply + extra + t_eig + t_back
             legs["blas3"][label] = {"seconds_full_estimate": t_b, "value": N * r / t_b / 1e9}
             notes["blas3"] = note_b + "; eigh and U = Q V at full size"
-    best = legs["blas3"]["threads_all"]
-    return {"value": best["value"], "unit": "GDoF*rank/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "sample": "blas3 leg at all threads: " + notes["blas3"], "seconds_full_estimate": best["seconds_full_estimate"],
-            "reference_style": dict(legs["reference_style"], sample=notes["reference_style"]),
+    thread_count = dict(settings)
+    best_label = max(legs["blas3"], key=lambda lb: legs["blas3"][lb]["value"])
+    best = legs["blas3"][best_label]
+    best_ref_label = max(legs["reference_style"], key=lambda lb: legs["reference_style"][lb]["value"])
+    return {"value": best["value"], "unit": "GDoF*rank/s", "cores": thread_count[best_label], "kind": "port", "cpu_model": _cpu_model(),
+            "threads": topo["threads"], "physical_cores": topo["physical_cores"], "sockets": topo["sockets"],
+            "thread_settings": thread_count, "best_setting": best_label,
+            "sample": "blas3 leg at %s = %d BLAS threads (the best of %s): %s" % (best_label, thread_count[best_label], ", ".join(thread_count), notes["blas3"]),
+            "seconds_full_estimate": best["seconds_full_estimate"],
+            "reference_style": dict(legs["reference_style"], sample=notes["reference_style"], best_setting=best_ref_label,
+                                    value=legs["reference_style"][best_ref_label]["value"],
+                                    seconds_full_estimate=legs["reference_style"][best_ref_label]["seconds_full_estimate"]),
             "blas3": dict(legs["blas3"], sample=notes["blas3"])}
 
 
@@ -454,23 +498,193 @@ def ingest_line(args):
     print(json.dumps(out), flush=True)
 
 
+def kernel_point_line(args):
+    """--kernel-point: the north star's kernel point G = X^T Omega (snapshot^T x probe block) at N = 1e6, k = r + p = 138 for
+    several snapshot counts n: achieved algorithmic GB/s against the 8 TB/s HBM roof AND TFLOP/s against the 78.6 TFLOP/s fp64
+    MFMA roof, the binding one named.  Median of five 10-launch batches per variant, best of the two operand
+    orientations / kernels, timed with HIP events on the library's stream (hfmi_bench_tsgemm_tn)."""
+    import ctypes as C
+    import hippyflow_amd as hf
+    from hippyflow_amd import _lib as L
+    hf.Context.default()
+    N, k = (1000000 // (8 if args.quick else 1)), 138
+    W = hf.MultiVector(N, k)
+    hf.parRandom.normal(1.0, W)
+    rows = []
+    for n in (8, 16, 32, 48, 64, 96, 138, 512, 2048):
+        X = hf.MultiVector(N, n)
+        hf.parRandom.normal(1.0, X)
+        best = None
+        for ss in ((1, 0) if n <= 160 else (0,)):     # 1: the skinny kernel where applicable (the default), 0: force tsgemm_tn
+            L.call("hfmi_tuning_set", b"ss", ss)
+            for orient in ("X^T W", "(W^T X)^T"):
+                A, B = (X, W) if orient == "X^T W" else (W, X)
+                reps = []
+                for _ in range(5):
+                    ms = C.c_double(0)
+                    L.call("hfmi_bench_tsgemm_tn", A.handle, B.handle, 0, 10, None, C.byref(ms))
+                    reps.append(ms.value)
+                t_med = float(np.median(reps))
+                if best is None or t_med < best[1]:
+                    best = (orient + (" [ss]" if ss and n <= 160 else " [tn]"), t_med)
+        L.call("hfmi_tuning_set", b"ss", 1)
+        ts = best[1] * 1e-3
+        by, fl = 8.0 * (N * n + N * k + n * k), 2.0 * N * n * k
+        ai = fl / by
+        bound = "mfma" if ai > FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9) else "hbm"
+        rows.append({"n": n, "kernel": best[0], "ms": best[1], "hbm_frac": by / ts / (HBM_PEAK_GBS * 1e9),
+                     "mfma_frac": fl / ts / (FP64_MFMA_PEAK_TFLOPS * 1e12), "bound": bound,
+                     "frac": (fl / ts / (FP64_MFMA_PEAK_TFLOPS * 1e12)) if bound == "mfma" else by / ts / (HBM_PEAK_GBS * 1e9)})
+        del X
+    print(json.dumps({"kernel_point": {"N": N, "k": k, "rows": rows, "build_tag": hf.build_tag(),
+                                       "peaks": {"hbm_gbs": HBM_PEAK_GBS, "fp64_mfma_tflops": FP64_MFMA_PEAK_TFLOPS}}}), flush=True)
+
+
+def _compact(line):
+    """What an extra workload contributes to the headline line: time, dominant kernel against its roof, parity, a host baseline."""
+    out = {k: line.get(k) for k in ("value", "unit", "ms_per_step", "median_ms_per_step", "literal_T_ms_per_step", "steps", "warmup")}
+    out["workload"] = (line.get("config") or {}).get("workload")
+    rf = line.get("roofline") or {}
+    out["roofline"] = {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic")}
+    out["parity"] = {k: v for k, v in (line.get("parity") or {}).items() if k not in ("note", "oracle_form")}
+    out["phases_ms_per_step"] = line.get("phases_ms_per_step")
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "kind", "cores", "threads", "physical_cores", "sockets",
+                                                       "best_setting", "seconds_full_estimate", "sample")}
+        out["cpu_baseline"]["reference_style_value"] = (cb.get("reference_style") or {}).get("value")
+    comm = line.get("communicator") or {}
+    if comm.get("ranks"):
+        out["communicator"] = comm
+    return out
+
+
+def run_extras(args):
+    """The rest of the evidence set, appended to the driver's one default run: each extra is a CHILD
+    process of this one (a fresh interpreter started with subprocess: nothing is re-exec'ed; the headline workload has been
+    freed), bounded by its own time-out, so that a failure or a hang there can never cost the headline line.  Budget: about
+    90 s of wall clock in total."""
+    import subprocess
+    q = ["--quick"] if args.quick else []
+    jobs = [("kernel_point", ["--kernel-point"] + q, 60),
+            ("config3", ["--workload", "pod", "--steps", "5", "--warmup", "2", "--cpu-baseline", "quick"] + q, 120),
+            ("config2", ["--workload", "kle", "--steps", "5", "--warmup", "2", "--cpu-baseline", "quick"] + q, 180),
+            ("shard64", ["--samples-total", "64", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90),
+            ("shard64_rccl_1rank", ["--samples-total", "64", "--dist-single", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90)]
+    extras, seconds = {}, {}
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    for name, argv, limit in jobs:
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--headline-only"] + argv, env=env, stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE, timeout=limit)
+            lines = [ln for ln in res.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+            if res.returncode != 0 or not lines:
+                extras[name] = {"error": "exit code %d" % res.returncode, "stderr_tail": res.stderr.decode("utf-8", "replace")[-600:]}
+            else:
+                line = json.loads(lines[-1])
+                extras[name] = line["kernel_point"] if name == "kernel_point" else _compact(line)
+        except subprocess.TimeoutExpired:
+            extras[name] = {"error": "timed out after %d s" % limit}
+        except Exception as exc:                          # never let an extra cost the headline
+            extras[name] = {"error": repr(exc)}
+        seconds[name] = time.perf_counter() - t0
+    extras["extras_wall_seconds"] = seconds
+    return extras
+
+
+def _error_line(args, message, **more):
+    out = {"metric": "randomized-SVD throughput (GDoF*rank/s)", "value": None, "unit": "GDoF*rank/s", "n_gpus": args.gpus,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": args.workload}, "error": message}
+    out.update(more)
+    return out
+
+
+def spawn_and_report(args):
+    """Plain ``python bench.py --gpus N``: this parent touches no GPU; it starts N fresh child interpreters (one per device,
+    nothing is re-exec'ed), captures their output and prints exactly ONE JSON line: rank 0's on success, otherwise an error
+    line with every rank's exit code, the transport the ranks had agreed on (if they got that far) and the tail of every
+    rank's stderr.  A rank that dies takes its peers down at once; a hang ends at the time-out (HFMI_BENCH_TIMEOUT_S)."""
+    from hippyflow_amd.launch import spawn_ranks
+    report = {}
+    limit = float(os.environ.get("HFMI_BENCH_TIMEOUT_S", "1800"))
+    rc = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=limit, report=report)
+    lines = [ln for ln in report.get("stdout_rank0", "").splitlines() if ln.startswith("{")]
+    for rnk, tail in sorted(report.get("stderr_tail", {}).items()):
+        if tail and (rc != 0 or rnk == "0"):
+            sys.stderr.write("---- rank %s stderr (tail) ----\n%s\n" % (rnk, tail))
+    if rc == 0 and lines:
+        print(lines[-1], flush=True)
+        return 0
+    transport = None
+    for tail in report.get("stderr_tail", {}).values():
+        for ln in tail.splitlines():
+            if ln.startswith("[bench] communicator "):
+                try:
+                    transport = json.loads(ln[len("[bench] communicator "):])
+                except ValueError:
+                    pass
+    why = ("timed out after %.0f s" % limit) if report.get("timed_out") else \
+          ("rank %s exited with code %s" % (report.get("first_failed"), (report.get("codes") or [None])[report.get("first_failed") or 0]))
+    if rc == 0:
+        why, rc = "rank 0 printed no JSON line", 1
+    print(json.dumps(_error_line(args, why, rank_exit_codes=report.get("codes"), ranks_stopped_by_launcher=report.get("stopped"),
+                                 communicator=transport or "not reached", launcher_seconds=report.get("seconds"),
+                                 stderr_tail=report.get("stderr_tail"))), flush=True)
+    return rc or 1
+
+
 def main():
     args = parse_args()
     if args.workload == "dipnet":
         return dipnet_line(args)
+    if args.kernel_point:
+        return kernel_point_line(args)
     if args.ingest:
         return ingest_line(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: this parent touches no GPU; it starts N fresh child interpreters (one per
-        # device, nothing is re-exec'ed) and rank 0's JSON line arrives on the inherited stdout
-        from hippyflow_amd.launch import spawn_ranks
-        sys.exit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        sys.exit(spawn_and_report(args))
     # stdout carries exactly ONE JSON line: anything libraries print (e.g. the RCCL version banner) goes to stderr
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    try:
+        out = solve_line(args, world, rank)
+    except BaseException as exc:
+        # under an external launcher (python -m torch.distributed.run) there is no parent of ours to report: rank 0 leaves ONE
+        # JSON line that says what happened, every rank exits non-zero
+        if rank == 0 and not isinstance(exc, KeyboardInterrupt):
+            import traceback
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            print(json.dumps(_error_line(args, "%s: %s" % (type(exc).__name__, exc), traceback=traceback.format_exc()[-1500:])), flush=True)
+            os.dup2(2, 1)
+        if isinstance(exc, SystemExit) and exc.code in (0, None):
+            raise SystemExit(1)
+        raise
+    if out is None:                                  # ranks other than 0
+        return
+    if kernel_extras_wanted(args, world):
+        out.update(run_extras(args))
+        out["extra_keys"] = ["kernel_point", "config3", "config2", "shard64", "shard64_rccl_1rank"]
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                      # whatever the libraries print while shutting down stays off stdout
+
+
+def kernel_extras_wanted(args, world):
+    """The extra evidence lines ride on the driver's default run only: config 4, one GPU, all 512 samples, plain doublePass."""
+    return (world == 1 and not args.headline_only and args.workload == "as" and not args.prior and not args.dist_single
+            and args.samples_total == 512)
+
+
+def solve_line(args, world, rank):
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.transport != "auto":
@@ -485,6 +699,11 @@ def main():
     use_dist = world > 1 or args.dist_single
     if world > 1:
         collective = hf.NativeCollective.from_env(ctx)          # id through $HFMI_COMM_ID_FILE / the launcher's temp file
+        try:                                                    # what the ranks agreed on: the launcher's error line quotes it
+            sys.stderr.write("[bench] communicator %s\n" % json.dumps(dict(collective.describe(), rank=rank)))
+            sys.stderr.flush()
+        except Exception:
+            pass
     elif args.dist_single:
         collective = hf.NativeCollective.from_unique_id(hf.NativeCollective.unique_id(), 1, 0, ctx=ctx)
     else:
@@ -563,10 +782,11 @@ def main():
     if hasattr(collective, "describe"):
         comm_info.update(collective.describe())      # why this transport (RCCL first-contact fallback), PCI bus id of every rank
         comm_info["row_panels_overlapped"] = int(os.environ.get("HFMI_COMM_PANELS", "4"))
+    comm_info["step_ms_max_over_ranks"] = elapsed / args.steps * 1e3
     if use_dist:
         collective.close()                           # collective: every rank leaves the communicator here;
     if rank != 0:                                    # rank 0 goes on alone with the oracle legs
-        return
+        return None
 
     ms_per_step = elapsed / args.steps * 1e3
     value = N * r / (elapsed / args.steps) / 1e9
@@ -677,10 +897,12 @@ def main():
         # rank 0 alone (the other ranks have left the communicator): at N > 1 `wl` is rank 0's shard, the bounded sample is
         # drawn from it and scaled to the whole job exactly as at N = 1
         out["cpu_baseline"] = cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o)
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    print(json.dumps(out), flush=True)
-    os.dup2(2, 1)                      # whatever the libraries print while shutting down stays off stdout
+    # release the workload's HBM before anything else is started on this GPU (the extras are child processes)
+    del wl, op, A, Omega, U, B, Binv
+    import gc
+    gc.collect()
+    ctx.synchronize()
+    return out
 
 
 if __name__ == "__main__":

@@ -216,9 +216,32 @@ class _PinnedArray(np.ndarray):
             self._owner = getattr(obj, "_owner", None)
 
 
+_RANK_VARS = ("RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "PMIX_RANK", "SLURM_PROCID")
+_LOCAL_RANK_VARS = ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID")
+
+
+def _env_int(names, default=0):
+    for name in names:
+        v = os.environ.get(name)
+        if v is not None and v.strip().lstrip("-").isdigit():
+            return int(v)
+    return default
+
+
+def launcher_rank():
+    """World rank of this process as its launcher exported it: torchrun ($RANK), Open MPI, MPICH / Intel MPI (PMI), PMIx, srun.
+    The reference seeds hp.parRandom per MPI rank; mpirun / srun set neither $RANK nor $LOCAL_RANK."""
+    return _env_int(_RANK_VARS)
+
+
+def launcher_local_rank():
+    """Node-local rank (picks the GPU of a one-process-per-GPU run) under the same launchers."""
+    return _env_int(_LOCAL_RANK_VARS)
+
+
 class Context:
     """One per GPU (hfmi_ctx).  `Context.default()` gives the process-wide context of
-    cuda:LOCAL_RANK (one process per GPU)."""
+    cuda:<node-local rank> (one process per GPU; torchrun, mpirun and srun launches alike)."""
     _default = None
 
     def __init__(self, device=0):
@@ -229,7 +252,7 @@ class Context:
     @classmethod
     def default(cls):
         if cls._default is None:
-            cls._default = cls(int(os.environ.get("LOCAL_RANK", "0")) % max(device_count(), 1))
+            cls._default = cls(launcher_local_rank() % max(device_count(), 1))
         return cls._default
 
     def synchronize(self):

@@ -88,11 +88,11 @@ class _Collective:
     name = "collective"
 
     def _split_random(self):
-        """hp.parRandom is seeded per process; here the process-wide generator's PRIVATE streams are keyed by this
-        communicator's rank (the sample-parallel rank), so that the Monte-Carlo draws of the ranks differ while shared
-        draws (probe blocks) stay identical (randomized._ParRandom)."""
+        """hp.parRandom is seeded per process; here the process-wide generator's PRIVATE streams are keyed by the rank of the
+        FIRST communicator the process builds (the world / sample-parallel one), so that the Monte-Carlo draws of the ranks
+        differ while shared draws (probe blocks) stay identical (randomized._ParRandom).  Later collectives do not re-key."""
         from .randomized import parRandom
-        parRandom.split(self.rank())
+        parRandom.split(self.rank(), by_collective=True)
 
     # ---- reductions
     def allReduce(self, v, op):

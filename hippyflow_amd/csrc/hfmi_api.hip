@@ -1046,12 +1046,18 @@ static int cheb_solve(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, bool* han
     HFMI_TRY(launch_cheb_step(ctx, M, B, X[cur], (double*)rs, k, 0.0, 0.0, true));
     HFMI_TRY(launch_rm_colsq(ctx, (const double*)rs, N, k, rr));
     HFMI_TRY(read_back(ctx, bb, (size_t)2 * k, h.data()));
-    bool done = true;
+    bool done = true, diverged = false;
     for (int j = 0; j < k; ++j) {
-      if (!std::isfinite(h[k + j]) || !std::isfinite(h[j]))
-        HFMI_FAIL(HFMI_ERR_NUMERIC, "csr solve: non-finite residual in vector %d after %d Chebyshev steps (matrix not SPD, or non-finite input)", j, steps);
+      if (!std::isfinite(h[j]))
+        HFMI_FAIL(HFMI_ERR_NUMERIC, "csr solve: non-finite right-hand side in vector %d", j);
+      // a residual that is not finite, or larger than the right-hand side it started from, means the polynomial grew: an
+      // eigenvalue of D^-1 A lies outside the bracket (Ritz values of a short CG run from one random vector can miss the top of
+      // the spectrum).  That is a failure of the ESTIMATE, not of the matrix: hand the solve to the block CG, which alone
+      // reports a matrix that is not SPD (advisor r4)
+      if (!std::isfinite(h[k + j]) || h[k + j] > h[j]) diverged = true;
       if (!(h[k + j] <= op->rel_tol * op->rel_tol * h[j])) done = false;
     }
+    if (diverged) break;
     if (done) {
       op->last_iters = steps;
       op->last_method = 1;

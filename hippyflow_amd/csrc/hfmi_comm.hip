@@ -337,7 +337,12 @@ struct p2p_ptrs {
 // scale, and store into the same slice of every rank's buffer.
 __global__ void __launch_bounds__(256) k_p2p_reduce(p2p_ptrs bufs, int nranks, int64_t lo, int64_t hi, double scale, int op,
                                                     const int* __restrict__ dev_err) {
-  if (dev_err && *dev_err) return;      // a poll gave up: the peers' data may be missing, leave the buffers alone
+  // a poll gave up: the peers' data may be missing, leave the buffers alone.  The error word lives in pinned HOST memory: one
+  // thread per workgroup reads it over PCIe and hands it on through LDS (every thread reading it was 256 reads per workgroup)
+  __shared__ int s_err;
+  if (threadIdx.x == 0) s_err = dev_err ? *(volatile const int*)dev_err : 0;
+  __syncthreads();
+  if (s_err) return;
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {

@@ -1,0 +1,1140 @@
+// Whole-GPU symmetric eigensolver for 256 < n <= 4096: the n x n Gram problem of the deterministic POD (la.eigh(G),
+// PODProjector.py:812-833 -- any number of snapshots; dataGenerator.py:278-279 hands it the whole training set), i.e. LAPACK
+// dsyevd's algorithm family spread over the 256 compute units instead of the one-workgroup kernels of hfmi_eig_dc.hip:
+//
+//   1. panel Householder tridiagonalisation (dsytrd / dlatrd's recurrences, panels of EB_NB columns).  A column costs TWO
+//      launches, both over many workgroups and without a host round trip:
+//        k_tri_a  finalises the previous column of W (w = tau (A v - V W^T v - W V^T v) + alpha v; alpha needs v . w', which is
+//                 taken from the identity v^T w' = tau (v^T A v - 2 (V^T v).(W^T v)), so no second device-wide reduction), then
+//                 forms column j of the reduced matrix, a_j - V W_j^T - W V_j^T, and the partial sums of its norm;
+//        k_tri_b  every workgroup derives the reflector scalars from those partial sums (same arithmetic, same bits), keeps v in
+//                 LDS, and its waves take whole columns of the (un-updated) trailing block and of the panel's V and W:
+//                 y = A v, V^T v, W^T v as plain dot products along contiguous columns (A is symmetric: A v = A^T v), each
+//                 summed by ONE wave in a fixed order -- no partial sums cross workgroups except the scalar v . y.
+//      The trailing rank-2 EB_NB update A <- A - V W^T - W V^T runs on the fp64 MFMA (k_dgemm, both products in one pass).
+//   2. divide and conquer on the tridiagonal matrix: the couplings of the upper tree levels are torn first, the 2^Lf leaves of at
+//      most 256 rows are solved by the one-workgroup kernel of hfmi_eig_dc.hip, one leaf per compute unit (k_dc_batch); the upper
+//      merges run level by level over the whole GPU: rank sort + deflation (dlaed2's rules; the rotation scan is the only
+//      sequential piece, in LDS), one WAVE per root of the secular equation, Gu-Eisenstat vector, eigenvectors of the rank-one
+//      problem, and Q <- Q S on the MFMA.
+//   3. back-transformation with compact-WY block reflectors: Gram matrices of the panels (one batched MFMA product), the
+//      triangular factors, Y = V T, then per panel Z <- Z - Y (V^T Z): two MFMA products.
+//   4. eigenvalues sorted on the host (n numbers), eigenvectors permuted + transposed to the row-major output on the device.
+//
+// Every reduction has a fixed order: results are bit-reproducible from run to run.  tests/helpers/eig_blocked_twin.py is the numpy
+// twin (same recurrences, same tearing); tests/test_eig_blocked_twin.py pins it against numpy.linalg.eigh on the CPU.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+#include <vector>
+
+#include "hfmi_dc_common.h"
+
+int launch_dc_leaves(hfmi_ctx* ctx, int n, int Lf, const double* dvec, const double* evec, double* Dout, double* Qbig, int64_t ldq,
+                     int* fail);
+int sym_eig_large_jacobi(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V);
+
+namespace {
+constexpr int EB_NB = 64;          // panel width of the tridiagonalisation and of the block reflectors
+constexpr int EB_MAXN = 4096;
+constexpr int GT = 64;             // k_dgemm: C tile
+constexpr int GK = 16;             // reduction depth of an LDS stage
+constexpr int GLD = 80;            // LDS row stride: = 16 mod 32 doubles, so the four k-rows of an MFMA operand fall into two bank halves
+
+// ------------------------------------------------------------------------------------------------ fp64 MFMA GEMM
+// element (t, k) of an operand tile, t = the operand's OWN index (row of op(A) / column of op(B)), for thread tid, slot u of 4
+template <bool KC>
+__device__ __forceinline__ void tile_idx(int tid, int u, int& t, int& k) {
+  if (KC) {           // the reduction index is the contiguous one in memory
+    k = tid & 15;
+    t = (tid >> 4) + 16 * u;
+  } else {            // the operand's own index is contiguous
+    t = tid & 63;
+    k = (tid >> 6) + 4 * u;
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void tile_load(const double* __restrict__ X, int64_t ld, int t0, int k0, int Tdim, int Kdim, int tid,
+                                          double (&r)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int t, k;
+    tile_idx<KC>(tid, u, t, k);
+    const bool ok = t0 + t < Tdim && k0 + k < Kdim;
+    const int64_t off = KC ? (int64_t)(k0 + k) + (int64_t)(t0 + t) * ld : (int64_t)(t0 + t) + (int64_t)(k0 + k) * ld;
+    r[u] = ok ? X[off] : 0.0;
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void tile_store(double (*s)[GLD], int tid, const double (&r)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int t, k;
+    tile_idx<KC>(tid, u, t, k);
+    s[k][t] = r[u];
+  }
+}
+// C (M x N) = alpha (op(A) op(B) + op(A2) op(B2)) + beta C, everything column-major.  op(A) = A (M x K, lda) or A^T (A is K x M);
+// op(B) = B (K x N) or B^T (B is N x K); the second product (K2 columns, same shapes and leading dimensions) is optional
+// (K2 = 0) -- it makes the symmetric rank-2k update one pass over C.  blockIdx.z = batch index (element strides sA, sB, sC).
+// 64 x 64 tile per workgroup, 4 waves of 32 x 32 (2 x 2 MFMA 16x16x4 tiles), operands staged k-major through two LDS buffers.
+// The MFMA's first operand carries the N index, the second the M index: the accumulator then holds 16 consecutive rows of a
+// column per register, and the stores of C are 128-byte runs.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha, const double* __restrict__ A, int64_t lda,
+                                               const double* __restrict__ B, int64_t ldb, int K2, const double* __restrict__ A2,
+                                               const double* __restrict__ B2, double beta, double* __restrict__ C, int64_t ldc,
+                                               int64_t sA, int64_t sB, int64_t sC) {
+  __shared__ double s_a[2][GK][GLD], s_b[2][GK][GLD];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, li = l & 15, lk = l >> 4;
+  const int wm = w & 1, wn = w >> 1;
+  const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+  const int nk1 = (K + GK - 1) / GK, nk2 = (K2 + GK - 1) / GK, nk = nk1 + nk2;
+  double ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const bool second = kt >= nk1;
+    const double* Ap = second ? A2 : A;
+    const double* Bp = second ? B2 : B;
+    const int Kc = second ? K2 : K, k0 = (second ? kt - nk1 : kt) * GK;
+    tile_load<TA>(Ap, lda, i0, k0, M, Kc, tid, ra);
+    tile_load<!TB>(Bp, ldb, j0, k0, N, Kc, tid, rb);
+  };
+  if (nk > 0) {
+    gload(0);
+    tile_store<TA>(s_a[0], tid, ra);
+    tile_store<!TB>(s_b[0], tid, rb);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int k4 = 0; k4 < GK / 4; ++k4) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[mi] = s_a[buf][k4 * 4 + lk][wm * 32 + mi * 16 + li];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = s_b[buf][k4 * 4 + lk][wn * 32 + ni * 16 + li];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = MFMA_F64(bf[ni], af[mi], acc[mi][ni]);
+    }
+    if (kt + 1 < nk) {
+      tile_store<TA>(s_a[buf ^ 1], tid, ra);
+      tile_store<!TB>(s_b[buf ^ 1], tid, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = i0 + wm * 32 + mi * 16 + li, j = j0 + wn * 32 + ni * 16 + lk + 4 * reg;
+        if (i < M && j < N) {
+          double* cp = C + (int64_t)i + (int64_t)j * ldc;
+          double v = alpha * acc[mi][ni][reg];
+          if (beta != 0.0) v = fma(beta, *cp, v);
+          *cp = v;
+        }
+      }
+}
+
+struct gemm_desc {
+  bool ta, tb;
+  int M, N, K;
+  double alpha, beta;
+  const double *A, *B;
+  int64_t lda, ldb;
+  double* C;
+  int64_t ldc;
+  int K2 = 0;
+  const double *A2 = nullptr, *B2 = nullptr;
+  int batch = 1;
+  int64_t sA = 0, sB = 0, sC = 0;
+};
+int launch_dgemm(hfmi_ctx* ctx, const gemm_desc& g) {
+  if (g.M <= 0 || g.N <= 0) return HFMI_OK;
+  const dim3 grid((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, g.batch), block(256);
+#define EB_GEMM(TAV, TBV)                                                                                                              \
+  hipLaunchKernelGGL((k_dgemm<TAV, TBV>), grid, block, 0, ctx->stream, g.M, g.N, g.K, g.alpha, g.A, g.lda, g.B, g.ldb, g.K2, g.A2, g.B2, \
+                     g.beta, g.C, g.ldc, g.sA, g.sB, g.sC)
+  if (!g.ta && !g.tb) EB_GEMM(false, false);
+  else if (g.ta && !g.tb) EB_GEMM(true, false);
+  else if (!g.ta && g.tb) EB_GEMM(false, true);
+  else EB_GEMM(true, true);
+#undef EB_GEMM
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ load: symmetrise, scale
+// raw: the caller's n x n row-major matrix.  A (column-major, ld) = (raw + raw^T) / 2; per-tile max |entry| -> pmax
+__global__ __launch_bounds__(256) void k_sym_load(const double* __restrict__ raw, int n, double* __restrict__ A, int64_t ld,
+                                                  double* __restrict__ pmax) {
+  __shared__ double t1[32][33], t2[32][33];
+  __shared__ double s_red[4];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = ty + 8 * q;
+    t1[a][tx] = (i0 + a < n && j0 + tx < n) ? raw[(size_t)(i0 + a) * n + (j0 + tx)] : 0.0;     // raw[i][j]
+    t2[a][tx] = (j0 + a < n && i0 + tx < n) ? raw[(size_t)(j0 + a) * n + (i0 + tx)] : 0.0;     // raw[j][i]
+  }
+  __syncthreads();
+  double mx = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = ty + 8 * q;            // j = j0 + b, i = i0 + tx
+    const double v = 0.5 * (t1[tx][b] + t2[b][tx]);
+    if (i0 + tx < n && j0 + b < n) {
+      A[(size_t)(i0 + tx) + (size_t)(j0 + b) * ld] = v;
+      mx = fmax(mx, fabs(v));
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) pmax[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+}
+// power-of-two scaling to max |entry| in [1, 2): norms cannot overflow / underflow, the eigenvalues scale back exactly
+__global__ __launch_bounds__(1024) void k_scale_exp(const double* __restrict__ pmax, int np, int* __restrict__ sexp_out) {
+  __shared__ double s_red[16];
+  double mx = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) mx = fmax(mx, pmax[i]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double amax = 0.0;
+    for (int q = 0; q < 16; ++q) amax = fmax(amax, s_red[q]);
+    int sexp = 0;
+    if (amax > 0.0 && isfinite(amax)) sexp = ilogb(amax);
+    *sexp_out = sexp;
+  }
+}
+__global__ __launch_bounds__(256) void k_scale_apply(double* __restrict__ A, int64_t ld, int n, const int* __restrict__ sexp) {
+  const double sc = ldexp(1.0, -*sexp);
+  double* col = A + (size_t)blockIdx.x * ld;
+  for (int r = threadIdx.x; r < n; r += 256) col[r] *= sc;
+}
+
+// ------------------------------------------------------------------------------------------------ tridiagonalisation
+struct tri_args {
+  int n, j, jj, p0, mode;       // mode bit 0: finalise W[:, jj - 1] (products of step j - 1); bit 1: form column j
+  int64_t ld;
+  double* A;
+  double* Vh;                   // reflectors, n x n (column j = v_j with explicit zeros and the unit entry)
+  double* W;                    // panel W, n x EB_NB
+  double* colbuf;               // column j of the reduced matrix (rows j ..)
+  double* ybuf;                 // A v of the last step
+  double *x1, *x2;              // V^T v, W^T v of the last step
+  double* pvy;                  // partial sums of v . y, one per workgroup of the last k_tri_b
+  int npvy;
+  double* pn;                   // partial sums of |col[j + 2 ..]|^2, one per workgroup of k_tri_a
+  int npn;
+  double *dvec, *evec, *tauv;
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double* s_red) {   // fixed order; every thread gets the result
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  __syncthreads();
+  return r;
+}
+
+// rows r = j + blockIdx.x * 256 + tid
+__global__ __launch_bounds__(256) void k_tri_a(tri_args p) {
+  __shared__ double s_x1[EB_NB], s_x2[EB_NB], s_vj[EB_NB], s_wj[EB_NB], s_red[4];
+  __shared__ double s_alpha;
+  const int tid = threadIdx.x, n = p.n, j = p.j, jj = p.jj;
+  const int64_t ld = p.ld;
+  const double* __restrict__ Vp = p.Vh + (size_t)p.p0 * ld;
+  double* __restrict__ W = p.W;
+  const bool fin = (p.mode & 1) && jj > 0, col = (p.mode & 2) != 0;
+  const int kf = jj - 1;                       // the column being finalised
+  const double tprev = fin ? p.tauv[j - 1] : 0.0;
+  if (tid < 64) {
+    if (fin) {
+      double s = 0.0;
+      for (int q = tid; q < p.npvy; q += 64) s += p.pvy[q];
+      const double vy = wave_sum(s);
+      const double x1v = tid < kf ? p.x1[tid] : 0.0, x2v = tid < kf ? p.x2[tid] : 0.0;
+      s_x1[tid] = x1v;
+      s_x2[tid] = x2v;
+      const double s12 = wave_sum(x1v * x2v);
+      const double alpha = -0.5 * tprev * tprev * (vy - 2.0 * s12);      // -tau/2 (v . w'),  v . w' = tau (v.y - 2 x1.x2)
+      if (tid == 0) s_alpha = alpha;
+      if (col) {      // row j of V and W, the finalised entry W[j, kf] included: every workgroup computes it for itself
+        const double vjk = tid < kf ? Vp[(size_t)j + (size_t)tid * ld] : 0.0, wjk = tid < kf ? W[(size_t)j + (size_t)tid * ld] : 0.0;
+        const double yc = wave_sum(fma(vjk, x2v, wjk * x1v));
+        const double vjl = Vp[(size_t)j + (size_t)kf * ld];
+        const double wjl = fma(tprev, p.ybuf[j] - yc, alpha * vjl);
+        s_vj[tid] = tid < kf ? vjk : (tid == kf ? vjl : 0.0);
+        s_wj[tid] = tid < kf ? wjk : (tid == kf ? wjl : 0.0);
+      }
+    } else if (col) {
+      s_vj[tid] = tid < jj ? Vp[(size_t)j + (size_t)tid * ld] : 0.0;
+      s_wj[tid] = tid < jj ? W[(size_t)j + (size_t)tid * ld] : 0.0;
+    }
+  }
+  __syncthreads();
+  const int r = j + blockIdx.x * 256 + tid;
+  const bool live = r < n;
+  double colv = 0.0;
+  if (live) {
+    const int kmax = fin ? kf : jj;
+    double accy = 0.0, accc = 0.0;
+    for (int k = 0; k < kmax; ++k) {
+      const double v = Vp[(size_t)r + (size_t)k * ld], wv = W[(size_t)r + (size_t)k * ld];
+      if (fin) accy = fma(v, s_x2[k], fma(wv, s_x1[k], accy));
+      if (col) accc = fma(v, s_wj[k], fma(wv, s_vj[k], accc));
+    }
+    if (fin) {
+      const double vr = Vp[(size_t)r + (size_t)kf * ld];
+      const double wr = fma(tprev, p.ybuf[r] - accy, s_alpha * vr);
+      W[(size_t)r + (size_t)kf * ld] = wr;
+      if (col) accc = fma(vr, s_wj[kf], fma(wr, s_vj[kf], accc));
+    }
+    if (col) {
+      colv = p.A[(size_t)r + (size_t)j * ld] - accc;
+      p.colbuf[r] = colv;
+      if (r == j) p.dvec[j] = colv;
+    }
+  }
+  if (col) {
+    const double part = block_sum_256((live && r >= j + 2) ? colv * colv : 0.0, s_red);
+    if (tid == 0) p.pn[blockIdx.x] = part;
+  }
+}
+
+// 512 threads; dynamic LDS: v on rows [rs, ld), rs = (j + 1) rounded down to 64
+__global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
+  extern __shared__ __attribute__((aligned(16))) double s_v[];
+  __shared__ double s_part[8];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
+  const int64_t ld = p.ld;
+  const int rs = (j + 1) & ~63;
+  double xn2 = 0.0;
+  for (int q = 0; q < p.npn; ++q) xn2 += p.pn[q];
+  const double alpha0 = p.colbuf[j + 1];
+  double tau = 0.0, beta = alpha0, scl = 0.0;
+  if (xn2 > 1e-280) {      // entries are scaled to O(1): below this the column is zero to any precision that matters
+    const double nrm = sqrt(fma(alpha0, alpha0, xn2));
+    beta = -copysign(nrm, alpha0);
+    tau = (beta - alpha0) / beta;
+    scl = 1.0 / (alpha0 - beta);
+  }
+  for (int r = rs + tid; r < (int)ld; r += 512) s_v[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : p.colbuf[r] * scl);
+  double* __restrict__ vcol = p.Vh + (size_t)j * ld;
+  for (int r = blockIdx.x * 512 + tid; r < n; r += gridDim.x * 512) vcol[r] = r <= j ? 0.0 : (r == j + 1 ? 1.0 : p.colbuf[r] * scl);
+  if (blockIdx.x == 0 && tid == 0) {
+    p.evec[j] = beta;
+    p.tauv[j] = tau;
+  }
+  __syncthreads();
+  const int nA = n - j - 1, nc = nA + 2 * jj;
+  const int npair = ((int)ld - rs) >> 1;
+  const d2* __restrict__ v2 = (const d2*)s_v;
+  double vyp = 0.0;
+  for (int q = blockIdx.x * 8 + w; q < nc; q += gridDim.x * 8) {
+    const double* colp;
+    if (q < nA) colp = p.A + (size_t)(j + 1 + q) * ld;
+    else if (q < nA + jj) colp = p.Vh + (size_t)(p.p0 + q - nA) * ld;
+    else colp = p.W + (size_t)(q - nA - jj) * ld;
+    const d2* __restrict__ c2 = (const d2*)(colp + rs);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = l;
+    for (; i + 64 < npair; i += 128) {
+      const d2 x = c2[i], xb = c2[i + 64];
+      const d2 vv = v2[i], vb = v2[i + 64];
+      a0 = fma(x.x, vv.x, a0);
+      a1 = fma(x.y, vv.y, a1);
+      a2 = fma(xb.x, vb.x, a2);
+      a3 = fma(xb.y, vb.y, a3);
+    }
+    if (i < npair) {
+      const d2 x = c2[i];
+      const d2 vv = v2[i];
+      a0 = fma(x.x, vv.x, a0);
+      a1 = fma(x.y, vv.y, a1);
+    }
+    const double y = wave_sum((a0 + a1) + (a2 + a3));
+    if (q < nA) {
+      if (l == 0) p.ybuf[j + 1 + q] = y;
+      vyp = fma(y, s_v[j + 1 + q - rs], vyp);
+    } else if (q < nA + jj) {
+      if (l == 0) p.x1[q - nA] = y;
+    } else {
+      if (l == 0) p.x2[q - nA - jj] = y;
+    }
+  }
+  if (l == 0) s_part[w] = vyp;
+  __syncthreads();
+  if (tid == 0) p.pvy[blockIdx.x] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) + ((s_part[4] + s_part[5]) + (s_part[6] + s_part[7]));
+}
+// the last 2 x 2 block of the reduced matrix
+__global__ void k_tri_tail(const double* __restrict__ A, int64_t ld, int n, double* __restrict__ dvec, double* __restrict__ evec) {
+  if (threadIdx.x == 0) {
+    dvec[n - 2] = A[(size_t)(n - 2) + (size_t)(n - 2) * ld];
+    evec[n - 2] = A[(size_t)(n - 1) + (size_t)(n - 2) * ld];
+    dvec[n - 1] = A[(size_t)(n - 1) + (size_t)(n - 1) * ld];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ divide and conquer, upper levels
+struct dcl_node {
+  int lo, mid, hi, K, nrot, skip;
+  double rho, tol;
+};
+struct dcl_args {
+  int n, L;
+  int64_t ld;
+  const double* evec;
+  double *D, *Dnew;             // eigenvalue of every column before / after the level's merges
+  double *Q, *Qout, *Qg, *S;
+  double *Zv, *Ds, *Zs, *dl, *wv, *tauS, *zhat, *rc, *rs;
+  int *Col, *Live, *Ks, *Src, *orgv, *ra, *rb;
+  dcl_node* nodes;
+  int* fail;
+};
+__device__ __forceinline__ void dcl_range(int n, int L, int t, int& node, int& lo, int& mid, int& hi) {
+  node = (((t + 1) << L) - 1) / n;
+  lo = (int)(((int64_t)node * n) >> L);
+  hi = (int)(((int64_t)(node + 1) * n) >> L);
+  mid = (int)(((int64_t)(2 * node + 1) * n) >> (L + 1));
+}
+// the rank-one vector of every node: last row of the left child's Q, first row of the right child's; tolerance of the node
+__global__ __launch_bounds__(1024) void k_dcl_z(dcl_args p) {
+  __shared__ double s_d[16], s_z[16];
+  const int node = blockIdx.x, n = p.n, L = p.L, tid = threadIdx.x;
+  const int lo = (int)(((int64_t)node * n) >> L), hi = (int)(((int64_t)(node + 1) * n) >> L);
+  const int mid = (int)(((int64_t)(2 * node + 1) * n) >> (L + 1));
+  const double beta = p.evec[mid - 1], sgn = beta >= 0.0 ? 1.0 : -1.0, rho = 2.0 * fabs(beta);
+  double dmax = 0.0, zmax = 0.0;
+  for (int t = lo + tid; t < hi; t += 1024) {
+    const double q = t < mid ? p.Q[(size_t)(mid - 1) + (size_t)t * p.ld] : sgn * p.Q[(size_t)mid + (size_t)t * p.ld];
+    const double z = q * 0.70710678118654752440;
+    p.Zv[t] = z;
+    dmax = fmax(dmax, fabs(p.D[t]));
+    zmax = fmax(zmax, fabs(z));
+  }
+  dmax = wave_max(dmax);
+  zmax = wave_max(zmax);
+  if ((tid & 63) == 0) {
+    s_d[tid >> 6] = dmax;
+    s_z[tid >> 6] = zmax;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int q = 1; q < 16; ++q) {
+      dmax = fmax(dmax, s_d[q]);
+      zmax = fmax(zmax, s_z[q]);
+    }
+    const double tol = 8.0 * DC_EPS * fmax(dmax, zmax);
+    dcl_node nd;
+    nd.lo = lo;
+    nd.mid = mid;
+    nd.hi = hi;
+    nd.K = 0;
+    nd.nrot = 0;
+    nd.skip = rho * zmax <= tol ? 1 : 0;            // nothing couples: every component counts as small
+    nd.rho = rho;
+    nd.tol = tol;
+    p.nodes[node] = nd;
+  }
+}
+// ascending rank of every pole inside its node (ties by column), components below the tolerance drop out (dlaed2's first test)
+__global__ __launch_bounds__(256) void k_dcl_rank(dcl_args p) {
+  __shared__ double s_d[256], s_z[256];
+  const int n = p.n, L = p.L, tid = threadIdx.x;
+  const int t = blockIdx.x * 256 + tid;
+  const bool valid = t < n;
+  int node = 0, lo = 0, mid = 0, hi = 0;
+  if (valid) dcl_range(n, L, t, node, lo, mid, hi);
+  int ulo, uhi;
+  {
+    const int t_first = blockIdx.x * 256, t_last = min(n, t_first + 256) - 1;
+    int nd, a, m, b;
+    dcl_range(n, L, t_first, nd, a, m, b);
+    ulo = a;
+    dcl_range(n, L, t_last, nd, a, m, b);
+    uhi = b;
+  }
+  double dt = 0.0, zt = 0.0, rho = 0.0, thr = 0.0;
+  if (valid) {
+    dt = p.D[t];
+    zt = p.Zv[t];
+    rho = p.nodes[node].rho;
+    thr = p.nodes[node].skip ? INFINITY : p.nodes[node].tol;
+  }
+  int rank = 0, pre = 0, cnt = 0;
+  for (int base = ulo; base < uhi; base += 256) {
+    const int u = base + tid;
+    if (u < uhi) {
+      s_d[tid] = p.D[u];
+      s_z[tid] = p.Zv[u];
+    }
+    __syncthreads();
+    const int m = min(256, uhi - base);
+    if (valid) {
+      const int q0 = max(0, lo - base), q1 = min(m, hi - base);
+      for (int q = q0; q < q1; ++q) {
+        const double du = s_d[q], zu = s_z[q];
+        const bool before = du < dt || (du == dt && base + q < t);
+        const bool live = !(rho * fabs(zu) <= thr);
+        rank += before ? 1 : 0;
+        pre += (before && live) ? 1 : 0;
+        cnt += live ? 1 : 0;
+      }
+    }
+    __syncthreads();
+  }
+  if (valid) {
+    const bool live_t = !(rho * fabs(zt) <= thr);
+    p.Ds[lo + rank] = dt;
+    p.Zs[lo + rank] = zt;
+    p.Col[lo + rank] = t;
+    p.Live[lo + rank] = live_t ? 1 : 0;
+    if (live_t) p.Ks[lo + pre] = lo + rank;
+    if (t == lo) p.nodes[node].K = cnt;
+  }
+}
+// dlaed2's second test (two neighbouring surviving poles so close that a plane rotation decouples one of them): checked on all
+// pairs in parallel; only if some pair is close, one thread redoes the scan sequentially with the rotations (everything in LDS).
+// Then the kept poles are gathered and the new column order of the node is fixed: kept poles first (ascending), the deflated
+// columns behind them (ascending).
+__global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
+  // dynamic LDS, cap = the largest node of the level rounded up to 64: 26 bytes per pole (106 KB at 4096)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  double* s_d = (double*)s_raw;
+  double* s_z = s_d + cap;
+  int* s_ks = (int*)(s_z + cap);
+  int* s_kp = s_ks + cap;
+  unsigned char* s_kept = (unsigned char*)(s_kp + cap);
+  unsigned char* s_lv = s_kept + cap;
+  __shared__ int s_scan[1024];
+  __shared__ int s_any, s_K, s_nrot;
+  const int node = blockIdx.x, tid = threadIdx.x;
+  const dcl_node nd = p.nodes[node];
+  const int lo = nd.lo, hi = nd.hi, nn = hi - lo, K0 = nd.K;
+  const double tol = nd.tol;
+  if (tid == 0) {
+    s_any = 0;
+    s_K = K0;
+    s_nrot = 0;
+  }
+  for (int i = tid; i < K0; i += 1024) {
+    const int s = p.Ks[lo + i];
+    s_ks[i] = s;
+    s_d[i] = p.Ds[s];
+    s_z[i] = p.Zs[s];
+    s_kp[i] = i;
+    s_kept[i] = 1;
+  }
+  for (int q = tid; q < nn; q += 1024) s_lv[q] = (unsigned char)p.Live[lo + q];
+  __syncthreads();
+  for (int i = 1 + tid; i < K0; i += 1024) {
+    const double zs = s_z[i], zp = s_z[i - 1], t = s_d[i] - s_d[i - 1];
+    // |t c s| <= tol with c = zs / tau, s = -zp / tau, tau^2 = zs^2 + zp^2
+    if (fabs(t * zs * zp) <= tol * fma(zs, zs, zp * zp)) s_any = 1;
+  }
+  __syncthreads();
+  if (s_any) {
+    if (tid == 0) {
+      int K = 0, nrot = 0, pj = -1;
+      double zp = 0.0, dp = 0.0;
+      for (int i = 0; i < K0; ++i) {
+        const double zs = s_z[i], ds = s_d[i];
+        if (pj < 0) {
+          pj = i;
+          zp = zs;
+          dp = ds;
+          continue;
+        }
+        const double tau = sqrt(fma(zs, zs, zp * zp));     // |z| <= 1: no overflow to guard
+        const double c = zs / tau, sn = -zp / tau;
+        const double t = ds - dp;
+        if (fabs(t * c * sn) <= tol) {
+          s_z[pj] = 0.0;
+          s_kept[pj] = 0;
+          p.ra[lo + nrot] = s_ks[pj];
+          p.rb[lo + nrot] = s_ks[i];
+          p.rc[lo + nrot] = c;
+          p.rs[lo + nrot] = sn;
+          ++nrot;
+          s_d[pj] = dp * c * c + ds * sn * sn;
+          const double dnew = dp * sn * sn + ds * c * c;
+          s_d[i] = dnew;
+          s_z[i] = tau;
+          pj = i;
+          zp = tau;
+          dp = dnew;
+        } else {
+          s_kp[K++] = pj;
+          pj = i;
+          zp = zs;
+          dp = ds;
+        }
+      }
+      if (pj >= 0) s_kp[K++] = pj;
+      s_K = K;
+      s_nrot = nrot;
+    }
+    __syncthreads();
+    for (int i = tid; i < K0; i += 1024)
+      if (!s_kept[i]) s_lv[s_ks[i] - lo] = 0;
+    __syncthreads();
+  }
+  const int K = s_K;
+  // kept poles -> the secular problem
+  for (int i = tid; i < K; i += 1024) {
+    const int li = s_kp[i], s = s_ks[li];
+    p.dl[lo + i] = s_d[li];
+    p.wv[lo + i] = s_z[li];
+    p.Src[lo + i] = p.Col[s];
+  }
+  // deflated columns: position among the deflated, in sorted order (exclusive scan of the dead flags, 4 positions per thread)
+  const int per = (nn + 1023) / 1024;
+  int dead = 0;
+  for (int q = tid * per; q < min(nn, (tid + 1) * per); ++q) dead += s_lv[q] ? 0 : 1;
+  s_scan[tid] = dead;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = s_scan[tid] - dead;
+  // the eigenvalue of a deflated column: its (possibly rotated) pole.  Rotated poles sit in s_d under their live index: map back
+  // through a second pass over the live list (a dead-by-rotation position is a live-list member with kept = 0)
+  for (int i = tid; i < K0; i += 1024)
+    if (!s_kept[i]) p.Ds[s_ks[i]] = s_d[i];
+  __syncthreads();
+  for (int q = tid * per; q < min(nn, (tid + 1) * per); ++q) {
+    if (!s_lv[q]) {
+      p.Src[lo + K + pos] = p.Col[lo + q];
+      p.Dnew[lo + K + pos] = p.Ds[lo + q];
+      ++pos;
+    }
+  }
+  if (tid == 0) {
+    p.nodes[node].K = K;
+    p.nodes[node].nrot = s_nrot;
+  }
+}
+// the deflating rotations on the columns of Q, one thread per row, in scan order (a chain of rotations hands its second column on
+// as the first column of the next one: that value stays in a register)
+__global__ __launch_bounds__(256) void k_dcl_rot(dcl_args p) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= p.n) return;
+  int node, lo, mid, hi;
+  dcl_range(p.n, p.L, r, node, lo, mid, hi);
+  const int nrot = p.nodes[node].nrot;
+  int prev_cb = -1;
+  double prev_val = 0.0;
+  for (int q = 0; q < nrot; ++q) {
+    const int ca = p.Col[p.ra[lo + q]], cb = p.Col[p.rb[lo + q]];
+    const double c = p.rc[lo + q], sn = p.rs[lo + q];
+    const double qa = ca == prev_cb ? prev_val : p.Q[(size_t)r + (size_t)ca * p.ld];
+    const double qb = p.Q[(size_t)r + (size_t)cb * p.ld];
+    const double na = c * qa + sn * qb, nb = c * qb - sn * qa;
+    p.Q[(size_t)r + (size_t)ca * p.ld] = na;
+    p.Q[(size_t)r + (size_t)cb * p.ld] = nb;
+    prev_cb = cb;
+    prev_val = nb;
+  }
+}
+// one wave per root of the secular equation
+__global__ __launch_bounds__(256) void k_dcl_secular(dcl_args p) {
+  const int l = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= p.n) return;
+  int node, lo, mid, hi;
+  dcl_range(p.n, p.L, t, node, lo, mid, hi);
+  const int K = p.nodes[node].K, i = t - lo;
+  if (i >= K) return;
+  int org, evals;
+  double tau;
+  const bool ok = secular_root<64>(p.dl + lo, p.wv + lo, K, i, l, p.nodes[node].rho, org, tau, evals);
+  if (l == 0) {
+    p.tauS[t] = tau;
+    p.orgv[t] = org;
+    p.Dnew[t] = p.dl[lo + org] + tau;
+    if (!ok) atomicOr(p.fail, 1);
+  }
+}
+// Gu-Eisenstat: the rank-one vector for which the COMPUTED roots are exact
+__global__ __launch_bounds__(256) void k_dcl_zhat(dcl_args p) {
+  const int l = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= p.n) return;
+  int node, lo, mid, hi;
+  dcl_range(p.n, p.L, t, node, lo, mid, hi);
+  const int K = p.nodes[node].K, i = t - lo;
+  if (i >= K) return;
+  const double* __restrict__ dl = p.dl + lo;
+  const double di = dl[i];
+  double prod = 1.0;
+  for (int j = l; j < K; j += 64) {
+    const double num = (dl[p.orgv[lo + j]] - di) + p.tauS[lo + j];     // lam_j - dl_i
+    prod *= (j == i) ? num : num * dc_rcp(dl[j] - di);
+  }
+  prod = group_prod<64>(prod);
+  if (l == 0) p.zhat[t] = copysign(sqrt(fabs(prod)), p.wv[t]);
+}
+// eigenvectors of the rank-one problem, normalised: column i of the node's S (K x K at S[lo.., lo..], column-major)
+__global__ __launch_bounds__(256) void k_dcl_svec(dcl_args p) {
+  const int l = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= p.n) return;
+  int node, lo, mid, hi;
+  dcl_range(p.n, p.L, t, node, lo, mid, hi);
+  const int K = p.nodes[node].K, i = t - lo;
+  if (i >= K) return;
+  const double* __restrict__ dl = p.dl + lo;
+  const double* __restrict__ zh = p.zhat + lo;
+  const double dorg = dl[p.orgv[t]], tau = p.tauS[t];
+  double nrm = 0.0;
+  for (int q = l; q < K; q += 64) {
+    const double sv = zh[q] * dc_rcp((dl[q] - dorg) - tau);
+    nrm = fma(sv, sv, nrm);
+  }
+  nrm = wave_sum(nrm);
+  const double inv = dc_rsqrt(nrm);
+  double* __restrict__ scol = p.S + (size_t)lo + (size_t)t * p.ld;
+  for (int q = l; q < K; q += 64) scol[q] = zh[q] * dc_rcp((dl[q] - dorg) - tau) * inv;
+}
+// new column order: kept columns gathered for the product (Qg), deflated columns moved over unchanged (Qout); rows of the node
+__global__ __launch_bounds__(256) void k_dcl_gather(dcl_args p) {
+  const int t = blockIdx.x;
+  int node, lo, mid, hi;
+  dcl_range(p.n, p.L, t, node, lo, mid, hi);
+  const int K = p.nodes[node].K;
+  const double* __restrict__ src = p.Q + (size_t)p.Src[t] * p.ld;
+  double* __restrict__ dst = (t - lo < K ? p.Qg : p.Qout) + (size_t)t * p.ld;
+  for (int r = lo + threadIdx.x; r < hi; r += 256) dst[r] = src[r];
+}
+
+// ------------------------------------------------------------------------------------------------ block reflectors
+// triangular factor of a panel from its Gram matrix (LAPACK dlarft, forward, columnwise): T[i][i] = tau_i,
+// T[0:i, i] = -tau_i T[0:i, 0:i] (V^T v_i).  One wave per panel.
+__global__ __launch_bounds__(64) void k_larft(const double* __restrict__ G, const double* __restrict__ tauv, double* __restrict__ Tf) {
+  __shared__ double s_t[EB_NB][EB_NB + 1], s_g[EB_NB];
+  const int r = threadIdx.x;
+  const double* g = G + (size_t)blockIdx.x * EB_NB * EB_NB;
+  for (int c = 0; c < EB_NB; ++c) s_t[r][c] = 0.0;
+  for (int i = 0; i < EB_NB; ++i) {
+    s_g[r] = g[r + i * EB_NB];           // column i of the Gram matrix: v_c . v_i
+    __syncthreads();
+    const double ti = tauv[blockIdx.x * EB_NB + i];
+    double v = 0.0;
+    if (r < i) {
+      double s = 0.0;
+      for (int c = r; c < i; ++c) s = fma(s_t[r][c], s_g[c], s);
+      v = -ti * s;
+    } else if (r == i) {
+      v = ti;
+    }
+    s_t[r][i] = v;
+    __syncthreads();
+  }
+  double* t = Tf + (size_t)blockIdx.x * EB_NB * EB_NB;
+  for (int c = 0; c < EB_NB; ++c) t[r + c * EB_NB] = s_t[r][c];
+}
+// out (row-major n x n) [i][pos] = Z[i, order[pos]]: permutation of the columns + transposition through LDS
+__global__ __launch_bounds__(256) void k_out(const double* __restrict__ Z, int64_t ld, int n, const int* __restrict__ order,
+                                             double* __restrict__ out) {
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = ty + 8 * q;            // position p0 + a, row i0 + tx
+    t[a][tx] = (p0 + a < n && i0 + tx < n) ? Z[(size_t)(i0 + tx) + (size_t)order[p0 + a] * ld] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = ty + 8 * q;            // row i0 + a, position p0 + tx
+    if (i0 + a < n && p0 + tx < n) out[(size_t)(i0 + a) * n + (p0 + tx)] = t[tx][a];
+  }
+}
+
+struct phase_clock {
+  hfmi_ctx* ctx;
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  double ms[8];
+  int cur;
+  explicit phase_clock(hfmi_ctx* c) : ctx(c), on(env_flag("HFMI_EIG_LARGE_TIMING")), cur(0) {
+    memset(ms, 0, sizeof(ms));
+    if (on) {
+      (void)hipStreamSynchronize(ctx->stream);
+      t0 = std::chrono::steady_clock::now();
+    }
+  }
+  void mark(int slot) {
+    if (!on) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    const auto t1 = std::chrono::steady_clock::now();
+    ms[slot] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t0 = t1;
+  }
+};
+}  // namespace
+
+// host_T: n x n row-major symmetric (the symmetric part is used); host_d: n eigenvalues descending (by |d| if
+// sort_by_abs); host_V: n x n row-major, eigenvectors in the columns (may be null).
+int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V) {
+  if (n > EB_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds %d", n, EB_MAXN);
+  static const bool jacobi = [] {
+    const char* e = getenv("HFMI_EIG_LARGE");
+    return e && !strcmp(e, "jacobi");
+  }();
+  if (jacobi || n < 3) return sym_eig_large_jacobi(ctx, host_T, n, sort_by_abs, host_d, host_V);
+  const int NB = EB_NB;
+  const int64_t ld = round_up(n, 128);
+  const int npad = (int)round_up(n, NB), npanels = npad / NB;
+  const size_t mat = (size_t)ld * npad;
+  const size_t vlen = (size_t)npad + 128;
+  // ---- workspace
+  const size_t n_mats = 5;
+  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)NB * npad + 2 * (size_t)npanels * NB * NB + 16 * vlen + 2 * 64 + 64 + 512 +
+                         (size_t)(npad / 32 + 1) * (npad / 32 + 1);
+  const size_t i_count = 8 * vlen + 64;
+  const size_t bytes = d_count * sizeof(double) + i_count * sizeof(int) + 64 * sizeof(dcl_node) + 256;
+  void* wv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, bytes, &wv));
+  double* dp = (double*)wv;
+  auto take = [&](size_t count) {
+    double* r = dp;
+    dp += count;
+    return r;
+  };
+  double* A = take(mat);        // the matrix; later S of the merges, then Y = V T of the back-transformation
+  double* Vh = take(mat);
+  double* Q1 = take(mat);
+  double* Q2 = take(mat);
+  double* Qg = take(mat);       // raw upload first, gathered columns of the merges, nothing afterwards
+  double* Wp = take((size_t)ld * NB);
+  double* W1 = take((size_t)NB * npad);
+  double* Gm = take((size_t)npanels * NB * NB);
+  double* Tf = take((size_t)npanels * NB * NB);
+  double* colbuf = take(vlen);
+  double* ybuf = take(vlen);
+  double* dvec = take(vlen);
+  double* evec = take(vlen);
+  double* tauv = take(vlen);
+  double* D0 = take(vlen);
+  double* D1 = take(vlen);
+  double* Zv = take(vlen);
+  double* Ds = take(vlen);
+  double* Zs = take(vlen);
+  double* dl = take(vlen);
+  double* wvv = take(vlen);
+  double* tauS = take(vlen);
+  double* zhat = take(vlen);
+  double* rc = take(vlen);
+  double* rs = take(vlen);
+  double* x1 = take(64);
+  double* x2 = take(64);
+  double* pn = take(64);
+  double* pvy = take(512);
+  double* pmax = take((size_t)(npad / 32 + 1) * (npad / 32 + 1));
+  int* ip = (int*)dp;
+  auto take_i = [&](size_t count) {
+    int* r = ip;
+    ip += count;
+    return r;
+  };
+  int* Col = take_i(vlen);
+  int* Live = take_i(vlen);
+  int* Ks = take_i(vlen);
+  int* Src = take_i(vlen);
+  int* orgv = take_i(vlen);
+  int* ra = take_i(vlen);
+  int* rb = take_i(vlen);
+  int* order = take_i(vlen);
+  int* fail = take_i(16);
+  int* sexp_dev = fail + 1;
+  dcl_node* nodes = (dcl_node*)round_up((int64_t)(uintptr_t)(ip + 48), 16);
+  hipStream_t st = ctx->stream;
+  phase_clock clk(ctx);
+
+  // ---- load
+  HIP_TRY(hipMemcpyAsync(Qg, host_T, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(A, 0, mat * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(Vh, 0, mat * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(Q1, 0, 2 * mat * sizeof(double), st));          // Q1 and Q2 are adjacent
+  HIP_TRY(hipMemsetAsync(Wp, 0, (size_t)ld * NB * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(colbuf, 0, 16 * vlen * sizeof(double), st));    // the vectors (tau beyond n - 3 must read 0)
+  HIP_TRY(hipMemsetAsync(fail, 0, 16 * sizeof(int), st));
+  {
+    const int nt = (n + 31) / 32;
+    hipLaunchKernelGGL(k_sym_load, dim3(nt, nt), dim3(256), 0, st, Qg, n, A, ld, pmax);
+    hipLaunchKernelGGL(k_scale_exp, dim3(1), dim3(1024), 0, st, pmax, nt * nt, sexp_dev);
+    hipLaunchKernelGGL(k_scale_apply, dim3(n), dim3(256), 0, st, A, ld, n, sexp_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  clk.mark(0);
+
+  // ---- tridiagonalisation
+  {
+    tri_args ta;
+    ta.n = n;
+    ta.ld = ld;
+    ta.A = A;
+    ta.Vh = Vh;
+    ta.W = Wp;
+    ta.colbuf = colbuf;
+    ta.ybuf = ybuf;
+    ta.x1 = x1;
+    ta.x2 = x2;
+    ta.pvy = pvy;
+    ta.pn = pn;
+    ta.dvec = dvec;
+    ta.evec = evec;
+    ta.tauv = tauv;
+    ta.npvy = 0;
+    ta.npn = 0;
+    for (int p0 = 0; p0 < n - 2; p0 += NB) {
+      const int ncols = std::min(NB, n - 2 - p0);
+      ta.p0 = p0;
+      for (int jj = 0; jj < ncols; ++jj) {
+        const int j = p0 + jj;
+        ta.j = j;
+        ta.jj = jj;
+        ta.mode = 3;
+        const int ga = (n - j + 255) / 256;
+        ta.npn = ga;
+        hipLaunchKernelGGL(k_tri_a, dim3(ga), dim3(256), 0, st, ta);
+        const int nc = (n - j - 1) + 2 * jj;
+        const int gb = std::max(1, std::min(512, (nc + 7) / 8));
+        const int rs0 = (j + 1) & ~63;
+        hipLaunchKernelGGL(k_tri_b, dim3(gb), dim3(512), (size_t)(ld - rs0) * sizeof(double), st, ta);
+        ta.npvy = gb;
+      }
+      const int t0 = p0 + ncols;
+      ta.j = t0;
+      ta.jj = ncols;
+      ta.mode = 1;
+      hipLaunchKernelGGL(k_tri_a, dim3((n - t0 + 255) / 256), dim3(256), 0, st, ta);
+      HIP_TRY(hipGetLastError());
+      // A[t0:, t0:] -= V W^T + W V^T
+      gemm_desc g;
+      g.ta = false;
+      g.tb = true;
+      g.M = g.N = n - t0;
+      g.K = g.K2 = ncols;
+      g.alpha = -1.0;
+      g.beta = 1.0;
+      g.A = Vh + (size_t)p0 * ld + t0;
+      g.B = Wp + t0;
+      g.A2 = Wp + t0;
+      g.B2 = Vh + (size_t)p0 * ld + t0;
+      g.lda = g.ldb = ld;
+      g.C = A + (size_t)t0 * ld + t0;
+      g.ldc = ld;
+      HFMI_TRY(launch_dgemm(ctx, g));
+    }
+    hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(64), 0, st, A, ld, n, dvec, evec);
+    HIP_TRY(hipGetLastError());
+  }
+  clk.mark(1);
+
+  // ---- divide and conquer
+  int Lf = 0;
+  while (((n + (1 << Lf) - 1) >> Lf) > 256) ++Lf;
+  HFMI_TRY(launch_dc_leaves(ctx, n, Lf, dvec, evec, D0, Q1, ld, fail));
+  clk.mark(2);
+  double *Dcur = D0, *Dnext = D1, *Qcur = Q1, *Qnext = Q2;
+  {
+    void* pin = nullptr;
+    HFMI_TRY(ctx_pinned(ctx, 64 * sizeof(dcl_node), &pin));
+    dcl_node* hnodes = (dcl_node*)pin;
+    dcl_args da;
+    da.n = n;
+    da.ld = ld;
+    da.evec = evec;
+    da.Qg = Qg;
+    da.S = A;
+    da.Zv = Zv;
+    da.Ds = Ds;
+    da.Zs = Zs;
+    da.dl = dl;
+    da.wv = wvv;
+    da.tauS = tauS;
+    da.zhat = zhat;
+    da.rc = rc;
+    da.rs = rs;
+    da.Col = Col;
+    da.Live = Live;
+    da.Ks = Ks;
+    da.Src = Src;
+    da.orgv = orgv;
+    da.ra = ra;
+    da.rb = rb;
+    da.nodes = nodes;
+    da.fail = fail;
+    for (int L = Lf - 1; L >= 0; --L) {
+      const int nn = 1 << L;
+      da.L = L;
+      da.D = Dcur;
+      da.Dnew = Dnext;
+      da.Q = Qcur;
+      da.Qout = Qnext;
+      hipLaunchKernelGGL(k_dcl_z, dim3(nn), dim3(1024), 0, st, da);
+      hipLaunchKernelGGL(k_dcl_rank, dim3((n + 255) / 256), dim3(256), 0, st, da);
+      const int cap = (int)round_up((n + nn - 1) / nn + 1, 64);
+      const size_t defl_lds = (size_t)cap * 26;
+      HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
+      hipLaunchKernelGGL(k_dcl_deflate, dim3(nn), dim3(1024), defl_lds, st, da, cap);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(hnodes, nodes, (size_t)nn * sizeof(dcl_node), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(ctx->ev_side, st));
+      hipLaunchKernelGGL(k_dcl_rot, dim3((n + 255) / 256), dim3(256), 0, st, da);
+      hipLaunchKernelGGL(k_dcl_secular, dim3((n + 3) / 4), dim3(256), 0, st, da);
+      hipLaunchKernelGGL(k_dcl_zhat, dim3((n + 3) / 4), dim3(256), 0, st, da);
+      hipLaunchKernelGGL(k_dcl_svec, dim3((n + 3) / 4), dim3(256), 0, st, da);
+      hipLaunchKernelGGL(k_dcl_gather, dim3(n), dim3(256), 0, st, da);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventSynchronize(ctx->ev_side));
+      for (int i = 0; i < nn; ++i) {
+        const dcl_node& nd = hnodes[i];
+        if (nd.K <= 0) continue;
+        gemm_desc g;
+        g.ta = g.tb = false;
+        g.M = nd.hi - nd.lo;
+        g.N = g.K = nd.K;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.A = Qg + (size_t)nd.lo * ld + nd.lo;
+        g.B = A + (size_t)nd.lo * ld + nd.lo;
+        g.lda = g.ldb = ld;
+        g.C = Qnext + (size_t)nd.lo * ld + nd.lo;
+        g.ldc = ld;
+        HFMI_TRY(launch_dgemm(ctx, g));
+      }
+      std::swap(Dcur, Dnext);
+      std::swap(Qcur, Qnext);
+    }
+  }
+  clk.mark(3);
+
+  // ---- eigenvalues to the host, output order
+  std::vector<double> lam(n);
+  int hfail[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(lam.data(), Dcur, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hfail, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (hfail[0]) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig (n=%d): a secular equation did not converge", n);
+  std::vector<int> perm(n);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return sort_by_abs ? fabs(lam[x]) > fabs(lam[y]) : lam[x] > lam[y]; });
+  for (int jx = 0; jx < n; ++jx) host_d[jx] = ldexp(lam[perm[jx]], hfail[1]);
+  if (!host_V) return HFMI_OK;
+
+  // ---- back-transformation: Z <- (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) Z
+  {
+    double* Z = Qcur;
+    double* Y = A;
+    gemm_desc g;
+    g.ta = true;                 // Gram matrices of all panels
+    g.tb = false;
+    g.M = g.N = NB;
+    g.K = n;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    g.A = g.B = Vh;
+    g.lda = g.ldb = ld;
+    g.C = Gm;
+    g.ldc = NB;
+    g.batch = npanels;
+    g.sA = g.sB = (int64_t)NB * ld;
+    g.sC = (int64_t)NB * NB;
+    HFMI_TRY(launch_dgemm(ctx, g));
+    hipLaunchKernelGGL(k_larft, dim3(npanels), dim3(64), 0, st, Gm, tauv, Tf);
+    HIP_TRY(hipGetLastError());
+    gemm_desc gy;                // Y_p = V_p T_p
+    gy.ta = gy.tb = false;
+    gy.M = n;
+    gy.N = gy.K = NB;
+    gy.alpha = 1.0;
+    gy.beta = 0.0;
+    gy.A = Vh;
+    gy.lda = ld;
+    gy.B = Tf;
+    gy.ldb = NB;
+    gy.C = Y;
+    gy.ldc = ld;
+    gy.batch = npanels;
+    gy.sA = gy.sC = (int64_t)NB * ld;
+    gy.sB = (int64_t)NB * NB;
+    HFMI_TRY(launch_dgemm(ctx, gy));
+    for (int pi = npanels - 1; pi >= 0; --pi) {
+      const int p0 = pi * NB, r0 = p0 + 1;
+      if (r0 >= n || p0 >= n - 2) continue;
+      gemm_desc g1;              // W1 = V_p^T Z   (rows r0 ..)
+      g1.ta = true;
+      g1.tb = false;
+      g1.M = NB;
+      g1.N = n;
+      g1.K = n - r0;
+      g1.alpha = 1.0;
+      g1.beta = 0.0;
+      g1.A = Vh + (size_t)p0 * ld + r0;
+      g1.lda = ld;
+      g1.B = Z + r0;
+      g1.ldb = ld;
+      g1.C = W1;
+      g1.ldc = NB;
+      HFMI_TRY(launch_dgemm(ctx, g1));
+      gemm_desc g2;              // Z -= Y_p W1
+      g2.ta = g2.tb = false;
+      g2.M = n - r0;
+      g2.N = n;
+      g2.K = NB;
+      g2.alpha = -1.0;
+      g2.beta = 1.0;
+      g2.A = Y + (size_t)p0 * ld + r0;
+      g2.lda = ld;
+      g2.B = W1;
+      g2.ldb = NB;
+      g2.C = Z + r0;
+      g2.ldc = ld;
+      HFMI_TRY(launch_dgemm(ctx, g2));
+    }
+    clk.mark(4);
+    HIP_TRY(hipMemcpyAsync(order, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    const int nt = (n + 31) / 32;
+    double* out = Qnext;
+    hipLaunchKernelGGL(k_out, dim3(nt, nt), dim3(256), 0, st, Z, ld, n, order, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_V, out, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    clk.mark(5);
+  }
+  if (clk.on)
+    fprintf(stderr, "[hfmi eig n=%d] ms: load %.3f | tridiagonalisation %.3f | leaves %.3f | merges %.3f | back-transformation %.3f | output %.3f\n",
+            n, clk.ms[0], clk.ms[1], clk.ms[2], clk.ms[3], clk.ms[4], clk.ms[5]);
+  return HFMI_OK;
+}

@@ -22,70 +22,17 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
-#include "hfmi_gemm_common.h"
+#include "hfmi_dc_common.h"
 
 namespace {
 constexpr int DC_THREADS = 1024;
 constexpr int DC_WAVES = 16;
 constexpr int DC_MAXN = 256;
-constexpr double DC_EPS = 2.220446049250313e-16;
 
-// Cross-lane sums on DPP moves (two v_mov_b32_dpp per double and stage) instead of ds_bpermute round trips through the LDS
-// crossbar: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.  After a
-// stage both partners hold a + b and b + a, i.e. identical bits, so every lane of the group ends with the same value.
-template <int CTRL>
-__device__ __forceinline__ double dpp_get(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <int G>   // G = 1, 2, 4, 8, 16 consecutive lanes
-__device__ __forceinline__ double group_sum(double v) {
-  if (G >= 2) v += dpp_get<0xB1>(v);
-  if (G >= 4) v += dpp_get<0x4E>(v);
-  if (G >= 8) v += dpp_get<0x141>(v);
-  if (G >= 16) v += dpp_get<0x140>(v);
-  return v;
-}
-template <int G>
-__device__ __forceinline__ double group_prod(double v) {
-  if (G >= 2) v *= dpp_get<0xB1>(v);
-  if (G >= 4) v *= dpp_get<0x4E>(v);
-  if (G >= 8) v *= dpp_get<0x141>(v);
-  if (G >= 16) v *= dpp_get<0x140>(v);
-  return v;
-}
-__device__ __forceinline__ double lane_get(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {   // all 64 lanes
-  v = group_sum<16>(v);
-  return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
-}
-// 1 / sqrt(x) and 1 / x from the hardware estimates plus Newton steps: short dependent chains instead of the IEEE sequences
-// (the reflector needs tau and the scale to a few ulp, not correctly rounded)
-__device__ __forceinline__ double dc_rsqrt(double x) {
-  const double y0 = __builtin_amdgcn_rsq(x);
-  const double e = fma(-(x * y0), y0, 1.0);
-  const double q = e * fma(0.375, e, 0.5);
-  return fma(y0, q, y0);
-}
-__device__ __forceinline__ double dc_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
 
 // ------------------------------------------------------------------------------------------------ tridiagonalisation
 // per-phase shader-clock counters of wave 0 (build with -DHFMI_DC_TICKS; every s_memtime read drains the LDS queue, so the
@@ -453,7 +400,11 @@ __global__ __launch_bounds__(64 * NW) void k_tridiag(const double* __restrict__ 
         }
       }
     } else {
+      // column j is already reduced (tau = 0: diagonal, tridiagonal or decoupled input).  No barrier of the arithmetic path
+      // separates the waves here, and form_reflector rewrites s_tau, s_pend and (PRE) the single-buffered s_v2: every wave
+      // must have read tau and v_j, and the owner of row j must have flushed reflector j, before the owner of row j + 1 writes
       flush_pending(vc);
+      __syncthreads();
       if (next_mine) {
         double x[CJ];
         pick_row(chn, j + 1, x);
@@ -520,135 +471,9 @@ __device__ __forceinline__ void dc_node(int n, int L, int t, int& node, int& lo,
   mid = ((2 * node + 1) * n) >> (L + 1);
 }
 
-template <int G>
-__device__ __forceinline__ void secular_eval(const double* __restrict__ dl, const double* __restrict__ wv, int K, int sub,
-                                             double dorg, double tau, double rho, int i0, double& f, double& dpsi, double& dphi,
-                                             double& err) {
-  double psi = 0.0, phi = 0.0, dps = 0.0, dph = 0.0;
-  int j = sub;
-  for (; j <= i0; j += G) {                  // poles to the left of the root, then those to the right: no selects
-    const double dj = (dl[j] - dorg) - tau;
-    const double inv = dc_rcp(dj);           // a couple of ulp: inside the 8 eps (|psi| + |phi|) the stopping test allows
-    const double z = wv[j];
-    const double t = z * z * inv;
-    psi += t;
-    dps = fma(t, inv, dps);
-  }
-  for (; j < K; j += G) {
-    const double dj = (dl[j] - dorg) - tau;
-    const double inv = dc_rcp(dj);
-    const double z = wv[j];
-    const double t = z * z * inv;
-    phi += t;
-    dph = fma(t, inv, dph);
-  }
-  psi = rho * group_sum<G>(psi);
-  phi = rho * group_sum<G>(phi);
-  dpsi = rho * group_sum<G>(dps);
-  dphi = rho * group_sum<G>(dph);
-  f = 1.0 + psi + phi;
-  err = 8.0 * (fabs(psi) + fabs(phi)) + 1.0 + fabs(tau) * (dpsi + dphi);
-}
-
-// root i of 1 + rho sum_j w_j^2 / (dl_j - lam) = 0: returns the origin pole and tau = lam - dl[origin].
-// One round = one evaluation + the "middle way" step; the step is written without data-dependent branches (the lanes of a wave
-// work on different roots: a branch taken by one root is paid by all), with the hardware reciprocal / rsqrt estimates plus
-// Newton steps instead of the IEEE sequences.  A round is a dependent chain of ~100 fp64 operations either way: that chain
-// times the rounds a root needs (4 on average, 8 at most) times the levels is the floor of this kernel.
-template <int G>
-__device__ __forceinline__ bool secular_root(const double* __restrict__ dl, const double* __restrict__ wv, int K, int i, int sub,
-                                             double rho, int& org_out, double& tau_out, int& evals) {
-  evals = 0;
-  if (K == 1) {
-    org_out = 0;
-    tau_out = rho * wv[0] * wv[0];
-    return true;
-  }
-  const bool last = (i == K - 1);
-  const int i0 = last ? K - 2 : i, i1 = i0 + 1;
-  int org;
-  double lo, hi, f, dpsi, dphi, err;
-  double tau;
-  bool have_eval = false;
-  if (last) {
-    org = K - 1;
-    double s2 = 0.0;
-    for (int j = sub; j < K; j += G) s2 = fma(wv[j], wv[j], s2);
-    lo = 0.0;
-    hi = rho * group_sum<G>(s2);
-    tau = 0.5 * hi;
-  } else {
-    const double gap = dl[i + 1] - dl[i];
-    tau = 0.5 * gap;
-    secular_eval<G>(dl, wv, K, sub, dl[i], tau, rho, i0, f, dpsi, dphi, err);
-    have_eval = true;        // the same point in either shifted variable: value and slopes carry over
-    if (f >= 0.0) {          // root in the lower half: origin = left pole
-      org = i;
-      lo = 0.0;
-      hi = tau;
-    } else {                 // origin = right pole, tau = -gap / 2 there
-      org = i + 1;
-      lo = -tau;
-      hi = 0.0;
-      tau = -tau;
-    }
-  }
-  const double dorg = dl[org];
-  const double d0 = dl[i0] - dorg, d1 = dl[i1] - dorg;
-  bool converged = false;
-  for (int it = 0; it < 100; ++it) {
-    if (!have_eval) secular_eval<G>(dl, wv, K, sub, dorg, tau, rho, i0, f, dpsi, dphi, err);
-    have_eval = false;
-    ++evals;
-    if (fabs(f) <= DC_EPS * err) {
-      converged = true;
-      break;
-    }
-    lo = (f < 0.0) ? tau : lo;
-    hi = (f < 0.0) ? hi : tau;
-    if (hi - lo <= 2.0 * DC_EPS * fmax(fabs(lo), fabs(hi))) {
-      tau = 0.5 * (lo + hi);
-      converged = true;
-      break;
-    }
-    // "middle way": the two neighbouring poles kept exact, the rest matched in value and slope; c eta^2 - a eta + b = 0
-    const double D0 = d0 - tau, D1 = d1 - tau;
-    const double dw = dpsi + dphi;
-    const double dd = D0 * D1;
-    const double a = fma(D0 + D1, f, -dd * dw);
-    const double b = dd * f;
-    const double c = f - fma(D0, dpsi, D1 * dphi);
-    const double disc = fma(a, a, -4.0 * b * c);
-    const bool dok = disc > 0.0 && disc < 1e300;
-    const double dsafe = dok ? disc : 1.0;
-    const double sq = dsafe * dc_rsqrt(dsafe);
-    const double q = 0.5 * (a + copysign(sq, a));
-    const double x1 = fma(q, dc_rcp(c), tau);             // q / c
-    const double x2 = fma(b, dc_rcp(q), tau);             // b / q
-    const double xn = fma(-f, dc_rcp(dw), tau);           // Newton: f is increasing, the step always points at the root
-    const bool ok1 = dok && x1 > lo && x1 < hi;           // (comparisons are false for NaN / inf)
-    const bool ok2 = dok && x2 > lo && x2 < hi;
-    const bool okn = xn > lo && xn < hi;
-    const bool take2 = ok2 && (!ok1 || fabs(x2 - tau) < fabs(x1 - tau));
-    double next = take2 ? x2 : x1;
-    const bool found = ok1 || ok2;
-    next = found ? next : xn;
-    if (!(found || okn)) {                     // bisection, geometric where the bracket spans decades (rare)
-      if (lo > 0.0 && hi > 4.0 * lo) next = sqrt(lo * hi);
-      else if (hi < 0.0 && lo < 4.0 * hi) next = -sqrt(lo * hi);
-      else if (lo == 0.0) next = hi * 0.0625;
-      else if (hi == 0.0) next = lo * 0.0625;
-      else next = 0.5 * (lo + hi);
-    }
-    tau = next;
-  }
-  org_out = org;
-  tau_out = tau;
-  return converged;
-}
 
 template <int G>
-__global__ __launch_bounds__(DC_THREADS) void k_dc(dc_args p) {
+__device__ __forceinline__ void dc_body(const dc_args& p) {
   __shared__ double sD[DC_MAXN], sZ[DC_MAXN], sDs[DC_MAXN], sZs[DC_MAXN], sDl[DC_MAXN], sW[DC_MAXN], sTau[DC_MAXN], sZh[DC_MAXN];
   __shared__ double sRc[DC_MAXN], sRs[DC_MAXN];
   __shared__ int sCol[DC_MAXN], sKs[DC_MAXN], sKc[DC_MAXN], sOrg[DC_MAXN], sRa[DC_MAXN], sRb[DC_MAXN];
@@ -1079,6 +904,17 @@ __global__ __launch_bounds__(DC_THREADS) void k_dc(dc_args p) {
   }
 }
 
+template <int G>
+__global__ __launch_bounds__(DC_THREADS) void k_dc(dc_args p) {
+  dc_body<G>(p);
+}
+// the leaves of the whole-GPU eigensolver (hfmi_eig_blocked.hip): one independent tridiagonal problem per workgroup
+template <int G>
+__global__ __launch_bounds__(DC_THREADS) void k_dc_batch(const dc_args* __restrict__ batch) {
+  const dc_args p = batch[blockIdx.x];
+  dc_body<G>(p);
+}
+
 // ------------------------------------------------------------------------------------------------ last merge, all CUs
 // Qout[:, kept] = Qin[:, kept] S for the root node (rows 0 .. n): one wave per 16 x 16 tile, the other columns copied by the
 // remaining workgroups.  Inside k_dc the same product is 81 tiles on one CU with every operand an L2 round trip away (k = 138:
@@ -1187,6 +1023,39 @@ __global__ __launch_bounds__(64) void k_dc_back(const double* __restrict__ Q, in
       if (r < n) Vout[(size_t)r * ldo + pc] = z[e];
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ leaves of the whole-GPU solver
+struct leaf_desc {
+  int lo, nl, ldq;
+  double* dleaf;
+  const double* Qfin;
+  const double* dvals;
+  const int* perm;
+  const hfmi_status_words* status;
+};
+// the couplings of the upper tree levels are torn before the leaves are solved: a leaf's first / last diagonal entry gives up
+// |e| of the coupling to its neighbour (Cuppen's rank-one tearing, the same convention as inside dc_body)
+__global__ void k_leaf_prep(const leaf_desc* __restrict__ leaves, int n, const double* __restrict__ dvec, const double* __restrict__ evec) {
+  const leaf_desc L = leaves[blockIdx.x];
+  for (int i = threadIdx.x; i < L.nl; i += blockDim.x) {
+    double d = dvec[L.lo + i];
+    if (i == 0 && L.lo > 0) d -= fabs(evec[L.lo - 1]);
+    if (i == L.nl - 1 && L.lo + L.nl < n) d -= fabs(evec[L.lo + L.nl - 1]);
+    L.dleaf[i] = d;
+  }
+}
+// leaf results into the big problem: eigenvalue of every column, eigenvectors as the diagonal blocks of Q
+__global__ void k_leaf_gather(const leaf_desc* __restrict__ leaves, double* __restrict__ Dout, double* __restrict__ Qbig, int64_t ldq,
+                              int* __restrict__ fail) {
+  const leaf_desc L = leaves[blockIdx.y];
+  const int c = blockIdx.x;
+  if (c >= L.nl) return;
+  if (c == 0 && threadIdx.x == 0 && L.status->failed) atomicOr(fail, 1);
+  if (threadIdx.x == 0) Dout[L.lo + c] = L.dvals[L.perm[c]];
+  const double* src = L.Qfin + (size_t)c * L.ldq;
+  double* dst = Qbig + (size_t)(L.lo + c) * ldq + L.lo;
+  for (int r = threadIdx.x; r < L.nl; r += blockDim.x) dst[r] = src[r];
 }
 }  // namespace
 
@@ -1316,5 +1185,80 @@ int launch_dc_eig(hfmi_ctx* ctx, int k, int slot_t, int slot_v, double* dvals, i
     fprintf(stderr, "[hfmi tridiag k=%d] wave-0 ticks: (b) slices + barrier %lld | p, dot %lld | update (+ next reflector every 4th step) %lld | waiting for the owner %lld\n",
             k, h[12], h[13], h[14], h[15]);
   }
+  return HFMI_OK;
+}
+
+// tridiag(dvec, evec) of size n, cut at tree level Lf into 2^Lf independent problems of at most 256 rows (node i covers
+// [i n / 2^Lf, (i + 1) n / 2^Lf)): Dout[c] = eigenvalue of column c, the eigenvectors go to the diagonal blocks of Qbig (column-major,
+// ldq; the caller has zeroed the rest).  *fail (device) is or-ed with 1 if a secular iteration did not converge.
+int launch_dc_leaves(hfmi_ctx* ctx, int n, int Lf, const double* dvec, const double* evec, double* Dout, double* Qbig, int64_t ldq,
+                     int* fail) {
+  const int nleaf = 1 << Lf;
+  int nlmax = 0;
+  for (int i = 0; i < nleaf; ++i) nlmax = std::max(nlmax, (int)((((int64_t)(i + 1) * n) >> Lf) - (((int64_t)i * n) >> Lf)));
+  if (nlmax > DC_MAXN || nlmax < 2) HFMI_FAIL(HFMI_ERR_INVALID, "dc_leaves: leaf size %d out of range", nlmax);
+  const int ldl = (int)round_up(nlmax, 16);
+  const size_t mat = (size_t)ldl * ldl;
+  const size_t per_leaf_d = 2 * DC_MAXN + 3 * mat;                 // dleaf, dvals, Q, Qt, S
+  size_t bytes = (size_t)nleaf * per_leaf_d * sizeof(double);
+  const size_t off_perm = bytes;
+  bytes += (size_t)nleaf * DC_MAXN * sizeof(int);
+  const size_t off_ticks = bytes = round_up(bytes, 16);
+  bytes += (size_t)nleaf * 16 * sizeof(long long);
+  const size_t off_status = bytes = round_up(bytes, 16);
+  bytes += (size_t)nleaf * sizeof(hfmi_status_words);
+  const size_t off_args = bytes = round_up(bytes, 16);
+  bytes += (size_t)nleaf * sizeof(dc_args);
+  const size_t off_desc = bytes = round_up(bytes, 16);
+  bytes += (size_t)nleaf * sizeof(leaf_desc);
+  const size_t off_zero = bytes = round_up(bytes, 16);
+  bytes += 16;
+  void* wv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_MISC, bytes, &wv));
+  char* base = (char*)wv;
+  std::vector<dc_args> args(nleaf);
+  std::vector<leaf_desc> desc(nleaf);
+  for (int i = 0; i < nleaf; ++i) {
+    const int lo = (int)(((int64_t)i * n) >> Lf), hi = (int)(((int64_t)(i + 1) * n) >> Lf), nl = hi - lo;
+    double* d0 = (double*)base + (size_t)i * per_leaf_d;
+    dc_args& a = args[i];
+    a.n = nl;
+    a.levels = 0;
+    while ((1 << a.levels) < nl) ++a.levels;
+    a.sort_by_abs = 0;
+    a.dvec = d0;
+    a.evec = evec + lo;
+    a.sexp = (const int*)(base + off_zero);
+    a.Q = d0 + 2 * DC_MAXN;
+    a.Qt = a.Q + mat;
+    a.S = a.Qt + mat;
+    a.ldq = ldl;
+    a.dvals = d0 + DC_MAXN;
+    a.perm = (int*)(base + off_perm) + (size_t)i * DC_MAXN;
+    a.status = (hfmi_status_words*)(base + off_status) + i;
+    a.ticks = (long long*)(base + off_ticks) + (size_t)i * 16;
+    a.split_top = 0;
+    a.top_meta = nullptr;
+    const int swaps = a.levels >= 1 ? a.levels - 1 : 0;
+    leaf_desc& L = desc[i];
+    L.lo = lo;
+    L.nl = nl;
+    L.ldq = ldl;
+    L.dleaf = d0;
+    L.Qfin = (swaps & 1) ? a.Qt : a.Q;
+    L.dvals = a.dvals;
+    L.perm = a.perm;
+    L.status = a.status;
+  }
+  HIP_TRY(hipMemsetAsync(base + off_zero, 0, 16, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(base + off_args, args.data(), (size_t)nleaf * sizeof(dc_args), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(base + off_desc, desc.data(), (size_t)nleaf * sizeof(leaf_desc), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));      // args / desc are pageable host memory
+  const leaf_desc* ddesc = (const leaf_desc*)(base + off_desc);
+  hipLaunchKernelGGL(k_leaf_prep, dim3(nleaf), dim3(256), 0, ctx->stream, ddesc, n, dvec, evec);
+  if (nlmax <= 128) hipLaunchKernelGGL((k_dc_batch<8>), dim3(nleaf), dim3(DC_THREADS), 0, ctx->stream, (const dc_args*)(base + off_args));
+  else hipLaunchKernelGGL((k_dc_batch<4>), dim3(nleaf), dim3(DC_THREADS), 0, ctx->stream, (const dc_args*)(base + off_args));
+  hipLaunchKernelGGL(k_leaf_gather, dim3(nlmax, nleaf), dim3(256), 0, ctx->stream, ddesc, Dout, Qbig, ldq, fail);
+  HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }

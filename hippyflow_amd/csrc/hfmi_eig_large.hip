@@ -1,7 +1,7 @@
-// Symmetric eigensolve for matrices too large for the one-workgroup Jacobi kernel (256 < n <= 4096): classical
-// two-sided Jacobi with a parallel (tournament) ordering, spread over the whole GPU.  Used by the deterministic POD of
-// PODProjectorFromData when there are more than 256 snapshots (the n x n Gram problem of PODProjector.py:812-833,
-// la.eigh there).
+// Two-sided Jacobi with a parallel (tournament) ordering, spread over the whole GPU: the eigensolver of rounds 2-4 for
+// 256 < n <= 4096 (the n x n Gram problem of PODProjector.py:812-833, la.eigh there).  Launch-bound; since round 5 the default
+// is the blocked tridiagonalisation + divide and conquer of hfmi_eig_blocked.hip, and this one stays behind
+// HFMI_EIG_LARGE=jacobi as the A/B partner and as an independent check of it on the device.
 //
 // A round of the tournament holds n/2 disjoint index pairs (p, q).  T <- J^T T J with J the product of the round's
 // plane rotations is applied in two launches: (1) one workgroup per pair computes its rotation from T_pp, T_qq, T_pq
@@ -90,7 +90,7 @@ __global__ void k_diag_large(const double* __restrict__ T, int64_t ld, int n, do
 
 // host_T: n x n row-major symmetric (the symmetric part is used); host_d: n eigenvalues descending (by |d| if
 // sort_by_abs); host_V: n x n row-major, eigenvectors in the columns (may be null).
-int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V) {
+int sym_eig_large_jacobi(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V) {
   if (n > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds 4096", n);
   const int64_t ld = round_up(n, 32);
   std::vector<double> A((size_t)ld * n, 0.0);      // column-major, symmetrised

@@ -284,7 +284,8 @@ int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int
 // R (k x k, slot_r) = U diag(s) V^T: singular values descending in svals (device), U -> slot_u, V -> slot_v (columns)
 int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, double* svals);
 
-// symmetric eigensolve for 256 < n <= 4096 (hfmi_eig_large.hip): host in, host out
+// symmetric eigensolve for 256 < n <= 4096: host in, host out.  hfmi_eig_blocked.hip (panel tridiagonalisation on the MFMA, divide
+// and conquer, block-reflector back-transformation); HFMI_EIG_LARGE=jacobi selects the two-sided Jacobi of hfmi_eig_large.hip
 int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V);
 
 // micro-benchmarks

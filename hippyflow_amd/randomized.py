@@ -42,16 +42,24 @@ class _ParRandom:
 
     def __init__(self, seed=1, rank=None):
         self.seed = int(seed)
-        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.rank = L.launcher_rank() if rank is None else int(rank)
         self.stream = 0
         self.shared_stream = 0
+        self._keyed_by_collective = False
 
     def reseed(self, seed, stream=0):
         self.seed, self.stream, self.shared_stream = int(seed), int(stream), int(stream)
 
-    def split(self, rank):
-        """Re-key the private draws for this rank of a sample-parallel run (done by the collectives' constructors)."""
+    def split(self, rank, by_collective=False):
+        """Re-key the private draws for this rank of a sample-parallel run.  Called explicitly it always applies.  The FIRST
+        collective a process constructs calls it with ``by_collective=True`` (the world / sample-parallel communicator, as in
+        the reference, where hp.parRandom is seeded per MPI rank); collectives built later -- e.g. over a sub-group in which
+        several processes hold the same group rank -- leave the key alone: re-keying there would collapse private streams
+        onto one key and change the draws in the middle of a run."""
+        if by_collective and self._keyed_by_collective:
+            return
         self.rank = int(rank)
+        self._keyed_by_collective = bool(by_collective)
 
     def key(self, shared):
         return (self.seed & 0xFFFFFFFF) | ((0 if shared else (self.rank + 1) & 0xFFFFFFFF) << 32)

@@ -1,0 +1,32 @@
+"""Wall time of hfmi_sym_eig_small beyond one workgroup (256 < n <= 4096: hfmi_eig_blocked.hip) next to numpy.linalg.eigh on
+the box's host, with the phase split the library prints under HFMI_EIG_LARGE_TIMING=1 (stderr).  Usage:
+python scripts/eig_large_time.py [n ...]; per-kernel times come from the rocprofv3 kernel trace of this script."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import hippyflow_amd as hf  # noqa: E402
+
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 1024, 2048, 4096]
+host = "--no-host" not in sys.argv
+rng = np.random.default_rng(0)
+for n in sizes:
+    X = rng.standard_normal((n, n + 50)) * np.exp(-0.01 * np.arange(n + 50))[None, :]
+    G = X @ X.T
+    d, V = hf.sym_eig_small(G)                  # warm-up: workspace allocation
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d, V = hf.sym_eig_small(G)
+        ts.append(time.perf_counter() - t0)
+    line = "n=%d  sym_eig_small %.2f ms (min of 3; %.2f max)" % (n, 1e3 * min(ts), 1e3 * max(ts))
+    if host:
+        t0 = time.perf_counter()
+        w, _ = np.linalg.eigh(G)
+        th = time.perf_counter() - t0
+        w = w[::-1]
+        line += "  numpy.linalg.eigh %.1f ms  | eig err %.1e  orth %.1e  resid %.1e" % (
+            1e3 * th, np.abs(d - w).max() / w[0], np.abs(V.T @ V - np.eye(n)).max(), np.abs(G @ V - V * d).max() / w[0])
+    print(line, flush=True)

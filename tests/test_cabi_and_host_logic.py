@@ -163,3 +163,30 @@ def test_spectrum_plot_is_optional_cosmetics(tmp_path):
         return
     assert fig is not None and os.path.getsize(out) > 1000
     assert len(fig.axes[0].lines[0].get_ydata()) == 3              # the entries <= 1e-10 are dropped, as in the reference
+
+
+def test_rank_and_device_follow_the_mpi_launchers_too(monkeypatch):
+    """mpirun / srun set neither $RANK nor $LOCAL_RANK (advisor r4): the private Philox key and the default device fall back to the
+    launchers' own variables, and a collective built later over a sub-group does not re-key the generator."""
+    from hippyflow_amd import _lib as L
+    from hippyflow_amd.randomized import _ParRandom
+    for name in L._RANK_VARS + L._LOCAL_RANK_VARS:
+        monkeypatch.delenv(name, raising=False)
+    assert L.launcher_rank() == 0 and L.launcher_local_rank() == 0
+    monkeypatch.setenv("OMPI_COMM_WORLD_RANK", "5")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "1")
+    assert L.launcher_rank() == 5 and L.launcher_local_rank() == 1
+    assert _ParRandom().rank == 5
+    monkeypatch.setenv("SLURM_PROCID", "9")                   # the earlier name in the list wins
+    assert L.launcher_rank() == 5
+    monkeypatch.delenv("OMPI_COMM_WORLD_RANK")
+    assert L.launcher_rank() == 9
+    monkeypatch.setenv("RANK", "2")                           # torchrun's name first
+    assert L.launcher_rank() == 2
+    g = _ParRandom(rank=0)
+    g.split(3, by_collective=True)                            # world / sample-parallel communicator
+    g.split(0, by_collective=True)                            # a sub-group collective built later: ignored
+    assert g.rank == 3
+    k3 = g.key(False)
+    g.split(1)                                                # an explicit split always applies
+    assert g.rank == 1 and g.key(False) != k3 and g.key(True) == _ParRandom(rank=7).key(True)

@@ -1,0 +1,48 @@
+"""The numpy twin of the whole-GPU eigensolver (tests/helpers/eig_blocked_twin.py) against numpy.linalg.eigh: the panel
+recurrences with the lazily finalised W column, the leaf tearing and the block-reflector back-transformation are right
+before a kernel runs.  CPU only."""
+import numpy as np
+import pytest
+
+from tests.helpers import dc_eig_twin as dct
+from tests.helpers import eig_blocked_twin as bt
+
+
+def _cases(n, rng):
+    S = rng.standard_normal((n, n))
+    yield "indefinite", S + S.T
+    X = rng.standard_normal((n, max(2, n // 4)))
+    yield "rank-deficient", X @ X.T
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    yield "graded", (Qm * np.exp(-0.2 * np.arange(n))) @ Qm.T
+    lam = np.repeat(np.arange(1.0, 1.0 + (n + 7) // 8), 8)[:n]
+    yield "clustered", (Qm * lam) @ Qm.T
+    yield "diagonal", np.diag(rng.standard_normal(n))
+    off = rng.standard_normal(n - 1)
+    yield "tridiagonal", np.diag(rng.standard_normal(n)) + np.diag(off, 1) + np.diag(off, -1)
+
+
+@pytest.mark.parametrize("n,nb,leaf", [(45, 8, 12), (97, 16, 20), (130, 32, 40)])
+def test_blocked_twin_matches_eigh(n, nb, leaf):
+    rng = np.random.default_rng(n)
+    for name, T in _cases(n, rng):
+        w, V = bt.eigh_blocked(T, nb=nb, leaf_max=leaf)
+        wr = np.linalg.eigvalsh(T)[::-1]
+        scale = max(np.abs(wr).max(), 1e-300)
+        assert np.abs(w - wr).max() <= 1e-13 * n * scale, name
+        assert np.abs(V.T @ V - np.eye(n)).max() <= 1e-13 * n, name
+        assert np.abs(T @ V - V * w).max() <= 1e-13 * n * scale, name
+
+
+def test_blocked_tridiagonalisation_is_the_unblocked_factorisation():
+    rng = np.random.default_rng(5)
+    n = 70
+    S = rng.standard_normal((n, n))
+    S = S + S.T
+    d, e, Vh, tau = bt.tridiagonalize_blocked(S, 16)
+    d0, e0, V0, tau0 = dct.tridiagonalize(S)
+    assert np.abs(d - d0).max() < 1e-11 and np.abs(e - e0).max() < 1e-11
+    assert np.abs(Vh - V0).max() < 1e-11 and np.abs(tau - tau0).max() < 1e-11
+    # the block reflectors reproduce the product of the single ones
+    Z = rng.standard_normal((n, 9))
+    assert np.abs(bt.back_transform_blocked(Vh, tau, Z, 16) - dct.back_transform(V0, tau0, Z)).max() < 1e-11

@@ -1,0 +1,142 @@
+"""hfmi_sym_eig_small for 256 < n <= 4096 (hfmi_eig_blocked.hip: panel tridiagonalisation on the MFMA, divide and conquer over
+the whole GPU, block-reflector back-transformation) against numpy.linalg.eigh -- what the reference calls at
+PODProjector.py:821 (la.eigh(G)).  Bar: eigenvalues to 1e-12 ||T||, ||V^T V - I|| <= 1e-12,
+residual <= 1e-12 ||T|| (max-abs entries; n eps grows to 9e-13 at n = 4096, so the largest sizes get 4e-12)."""
+import numpy as np
+import pytest
+
+import hippyflow_amd as hf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    if hf.device_count() < 1:
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    return hf.Context.default()
+
+
+def _spectrum_matrix(n, lam, rng):
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return (Qm * lam) @ Qm.T
+
+
+def _check(T, tol):
+    n = T.shape[0]
+    d, V = hf.sym_eig_small(T)
+    w = np.linalg.eigvalsh(0.5 * (T + T.T))[::-1]
+    scale = max(np.abs(w).max(), 1e-300)
+    assert np.all(np.diff(d) <= 0.0)
+    assert np.abs(d - w).max() <= tol * scale
+    assert np.abs(V.T @ V - np.eye(n)).max() <= tol
+    assert np.abs(T @ V - V * d).max() <= tol * scale
+    return d, V
+
+
+@pytest.mark.parametrize("n", [257, 300, 511, 512, 640, 1000, 1024, 2048])
+def test_sym_eig_blocked_random_and_gram(ctx, n):
+    rng = np.random.default_rng(n)
+    tol = 1e-12 if n <= 1024 else 4e-12
+    S = rng.standard_normal((n, n))
+    _check(S + S.T, tol)                                                          # indefinite
+    X = rng.standard_normal((n, n + 50)) * np.exp(-0.01 * np.arange(n + 50))[None, :]
+    _check(X @ X.T, tol)                                                          # Gram matrix, positive definite
+
+
+@pytest.mark.parametrize("n", [384, 1500])
+@pytest.mark.parametrize("kind", ["graded", "clustered", "rank-deficient", "two-clusters", "diagonal", "tridiagonal",
+                                  "block-diagonal", "identity", "zero", "tiny-scale", "huge-scale"])
+def test_sym_eig_blocked_hard_spectra(ctx, n, kind):
+    rng = np.random.default_rng(hash(kind) % 1000 + n)
+    tol = 1e-12 if n <= 1024 else 4e-12
+    if kind == "graded":
+        T = _spectrum_matrix(n, np.exp(-0.05 * np.arange(n)), rng)
+    elif kind == "clustered":
+        T = _spectrum_matrix(n, np.repeat(np.arange(1.0, 1.0 + (n + 15) // 16), 16)[:n], rng)
+    elif kind == "rank-deficient":
+        X = rng.standard_normal((n, n // 5))
+        T = X @ X.T
+    elif kind == "two-clusters":
+        lam = np.where(np.arange(n) < n // 2, 1.0, -1.0) + 1e-13 * rng.standard_normal(n)
+        T = _spectrum_matrix(n, lam, rng)
+    elif kind == "diagonal":
+        T = np.diag(rng.standard_normal(n))
+    elif kind == "tridiagonal":
+        T = np.diag(rng.standard_normal(n)) + np.diag(rng.standard_normal(n - 1), 1)
+        T = T + np.triu(T, 1).T
+    elif kind == "block-diagonal":
+        T = np.zeros((n, n))
+        for a in range(0, n, 37):
+            b = min(n, a + 37)
+            B = rng.standard_normal((b - a, b - a))
+            T[a:b, a:b] = B + B.T
+    elif kind == "identity":
+        T = np.eye(n)
+    elif kind == "zero":
+        T = np.zeros((n, n))
+    elif kind == "tiny-scale":
+        S = rng.standard_normal((n, n))
+        T = (S + S.T) * 1e-150
+    else:
+        S = rng.standard_normal((n, n))
+        T = (S + S.T) * 1e150
+    _check(T, tol)
+
+
+def test_sym_eig_blocked_4096_and_sort_by_abs(ctx):
+    n = 4096
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((n, 600)) * np.exp(-0.01 * np.arange(600))[None, :]
+    G = X @ X.T                                                                    # rank 600: the POD case (few snapshots span)
+    d, V = _check(G, 4e-12)
+    S = rng.standard_normal((n, n))
+    S = S + S.T
+    d2, V2 = hf.sym_eig_small(S, sort_by_abs=True)
+    assert np.all(np.diff(np.abs(d2)) <= 0.0)
+    w = np.linalg.eigvalsh(S)
+    w = w[np.argsort(-np.abs(w), kind="stable")]
+    assert np.abs(d2 - w).max() <= 4e-12 * np.abs(w).max()
+    assert np.abs(S @ V2 - V2 * d2).max() <= 4e-12 * np.abs(w).max()
+
+
+def test_sym_eig_blocked_is_bit_reproducible(ctx):
+    rng = np.random.default_rng(11)
+    n = 777
+    X = rng.standard_normal((n, 200))
+    G = X @ X.T + 1e-3 * np.eye(n)
+    d1, V1 = hf.sym_eig_small(G)
+    d2, V2 = hf.sym_eig_small(G)
+    assert np.array_equal(d1, d2) and np.array_equal(V1, V2)
+
+
+@pytest.mark.parametrize("k", [30, 74, 128, 138, 180, 200, 256])
+@pytest.mark.parametrize("kind", ["diagonal", "tridiagonal", "block-diagonal", "arrow-then-diagonal"])
+def test_sym_eig_small_on_already_reduced_inputs(ctx, k, kind):
+    """Inputs whose columns are (partly) reduced already: the tridiagonalisation kernel of the one-workgroup path then takes its
+    tau == 0 branch, where no barrier of the arithmetic path separates the waves (advisor r4: a race between the flush of
+    reflector j and the forming of reflector j + 1; fixed with a barrier).  PRE (k <= 160) and LDS-row (k > 160) instances."""
+    rng = np.random.default_rng(k)
+    if kind == "diagonal":
+        T = np.diag(rng.standard_normal(k))
+    elif kind == "tridiagonal":
+        T = np.diag(rng.standard_normal(k)) + np.diag(rng.standard_normal(k - 1), 1)
+        T = T + np.triu(T, 1).T
+    elif kind == "block-diagonal":
+        T = np.zeros((k, k))
+        for a in range(0, k, 7):
+            b = min(k, a + 7)
+            B = rng.standard_normal((b - a, b - a))
+            T[a:b, a:b] = B + B.T
+    else:
+        T = np.diag(rng.standard_normal(k))
+        m = k // 3
+        B = rng.standard_normal((m, m))
+        T[:m, :m] = B + B.T                       # a dense leading block, the rest decoupled
+    for _ in range(3):
+        d, V = hf.sym_eig_small(T, method="dc")
+        w = np.linalg.eigvalsh(T)[::-1]
+        scale = np.abs(w).max()
+        assert np.abs(d - w).max() <= 1e-13 * scale * k
+        assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-12
+        assert np.abs(T @ V - V * d).max() <= 1e-13 * scale * k

@@ -146,3 +146,54 @@ def test_missing_librccl_is_reported_not_fatal(tmp_path):
     env = dict(os.environ, HFMI_RCCL_LIB="/nonexistent/librccl.so", HFMI_COMM_TIMEOUT_S="30")
     from hippyflow_amd.launch import spawn_ranks
     assert spawn_ranks([WORKER, str(tmp_path), "payloads"], 2, env=env, timeout=120) == 0
+
+
+def test_a_rank_killed_mid_solve_gives_one_report_and_no_hang(tmp_path):
+    """a rank that dies in the middle of a run takes its peers down at once (they would otherwise sit in the
+    next collective until the communicator's time-out), and the launcher's report says which rank, with every rank's stderr."""
+    from hippyflow_amd.launch import spawn_ranks
+    script = tmp_path / "dies.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import hippyflow_amd as hf\n"
+        "c = hf.NativeCollective.from_env(host_only=True)\n"
+        "a = c.allReduce(np.ones(4), 'sum')\n"
+        "sys.stderr.write('rank %%d after the first collective\\n' %% c.rank()); sys.stderr.flush()\n"
+        "if c.rank() == 1:\n"
+        "    os._exit(7)\n"
+        "print('{\"never\": \"printed\"}') if False else None\n"
+        "c.allReduce(np.ones(4), 'sum')\n"          # the survivors wait here
+        "print('{\"value\": 1}')\n" % ROOT)
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="120")
+    report = {}
+    t0 = time.time()
+    code = spawn_ranks([str(script)], 3, env=env, timeout=100, report=report)
+    assert code == 7 and time.time() - t0 < 60                      # far inside the communicator's time-out
+    assert report["first_failed"] == 1 and report["codes"][1] == 7 and not report["timed_out"]
+    assert set(report["stopped"]) <= {0, 2}
+    assert "after the first collective" in report["stderr_tail"]["1"]
+    assert "value" not in report["stdout_rank0"]                    # rank 0 never got to its line
+
+
+def test_bench_multi_gpu_failure_is_one_json_error_line():
+    """`python bench.py --gpus 2` where the ranks cannot run (no GPU in this container): ONE JSON line with "error", the ranks'
+    exit codes and stderr tails, a non-zero exit code, no hang."""
+    import json
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--quick"],
+                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                         env=dict(os.environ, HFMI_BENCH_TIMEOUT_S="200"))
+    try:
+        import hippyflow_amd as hf
+        if hf.device_count() > 0:
+            pytest.skip("a GPU is visible here: this run succeeds")
+    except Exception:
+        pass
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert res.returncode != 0 and len(lines) == 1 and time.time() - t0 < 250
+    line = json.loads(lines[0])
+    assert line["value"] is None and "error" in line and line["n_gpus"] == 2
+    assert len(line["rank_exit_codes"]) == 2 and line["communicator"] == "not reached"
+    assert "needs a GPU" in "".join(line["stderr_tail"].values())
