@@ -257,114 +257,129 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
     # style loops like the reference's column-by-column MGS lose to their own fork/join and cross-socket traffic beyond that:
     # 0.81 s at 256 threads against 0.027 s at one, BENCH_r04), and one thread.  The best of each leg is reported.
     per_socket = max(1, min(cores, topo["physical_cores"] // max(1, topo["sockets"])))
-    settings = [("threads_all", cores), ("threads_one_socket_cores", per_socket)]
-    if args.cpu_baseline == "full":
-        settings.append(("threads_1", 1))
+    settings = [("threads_all", cores), ("threads_one_socket_cores", per_socket), ("threads_1", 1)]
+    quick = args.cpu_baseline == "quick"
+    # quick (the extra workloads of a default run): the reference-style leg at one thread only (its level-1 loops are fastest
+    # there on every box seen), the BLAS-3 leg at all threads and at one socket's cores
+    do_ref = {"threads_all": not quick, "threads_one_socket_cores": not quick, "threads_1": True}
+    do_blas3 = {"threads_all": True, "threads_one_socket_cores": True, "threads_1": not quick}
     k = Omega_host.shape[1]
     legs = {"reference_style": {}, "blas3": {}}
     notes = {}
     for label, limit in settings:
         with threadpool_limits(limits=limit):
-            # ------------------------------------------------------------ reference-style leg, on a reduced problem
-            N_s = max(1000, N // 4)
-            k_s = min(8, k)
-            W_s = np.ascontiguousarray(Omega_host[:N_s, :k_s])
-            Z = hp_o.as_block(Omega_host[:N_s])
-            if args.workload == "as":
-                ns_s = max(1, min(8, wl.J.nvec() // wl.q))
-                J_s = wl.J.view(0, ns_s * wl.q).to_vectors()[:, :N_s].reshape(ns_s, wl.q, N_s).copy()
-                op = hf_o.MeanJTJOperator(J_s)
-                units, units_s = wl.ns_total, ns_s
-            elif args.workload == "pod":
-                n_s = 64
-                X_s = wl.X.view(0, n_s).to_vectors()[:, :N_s].copy()
-                op = hf_o.SnapshotGramOperator(X_s)
-                units, units_s = wl.n, n_s
-            else:
-                rows_s = 500
-                C_s = wl.C.view(0, rows_s).to_vectors()[:, :N_s].copy()
+          if do_ref[label]:
+              # ------------------------------------------------------------ reference-style leg, on a reduced problem
+              N_s = max(1000, N // 4)
+              k_s = min(8, k)
+              W_s = np.ascontiguousarray(Omega_host[:N_s, :k_s])
+              Z = hp_o.as_block(Omega_host[:N_s])
+              if args.workload == "as":
+                  ns_s = max(1, min(8, wl.J.nvec() // wl.q))
+                  J_s = wl.J.view(0, ns_s * wl.q).to_vectors()[:, :N_s].reshape(ns_s, wl.q, N_s).copy()
+                  op = hf_o.MeanJTJOperator(J_s)
+                  units, units_s = wl.ns_total, ns_s
+              elif args.workload == "pod":
+                  n_s = 64
+                  X_s = wl.X.view(0, n_s).to_vectors()[:, :N_s].copy()
+                  op = hf_o.SnapshotGramOperator(X_s)
+                  units, units_s = wl.n, n_s
+              else:
+                  rows_s = 500
+                  C_s = wl.C.view(0, rows_s).to_vectors()[:, :N_s].copy()
 
-                class _Rows:                       # rows_s rows of y = C x per call (dense mat-vec, as npToDolfinOperator.mult)
-                    def mult(self, x, y):
-                        y[:rows_s] = C_s @ x
-                op = _Rows()
-                units, units_s = N, rows_s
-            y = np.zeros(N_s)
+                  class _Rows:                       # rows_s rows of y = C x per call (dense mat-vec, as npToDolfinOperator.mult)
+                      def mult(self, x, y):
+                          y[:rows_s] = C_s @ x
+                  op = _Rows()
+                  units, units_s = N, rows_s
+              y = np.zeros(N_s)
 
-            def ref_apply():
-                for j in range(k_s):
-                    op.mult(W_s[:, j], y)
-            _, t_apply = _timed(ref_apply)
-            _, t_mgs = _timed(hp_o.mgs_reortho, Z)
-            T = Z.T @ Z
-            _, t_eig = _timed(np.linalg.eigh, T)
-            U_s = hp_o.new_block(N_s, r)
-            _, t_back = _timed(hp_o.mv_ds_mat_mult, Z, np.ascontiguousarray(T[:, :r]), U_s)
-            fN = N / N_s
-            full_apply = t_apply * (k / k_s) * (units / units_s) * fN       # columns x operator rows x vector length
-            t_ref = 2.0 * full_apply + (t_mgs + t_back) * fN + t_eig
-            legs["reference_style"][label] = {"seconds_full_estimate": t_ref, "value": N * r / t_ref / 1e9,
-                                              "measured_seconds": {"apply": t_apply, "mgs_reortho": t_mgs, "eigh": t_eig, "MvDSmatMult": t_back}}
-            notes["reference_style"] = ("operator applied to %d of %d Omega columns on %d of %d %s at N/%d = %d rows, scaled linearly in "
-                                        "columns, %s and N, x2 applications; MGS with re-orthogonalisation and MvDSmatMult at N/%d scaled "
-                                        "linearly in N; eigh at full k=%d%s"
-                                        % (k_s, k, units_s, units, {"as": "samples", "pod": "snapshots", "kle": "covariance rows"}[args.workload],
-                                           N // N_s, N_s, {"as": "samples", "pod": "snapshots", "kle": "rows"}[args.workload], N // N_s, k,
-                                           "; B / B^-1 applications not included" if (prior is not None or args.workload == "kle") else ""))
-            # ------------------------------------------------------------ BLAS-3 leg, full N, bounded operator sample
-            if args.workload == "as":
-                ns_b = max(1, min(16, wl.J.nvec() // wl.q))     # this rank's share may hold fewer than 16 samples (many ranks, few samples)
-                Jh = wl.J.view(0, ns_b * wl.q).to_vectors()
-                _, t_apply = _timed(lambda: Jh.T @ (Jh @ Omega_host))
-                t_apply *= wl.ns_total / ns_b
-                note_b = "mean-JtJ apply as two GEMMs on %d of %d samples at full N=%d, k=%d, scaled linearly in samples, x2" % (ns_b, wl.ns_total, N, k)
-            elif args.workload == "pod":
-                n_b = 256
-                Xh = wl.X.view(0, n_b).to_vectors()
-                _, t_apply = _timed(lambda: Xh.T @ (Xh @ Omega_host))
-                t_apply *= wl.n / n_b
-                note_b = "snapshot-Gram apply as two GEMMs on %d of %d snapshots at full N, scaled linearly, x2" % (n_b, wl.n)
-            else:
-                rows_b = 4000
-                Ch = wl.C.view(0, rows_b).to_vectors()
-                _, t_c = _timed(lambda: Ch @ Omega_host)
-                _, t_m = _timed(lambda: wl.M @ Omega_host)
-                t_apply = t_c * (N / rows_b) + 2.0 * t_m
-                note_b = "M C M apply: dense C rows GEMM on %d of %d rows scaled linearly + 2 sparse M products, x2" % (rows_b, N)
-            extra = 0.0
-            if args.workload == "kle":
-                import scipy.sparse.linalg as spla
-                lu, t_fac = _timed(lambda: spla.splu(wl.M.tocsc()))
-                _, t_sol = _timed(lambda: lu.solve(np.ascontiguousarray(Omega_host)))
-                _, t_bq = _timed(lambda: hp_o._borth_blas3(Omega_host.copy(order="F"), lambda W: wl.M @ W))
-                extra = t_fac + t_sol + t_bq
-                note_b += "; + splu(M) factorisation, one block solve and the M-orthogonal QR (Householder + 2 Cholesky-QR rounds) at full size"
-            elif prior is not None:
-                _, t_sol = _timed(lambda: prior.Rsolver.solve_block(Omega_host))
-                _, t_bq = _timed(lambda: hp_o._borth_blas3(Omega_host.copy(order="F"), lambda W: prior.R @ W))
-                extra = t_sol + t_bq
-                note_b += "; + one R^-1 block solve (factorisation of A not counted: the prior owns it) and the R-orthogonal QR at full size"
-            else:
-                _, extra = _timed(lambda: hp_o._qr_posdiag(Omega_host))
-                note_b += "; + Householder QR at full size"
-            T = Omega_host[:k].T @ Omega_host[:k]
-            _, t_eig = _timed(np.linalg.eigh, T)
-            _, t_back = _timed(lambda: Omega_host @ T[:, :r])
-            t_b = 2.0 * t_apply + extra + t_eig + t_back
-            legs["blas3"][label] = {"seconds_full_estimate": t_b, "value": N * r / t_b / 1e9}
-            notes["blas3"] = note_b + "; eigh and U = Q V at full size"
+              def ref_apply():
+                  for j in range(k_s):
+                      op.mult(W_s[:, j], y)
+              _, t_apply = _timed(ref_apply)
+              _, t_mgs = _timed(hp_o.mgs_reortho, Z)
+              T = Z.T @ Z
+              _, t_eig = _timed(np.linalg.eigh, T)
+              U_s = hp_o.new_block(N_s, r)
+              _, t_back = _timed(hp_o.mv_ds_mat_mult, Z, np.ascontiguousarray(T[:, :r]), U_s)
+              fN = N / N_s
+              full_apply = t_apply * (k / k_s) * (units / units_s) * fN       # columns x operator rows x vector length
+              t_ref = 2.0 * full_apply + (t_mgs + t_back) * fN + t_eig
+              legs["reference_style"][label] = {"seconds_full_estimate": t_ref, "value": N * r / t_ref / 1e9,
+                                              "scale_factors": {"apply": (k / k_s) * (units / units_s) * fN, "N": fN},
+                                                "measured_seconds": {"apply": t_apply, "mgs_reortho": t_mgs, "eigh": t_eig, "MvDSmatMult": t_back}}
+              notes["reference_style"] = ("operator applied to %d of %d Omega columns on %d of %d %s at N/%d = %d rows, scaled linearly in "
+                                          "columns, %s and N, x2 applications; MGS with re-orthogonalisation and MvDSmatMult at N/%d scaled "
+                                          "linearly in N; eigh at full k=%d%s"
+                                          % (k_s, k, units_s, units, {"as": "samples", "pod": "snapshots", "kle": "covariance rows"}[args.workload],
+                                             N // N_s, N_s, {"as": "samples", "pod": "snapshots", "kle": "rows"}[args.workload], N // N_s, k,
+                                             "; B / B^-1 applications not included" if (prior is not None or args.workload == "kle") else ""))
+          if do_blas3[label]:
+              # ------------------------------------------------------------ BLAS-3 leg, full N, bounded operator sample
+              if args.workload == "as":
+                  ns_b = max(1, min(16, wl.J.nvec() // wl.q))     # this rank's share may hold fewer than 16 samples (many ranks, few samples)
+                  Jh = wl.J.view(0, ns_b * wl.q).to_vectors()
+                  _, t_apply = _timed(lambda: Jh.T @ (Jh @ Omega_host))
+                  t_apply *= wl.ns_total / ns_b
+                  note_b = "mean-JtJ apply as two GEMMs on %d of %d samples at full N=%d, k=%d, scaled linearly in samples, x2" % (ns_b, wl.ns_total, N, k)
+              elif args.workload == "pod":
+                  n_b = 256
+                  Xh = wl.X.view(0, n_b).to_vectors()
+                  _, t_apply = _timed(lambda: Xh.T @ (Xh @ Omega_host))
+                  t_apply *= wl.n / n_b
+                  note_b = "snapshot-Gram apply as two GEMMs on %d of %d snapshots at full N, scaled linearly, x2" % (n_b, wl.n)
+              else:
+                  rows_b = 4000
+                  Ch = wl.C.view(0, rows_b).to_vectors()
+                  _, t_c = _timed(lambda: Ch @ Omega_host)
+                  _, t_m = _timed(lambda: wl.M @ Omega_host)
+                  t_apply = t_c * (N / rows_b) + 2.0 * t_m
+                  note_b = "M C M apply: dense C rows GEMM on %d of %d rows scaled linearly + 2 sparse M products, x2" % (rows_b, N)
+              extra = 0.0
+              if args.workload == "kle":
+                  import scipy.sparse.linalg as spla
+                  lu, t_fac = _timed(lambda: spla.splu(wl.M.tocsc()))
+                  _, t_sol = _timed(lambda: lu.solve(np.ascontiguousarray(Omega_host)))
+                  _, t_bq = _timed(lambda: hp_o._borth_blas3(Omega_host.copy(order="F"), lambda W: wl.M @ W))
+                  extra = t_fac + t_sol + t_bq
+                  note_b += "; + splu(M) factorisation, one block solve and the M-orthogonal QR (Householder + 2 Cholesky-QR rounds) at full size"
+              elif prior is not None:
+                  _, t_sol = _timed(lambda: prior.Rsolver.solve_block(Omega_host))
+                  _, t_bq = _timed(lambda: hp_o._borth_blas3(Omega_host.copy(order="F"), lambda W: prior.R @ W))
+                  extra = t_sol + t_bq
+                  note_b += "; + one R^-1 block solve (factorisation of A not counted: the prior owns it) and the R-orthogonal QR at full size"
+              else:
+                  _, extra = _timed(lambda: hp_o._qr_posdiag(Omega_host))
+                  note_b += "; + Householder QR at full size"
+              T = Omega_host[:k].T @ Omega_host[:k]
+              _, t_eig = _timed(np.linalg.eigh, T)
+              _, t_back = _timed(lambda: Omega_host @ T[:, :r])
+              t_b = 2.0 * t_apply + extra + t_eig + t_back
+              legs["blas3"][label] = {"seconds_full_estimate": t_b, "value": N * r / t_b / 1e9}
+              notes["blas3"] = note_b + "; eigh and U = Q V at full size"
     thread_count = dict(settings)
     best_label = max(legs["blas3"], key=lambda lb: legs["blas3"][lb]["value"])
     best = legs["blas3"][best_label]
     best_ref_label = max(legs["reference_style"], key=lambda lb: legs["reference_style"][lb]["value"])
+    # each component of the reference-style leg at the thread count that suits IT (a user would pin the level-1 loops to one
+    # thread and leave the mat-vecs threaded; the reference itself runs one MPI rank per core): the best composed estimate
+    comp = {}
+    for lb, leg in legs["reference_style"].items():
+        for name, sec in leg["measured_seconds"].items():
+            comp[name] = min(comp.get(name, float("inf")), sec)
+    ref_scale = legs["reference_style"][best_ref_label]["scale_factors"]
+    t_comp = 2.0 * comp["apply"] * ref_scale["apply"] + (comp["mgs_reortho"] + comp["MvDSmatMult"]) * ref_scale["N"] + comp["eigh"]
     return {"value": best["value"], "unit": "GDoF*rank/s", "cores": thread_count[best_label], "kind": "port", "cpu_model": _cpu_model(),
             "threads": topo["threads"], "physical_cores": topo["physical_cores"], "sockets": topo["sockets"],
             "thread_settings": thread_count, "best_setting": best_label,
             "sample": "blas3 leg at %s = %d BLAS threads (the best of %s): %s" % (best_label, thread_count[best_label], ", ".join(thread_count), notes["blas3"]),
             "seconds_full_estimate": best["seconds_full_estimate"],
             "reference_style": dict(legs["reference_style"], sample=notes["reference_style"], best_setting=best_ref_label,
-                                    value=legs["reference_style"][best_ref_label]["value"],
-                                    seconds_full_estimate=legs["reference_style"][best_ref_label]["seconds_full_estimate"]),
+                                    value=max(legs["reference_style"][best_ref_label]["value"], N * r / t_comp / 1e9),
+                                    seconds_full_estimate=min(legs["reference_style"][best_ref_label]["seconds_full_estimate"], t_comp),
+                                    best_per_component_seconds=comp, best_per_component_estimate=t_comp),
             "blas3": dict(legs["blas3"], sample=notes["blas3"])}
 
 

@@ -174,8 +174,8 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   c->nn_upper_hint = false;
   HIP_TRY(hipMalloc((void**)&c->small, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->small, 0, (size_t)SM_NSLOTS * SM_MAXK * SM_LD * sizeof(double), c->stream));
-  HIP_TRY(hipMalloc((void**)&c->status_dev, sizeof(hfmi_status_words)));
-  HIP_TRY(hipMemsetAsync(c->status_dev, 0, sizeof(hfmi_status_words), c->stream));
+  HIP_TRY(hipMalloc((void**)&c->status_dev, 2 * sizeof(hfmi_status_words)));      // [1]: a factorisation taken on trust (qr_chol)
+  HIP_TRY(hipMemsetAsync(c->status_dev, 0, 2 * sizeof(hfmi_status_words), c->stream));
   HIP_TRY(hipHostMalloc((void**)&c->status_host, sizeof(hfmi_status_words), hipHostMallocDefault));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = c;
@@ -1276,6 +1276,9 @@ static int g_comm_panels = -1;    // HFMI_COMM_PANELS: 0 = one all-reduce after 
 // config 4 carried ~32 of them.  Level 2 (default): contractions and phases.  Level 1: only contractions of at least
 // HFMI_PROF_MIN_GFLOP (2.0) Gflop -- what a roofline line needs -- and no phases.
 static int g_prof_level = 2;
+// HFMI_QR_TRUST_FIRST=0 / tuning key "qr_trust_first": the first Cholesky-QR pass of the Gram-form solve waits for its status words
+// (the behaviour up to round 4: one host round trip in the middle of every solve); default 1
+static int g_qr_trust_first = -1;
 int api_tuning_set(const char* key, int value) {
   if (key && !strcmp(key, "comm_panels") && value >= 0 && value <= 8) {
     g_comm_panels = value;
@@ -1283,6 +1286,10 @@ int api_tuning_set(const char* key, int value) {
   }
   if (key && !strcmp(key, "prof_level") && (value == 1 || value == 2)) {
     g_prof_level = value;
+    return 1;
+  }
+  if (key && !strcmp(key, "qr_trust_first") && (value == 0 || value == 1)) {
+    g_qr_trust_first = value;
     return 1;
   }
   return 0;
@@ -1443,11 +1450,14 @@ extern "C" int hfmi_op_apply(hfmi_op* op, const hfmi_block* W, hfmi_block* Y, in
 // copied to pinned memory in stream order and verified by the caller after the synchronisation it needs anyway for the
 // eigenvalues.  If the assumption was wrong the caller repeats the solve on the checked path.  (Two host round trips of ~60 us
 // each per solve: 1.4 % of the 64-sample shard step.)
+static_assert(sizeof(hfmi_status_words) <= 128, "two sets of status words share the first 256 bytes of the late-check buffer");
 struct qr_late_checks {
   bool used;
   hfmi_status_words* st2;   // pinned
   double* aux;              // pinned, SM_LD + k doubles
   int k;
+  hfmi_status_words* st1;   // pinned: status words of the FIRST pass when that one was taken on trust as well
+  bool first_trusted;
 };
 static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* passes_out, bool* deferred = nullptr,
                    qr_late_checks* opt = nullptr) {
@@ -1477,6 +1487,11 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
   int passes = 0;
   const int max_passes = 6;
   bool first_pass_clean = false;
+  if (g_qr_trust_first < 0) {
+    const char* e = getenv("HFMI_QR_TRUST_FIRST");
+    g_qr_trust_first = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool trust_first = g_qr_trust_first != 0;
   for (;;) {
     const hfmi_block* right = Q;
     if (B) {
@@ -1485,10 +1500,28 @@ static int qr_chol(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, bool want_r, int* 
     }
     HFMI_TRY(launch_tsgemm_tn(ctx, Q->p, Q->ld, k, right->p, right->ld, k, N, 1.0, 0.0, sm_ptr(ctx, SM_GRAM), SM_LD, 1, 0));
     const int rtot_mode = (passes == 0) ? 1 : 2;   // always track R = R_p ... R_1: its diagonal exposes dependent columns
+    if (deferred && !B && passes == 0 && opt && trust_first) {
+      // The first pass on trust too: its status words go to their own slot (nothing overwrites them), Q <- Q R^-1 follows at
+      // once and NO host round trip interrupts the solve -- the host runs ahead of the device from here to the final
+      // synchronisation, so the small kernels of the tail are queued back to back.  The words are read with the second
+      // pass's (below); a shifted / failed first pass sends the whole solve to the checked path (double_pass_impl).
+      hfmi_status_words* const keep = ctx->status_dev;
+      ctx->status_dev = keep + 1;
+      const int cs = launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol);
+      ctx->status_dev = keep;
+      HFMI_TRY(cs);
+      HFMI_TRY(launch_nn_upper(ctx, Q->p, Q->ld, k, sm_ptr(ctx, SM_RINV), SM_LD, k, Q->p, Q->ld, N));
+      opt->first_trusted = true;
+      first_pass_clean = true;
+      ++passes;
+      continue;
+    }
     HFMI_TRY(launch_chol_inv(ctx, k, SM_GRAM, SM_R, SM_RINV, SM_RTOT, rtot_mode, want_r ? 1 : 0, shift_rel, pivot_tol));
     hfmi_status_words st;
     if (deferred && !B && passes == 1 && opt && first_pass_clean) {
       HFMI_TRY(side_copies_begin(ctx));
+      if (opt->first_trusted)
+        HIP_TRY(hipMemcpyAsync(opt->st1, ctx->status_dev + 1, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->aux_stream));
       HIP_TRY(hipMemcpyAsync(opt->st2, ctx->status_dev, sizeof(hfmi_status_words), hipMemcpyDeviceToHost, ctx->aux_stream));
       HIP_TRY(hipMemcpyAsync(opt->aux, sm_ptr(ctx, SM_AUX), ((size_t)SM_LD + k) * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
       HFMI_TRY(side_copies_end(ctx));                      // the eigensolver (next writer of the status words) waits for ev_side
@@ -1792,7 +1825,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   };
   HFMI_TRY(power_iterations());
   bool deferred = false;                                   // last Cholesky-QR pass left as R^-1 in SM_RINV
-  qr_late_checks late = {false, nullptr, nullptr, 0};
+  qr_late_checks late = {false, nullptr, nullptr, 0, nullptr, false};
   hfmi_block* Qp = const_cast<hfmi_block*>(cur);           // holds the block to orthogonalise
   hfmi_block* AQ = (Qp == &Q) ? &Y : &Q;
   int ph = phase_begin(ctx, HFMI_PHASE_QR);
@@ -1807,6 +1840,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
       void* pin = nullptr;
       HFMI_TRY(ctx_late_pinned(ctx, &pin));
       late.st2 = (hfmi_status_words*)pin;
+      late.st1 = (hfmi_status_words*)((char*)pin + 128);
       late.aux = (double*)((char*)pin + 256);
     }
     const int qs = qr_chol(Qp, B, nullptr, false, nullptr, gram_path ? &deferred : nullptr, late.st2 ? &late : nullptr);
@@ -1857,6 +1891,7 @@ static int double_pass_impl(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_bl
   if (late.used) {
     // the second orthogonalisation pass was taken on trust: look at what it reported, now that the stream has drained
     bool ok = !late.st2->failed && !late.st2->shifted && late.st2->gram_dev < 1e-2;
+    if (late.first_trusted && (late.st1->failed || late.st1->shifted)) ok = false;
     for (int j = 0; j < late.k && ok; ++j)
       if (!(late.aux[SM_LD + j] > 100.0 * 2.220446049250313e-16 * late.aux[j])) ok = false;
     if (!ok) return double_pass_impl(A, B, Binv, Omega, r, s, flags, host_d, U, false);   // the checked path decides (MGS fall-back, errors)

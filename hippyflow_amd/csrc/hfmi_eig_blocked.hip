@@ -251,62 +251,76 @@ struct tri_args {
   double *dvec, *evec, *tauv;
 };
 
-__device__ __forceinline__ double block_sum_256(double v, double* s_red) {   // fixed order; every thread gets the result
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  const double r = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  __syncthreads();
-  return r;
-}
-
-// rows r = j + blockIdx.x * 256 + tid
-__global__ __launch_bounds__(256) void k_tri_a(tri_args p) {
-  __shared__ double s_x1[EB_NB], s_x2[EB_NB], s_vj[EB_NB], s_wj[EB_NB], s_red[4];
+// 64 rows per workgroup (row r = j + 64 blockIdx.x + lane), the panel columns dealt to the 8 waves (wave w takes k = w, w + 8, ...):
+// every thread has at most 8 (V, W) pairs to fetch and issues all of them before anything waits, so a column costs a couple of
+// memory latencies instead of a 63-step dependent loop; the 8 partial sums of a row meet in LDS and wave 0 finishes the row.
+constexpr int TA_WAVES = 8;
+constexpr int TA_KPT = EB_NB / TA_WAVES;      // panel columns per thread
+__global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
+  __shared__ double s_x1[EB_NB], s_x2[EB_NB], s_vj[EB_NB], s_wj[EB_NB];
+  __shared__ double s_py[TA_WAVES][64], s_pc[TA_WAVES][64];
   __shared__ double s_alpha;
-  const int tid = threadIdx.x, n = p.n, j = p.j, jj = p.jj;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
   const int64_t ld = p.ld;
   const double* __restrict__ Vp = p.Vh + (size_t)p.p0 * ld;
   double* __restrict__ W = p.W;
   const bool fin = (p.mode & 1) && jj > 0, col = (p.mode & 2) != 0;
   const int kf = jj - 1;                       // the column being finalised
+  const int kmax = fin ? kf : jj;              // panel columns that are complete
+  const int r = j + blockIdx.x * 64 + l;
+  const bool live = r < n;
+  // this thread's (V, W) pairs first: nothing below waits for them until the barrier
+  double vv[TA_KPT], ww[TA_KPT];
+#pragma unroll
+  for (int u = 0; u < TA_KPT; ++u) {
+    const int k = w + TA_WAVES * u;
+    const bool ok = live && k < kmax;
+    vv[u] = ok ? Vp[(size_t)r + (size_t)k * ld] : 0.0;
+    ww[u] = ok ? W[(size_t)r + (size_t)k * ld] : 0.0;
+  }
   const double tprev = fin ? p.tauv[j - 1] : 0.0;
-  if (tid < 64) {
+  if (w == 0) {
     if (fin) {
       double s = 0.0;
-      for (int q = tid; q < p.npvy; q += 64) s += p.pvy[q];
+      for (int q = l; q < p.npvy; q += 64) s += p.pvy[q];
+      const double x1v = l < kf ? p.x1[l] : 0.0, x2v = l < kf ? p.x2[l] : 0.0;
+      const double vjk = (col && l < kf) ? Vp[(size_t)j + (size_t)l * ld] : 0.0, wjk = (col && l < kf) ? W[(size_t)j + (size_t)l * ld] : 0.0;
+      const double vjl = col ? Vp[(size_t)j + (size_t)kf * ld] : 0.0, yj = col ? p.ybuf[j] : 0.0;
       const double vy = wave_sum(s);
-      const double x1v = tid < kf ? p.x1[tid] : 0.0, x2v = tid < kf ? p.x2[tid] : 0.0;
-      s_x1[tid] = x1v;
-      s_x2[tid] = x2v;
+      s_x1[l] = x1v;
+      s_x2[l] = x2v;
       const double s12 = wave_sum(x1v * x2v);
       const double alpha = -0.5 * tprev * tprev * (vy - 2.0 * s12);      // -tau/2 (v . w'),  v . w' = tau (v.y - 2 x1.x2)
-      if (tid == 0) s_alpha = alpha;
+      if (l == 0) s_alpha = alpha;
       if (col) {      // row j of V and W, the finalised entry W[j, kf] included: every workgroup computes it for itself
-        const double vjk = tid < kf ? Vp[(size_t)j + (size_t)tid * ld] : 0.0, wjk = tid < kf ? W[(size_t)j + (size_t)tid * ld] : 0.0;
         const double yc = wave_sum(fma(vjk, x2v, wjk * x1v));
-        const double vjl = Vp[(size_t)j + (size_t)kf * ld];
-        const double wjl = fma(tprev, p.ybuf[j] - yc, alpha * vjl);
-        s_vj[tid] = tid < kf ? vjk : (tid == kf ? vjl : 0.0);
-        s_wj[tid] = tid < kf ? wjk : (tid == kf ? wjl : 0.0);
+        const double wjl = fma(tprev, yj - yc, alpha * vjl);
+        s_vj[l] = l < kf ? vjk : (l == kf ? vjl : 0.0);
+        s_wj[l] = l < kf ? wjk : (l == kf ? wjl : 0.0);
       }
     } else if (col) {
-      s_vj[tid] = tid < jj ? Vp[(size_t)j + (size_t)tid * ld] : 0.0;
-      s_wj[tid] = tid < jj ? W[(size_t)j + (size_t)tid * ld] : 0.0;
+      s_vj[l] = l < jj ? Vp[(size_t)j + (size_t)l * ld] : 0.0;
+      s_wj[l] = l < jj ? W[(size_t)j + (size_t)l * ld] : 0.0;
     }
   }
   __syncthreads();
-  const int r = j + blockIdx.x * 256 + tid;
-  const bool live = r < n;
+  double accy = 0.0, accc = 0.0;
+#pragma unroll
+  for (int u = 0; u < TA_KPT; ++u) {
+    const int k = w + TA_WAVES * u;
+    if (k < kmax) {        // wave-uniform
+      if (fin) accy = fma(vv[u], s_x2[k], fma(ww[u], s_x1[k], accy));
+      if (col) accc = fma(vv[u], s_wj[k], fma(ww[u], s_vj[k], accc));
+    }
+  }
+  s_py[w][l] = accy;
+  s_pc[w][l] = accc;
+  __syncthreads();
+  if (w != 0) return;
+  accy = ((s_py[0][l] + s_py[1][l]) + (s_py[2][l] + s_py[3][l])) + ((s_py[4][l] + s_py[5][l]) + (s_py[6][l] + s_py[7][l]));
+  accc = ((s_pc[0][l] + s_pc[1][l]) + (s_pc[2][l] + s_pc[3][l])) + ((s_pc[4][l] + s_pc[5][l]) + (s_pc[6][l] + s_pc[7][l]));
   double colv = 0.0;
   if (live) {
-    const int kmax = fin ? kf : jj;
-    double accy = 0.0, accc = 0.0;
-    for (int k = 0; k < kmax; ++k) {
-      const double v = Vp[(size_t)r + (size_t)k * ld], wv = W[(size_t)r + (size_t)k * ld];
-      if (fin) accy = fma(v, s_x2[k], fma(wv, s_x1[k], accy));
-      if (col) accc = fma(v, s_wj[k], fma(wv, s_vj[k], accc));
-    }
     if (fin) {
       const double vr = Vp[(size_t)r + (size_t)kf * ld];
       const double wr = fma(tprev, p.ybuf[r] - accy, s_alpha * vr);
@@ -320,8 +334,8 @@ __global__ __launch_bounds__(256) void k_tri_a(tri_args p) {
     }
   }
   if (col) {
-    const double part = block_sum_256((live && r >= j + 2) ? colv * colv : 0.0, s_red);
-    if (tid == 0) p.pn[blockIdx.x] = part;
+    const double part = wave_sum((live && r >= j + 2) ? colv * colv : 0.0);
+    if (l == 0) p.pn[blockIdx.x] = part;
   }
 }
 
@@ -332,8 +346,7 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
   const int64_t ld = p.ld;
   const int rs = (j + 1) & ~63;
-  double xn2 = 0.0;
-  for (int q = 0; q < p.npn; ++q) xn2 += p.pn[q];
+  const double xn2 = wave_sum(l < p.npn ? p.pn[l] : 0.0);       // at most 64 partial sums (one per 64 rows), one per lane
   const double alpha0 = p.colbuf[j + 1];
   double tau = 0.0, beta = alpha0, scl = 0.0;
   if (xn2 > 1e-280) {      // entries are scaled to O(1): below this the column is zero to any precision that matters
@@ -461,54 +474,62 @@ __global__ __launch_bounds__(1024) void k_dcl_z(dcl_args p) {
     p.nodes[node] = nd;
   }
 }
-// ascending rank of every pole inside its node (ties by column), components below the tolerance drop out (dlaed2's first test)
+// ascending rank of every pole inside its node (ties by column), components below the tolerance drop out (dlaed2's first test).
+// 64 poles per workgroup, the comparison partners dealt to its 4 waves (n / 64 workgroups: a level keeps many CUs busy).
 __global__ __launch_bounds__(256) void k_dcl_rank(dcl_args p) {
-  __shared__ double s_d[256], s_z[256];
-  const int n = p.n, L = p.L, tid = threadIdx.x;
-  const int t = blockIdx.x * 256 + tid;
+  __shared__ double s_d[256];
+  __shared__ unsigned char s_live[256];
+  __shared__ int s_cnt[3][4][64];
+  const int n = p.n, L = p.L, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x * 64 + l;
   const bool valid = t < n;
   int node = 0, lo = 0, mid = 0, hi = 0;
   if (valid) dcl_range(n, L, t, node, lo, mid, hi);
   int ulo, uhi;
   {
-    const int t_first = blockIdx.x * 256, t_last = min(n, t_first + 256) - 1;
+    const int t_first = blockIdx.x * 64, t_last = min(n, t_first + 64) - 1;
     int nd, a, m, b;
     dcl_range(n, L, t_first, nd, a, m, b);
     ulo = a;
     dcl_range(n, L, t_last, nd, a, m, b);
     uhi = b;
   }
-  double dt = 0.0, zt = 0.0, rho = 0.0, thr = 0.0;
-  if (valid) {
-    dt = p.D[t];
-    zt = p.Zv[t];
-    rho = p.nodes[node].rho;
-    thr = p.nodes[node].skip ? INFINITY : p.nodes[node].tol;
-  }
+  const double dt = valid ? p.D[t] : 0.0;
   int rank = 0, pre = 0, cnt = 0;
   for (int base = ulo; base < uhi; base += 256) {
     const int u = base + tid;
     if (u < uhi) {
+      int nu, a, m, b;
+      dcl_range(n, L, u, nu, a, m, b);
+      const dcl_node& nd = p.nodes[nu];
       s_d[tid] = p.D[u];
-      s_z[tid] = p.Zv[u];
+      s_live[tid] = (nd.skip || nd.rho * fabs(p.Zv[u]) <= nd.tol) ? 0 : 1;
     }
     __syncthreads();
-    const int m = min(256, uhi - base);
     if (valid) {
-      const int q0 = max(0, lo - base), q1 = min(m, hi - base);
-      for (int q = q0; q < q1; ++q) {
-        const double du = s_d[q], zu = s_z[q];
+      const int q0 = max(0, lo - base), q1 = min(min(256, uhi - base), hi - base);
+      for (int q = q0 + w; q < q1; q += 4) {
+        const double du = s_d[q];
+        const int live = s_live[q];
         const bool before = du < dt || (du == dt && base + q < t);
-        const bool live = !(rho * fabs(zu) <= thr);
         rank += before ? 1 : 0;
-        pre += (before && live) ? 1 : 0;
-        cnt += live ? 1 : 0;
+        pre += before ? live : 0;
+        cnt += live;
       }
     }
     __syncthreads();
   }
-  if (valid) {
-    const bool live_t = !(rho * fabs(zt) <= thr);
+  s_cnt[0][w][l] = rank;
+  s_cnt[1][w][l] = pre;
+  s_cnt[2][w][l] = cnt;
+  __syncthreads();
+  if (w == 0 && valid) {
+    rank = (s_cnt[0][0][l] + s_cnt[0][1][l]) + (s_cnt[0][2][l] + s_cnt[0][3][l]);
+    pre = (s_cnt[1][0][l] + s_cnt[1][1][l]) + (s_cnt[1][2][l] + s_cnt[1][3][l]);
+    cnt = (s_cnt[2][0][l] + s_cnt[2][1][l]) + (s_cnt[2][2][l] + s_cnt[2][3][l]);
+    const dcl_node& nd = p.nodes[node];
+    const double zt = p.Zv[t];
+    const bool live_t = !(nd.skip || nd.rho * fabs(zt) <= nd.tol);
     p.Ds[lo + rank] = dt;
     p.Zs[lo + rank] = zt;
     p.Col[lo + rank] = t;
@@ -735,15 +756,18 @@ __global__ __launch_bounds__(256) void k_dcl_gather(dcl_args p) {
 }
 
 // ------------------------------------------------------------------------------------------------ block reflectors
-// triangular factor of a panel from its Gram matrix (LAPACK dlarft, forward, columnwise): T[i][i] = tau_i,
-// T[0:i, i] = -tau_i T[0:i, 0:i] (V^T v_i).  One wave per panel.
+// triangular factor of a 64-column panel from its Gram matrix (LAPACK dlarft, forward, columnwise): T[i][i] = tau_i,
+// T[0:i, i] = -tau_i T[0:i, 0:i] (V^T v_i).  One wave per panel.  The panels are the diagonal 64 x 64 blocks of the EB_WY-wide
+// block reflectors: panel p lives at offset (p % 4) * 64 on the diagonal of block p / 4 of G and T (leading dimension EB_WY).
+constexpr int EB_WY = 256;         // width of a block reflector of the back-transformation
 __global__ __launch_bounds__(64) void k_larft(const double* __restrict__ G, const double* __restrict__ tauv, double* __restrict__ Tf) {
   __shared__ double s_t[EB_NB][EB_NB + 1], s_g[EB_NB];
   const int r = threadIdx.x;
-  const double* g = G + (size_t)blockIdx.x * EB_NB * EB_NB;
+  const size_t off = (size_t)(blockIdx.x / (EB_WY / EB_NB)) * EB_WY * EB_WY + (size_t)(blockIdx.x % (EB_WY / EB_NB)) * EB_NB * (EB_WY + 1);
+  const double* g = G + off;
   for (int c = 0; c < EB_NB; ++c) s_t[r][c] = 0.0;
   for (int i = 0; i < EB_NB; ++i) {
-    s_g[r] = g[r + i * EB_NB];           // column i of the Gram matrix: v_c . v_i
+    s_g[r] = g[r + (size_t)i * EB_WY];     // column i of the Gram matrix: v_c . v_i
     __syncthreads();
     const double ti = tauv[blockIdx.x * EB_NB + i];
     double v = 0.0;
@@ -757,8 +781,8 @@ __global__ __launch_bounds__(64) void k_larft(const double* __restrict__ G, cons
     s_t[r][i] = v;
     __syncthreads();
   }
-  double* t = Tf + (size_t)blockIdx.x * EB_NB * EB_NB;
-  for (int c = 0; c < EB_NB; ++c) t[r + c * EB_NB] = s_t[r][c];
+  double* tf = Tf + off;
+  for (int c = 0; c < EB_NB; ++c) tf[r + (size_t)c * EB_WY] = s_t[r][c];
 }
 // out (row-major n x n) [i][pos] = Z[i, order[pos]]: permutation of the columns + transposition through LDS
 __global__ __launch_bounds__(256) void k_out(const double* __restrict__ Z, int64_t ld, int n, const int* __restrict__ order,
@@ -813,12 +837,12 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   if (jacobi || n < 3) return sym_eig_large_jacobi(ctx, host_T, n, sort_by_abs, host_d, host_V);
   const int NB = EB_NB;
   const int64_t ld = round_up(n, 128);
-  const int npad = (int)round_up(n, NB), npanels = npad / NB;
+  const int npad = (int)round_up(n, EB_WY), npanels = npad / NB, nblk = npad / EB_WY;
   const size_t mat = (size_t)ld * npad;
   const size_t vlen = (size_t)npad + 128;
   // ---- workspace
   const size_t n_mats = 5;
-  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)NB * npad + 2 * (size_t)npanels * NB * NB + 16 * vlen + 2 * 64 + 64 + 512 +
+  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)EB_WY * npad + 3 * (size_t)nblk * EB_WY * EB_WY + 16 * vlen + 2 * 64 + 64 + 512 +
                          (size_t)(npad / 32 + 1) * (npad / 32 + 1);
   const size_t i_count = 8 * vlen + 64;
   const size_t bytes = d_count * sizeof(double) + i_count * sizeof(int) + 64 * sizeof(dcl_node) + 256;
@@ -836,9 +860,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   double* Q2 = take(mat);
   double* Qg = take(mat);       // raw upload first, gathered columns of the merges, nothing afterwards
   double* Wp = take((size_t)ld * NB);
-  double* W1 = take((size_t)NB * npad);
-  double* Gm = take((size_t)npanels * NB * NB);
-  double* Tf = take((size_t)npanels * NB * NB);
+  double* W1 = take((size_t)EB_WY * npad);
+  double* Gm = take((size_t)nblk * EB_WY * EB_WY);
+  double* Tf = take((size_t)nblk * EB_WY * EB_WY);
+  double* Tt = take((size_t)nblk * EB_WY * EB_WY);      // products in flight while the triangular factors are merged
   double* colbuf = take(vlen);
   double* ybuf = take(vlen);
   double* dvec = take(vlen);
@@ -857,7 +882,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   double* rs = take(vlen);
   double* x1 = take(64);
   double* x2 = take(64);
-  double* pn = take(64);
+  double* pn = take(64);           // one partial norm per 64 rows: at most 64
   double* pvy = take(512);
   double* pmax = take((size_t)(npad / 32 + 1) * (npad / 32 + 1));
   int* ip = (int*)dp;
@@ -924,9 +949,9 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         ta.j = j;
         ta.jj = jj;
         ta.mode = 3;
-        const int ga = (n - j + 255) / 256;
+        const int ga = (n - j + 63) / 64;
         ta.npn = ga;
-        hipLaunchKernelGGL(k_tri_a, dim3(ga), dim3(256), 0, st, ta);
+        hipLaunchKernelGGL(k_tri_a, dim3(ga), dim3(64 * TA_WAVES), 0, st, ta);
         const int nc = (n - j - 1) + 2 * jj;
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
@@ -937,7 +962,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       ta.j = t0;
       ta.jj = ncols;
       ta.mode = 1;
-      hipLaunchKernelGGL(k_tri_a, dim3((n - t0 + 255) / 256), dim3(256), 0, st, ta);
+      hipLaunchKernelGGL(k_tri_a, dim3((n - t0 + 63) / 64), dim3(64 * TA_WAVES), 0, st, ta);
       HIP_TRY(hipGetLastError());
       // A[t0:, t0:] -= V W^T + W V^T
       gemm_desc g;
@@ -1003,7 +1028,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       da.Q = Qcur;
       da.Qout = Qnext;
       hipLaunchKernelGGL(k_dcl_z, dim3(nn), dim3(1024), 0, st, da);
-      hipLaunchKernelGGL(k_dcl_rank, dim3((n + 255) / 256), dim3(256), 0, st, da);
+      hipLaunchKernelGGL(k_dcl_rank, dim3((n + 63) / 64), dim3(256), 0, st, da);
       const int cap = (int)round_up((n + nn - 1) / nn + 1, 64);
       const size_t defl_lds = (size_t)cap * 26;
       HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
@@ -1053,50 +1078,80 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   for (int jx = 0; jx < n; ++jx) host_d[jx] = ldexp(lam[perm[jx]], hfail[1]);
   if (!host_V) return HFMI_OK;
 
-  // ---- back-transformation: Z <- (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) Z
+  // ---- back-transformation: Z <- (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) Z with block reflectors of EB_WY = 256
+  // columns (four panels): 64-column products V^T Z would be 64 tiles on 256 compute units.  The triangular factor of a block is
+  // assembled from those of its panels: [V_a V_b] has T = [[T_a, -T_a (V_a^T V_b) T_b], [0, T_b]] (twice: 64 -> 128 -> 256).
   {
     double* Z = Qcur;
     double* Y = A;
+    const int64_t sWY = (int64_t)EB_WY * EB_WY;
     gemm_desc g;
-    g.ta = true;                 // Gram matrices of all panels
+    g.ta = true;                 // Gram matrices of all blocks
     g.tb = false;
-    g.M = g.N = NB;
+    g.M = g.N = EB_WY;
     g.K = n;
     g.alpha = 1.0;
     g.beta = 0.0;
     g.A = g.B = Vh;
     g.lda = g.ldb = ld;
     g.C = Gm;
-    g.ldc = NB;
-    g.batch = npanels;
-    g.sA = g.sB = (int64_t)NB * ld;
-    g.sC = (int64_t)NB * NB;
+    g.ldc = EB_WY;
+    g.batch = nblk;
+    g.sA = g.sB = (int64_t)EB_WY * ld;
+    g.sC = sWY;
     HFMI_TRY(launch_dgemm(ctx, g));
+    HIP_TRY(hipMemsetAsync(Tf, 0, (size_t)nblk * sWY * sizeof(double), st));
     hipLaunchKernelGGL(k_larft, dim3(npanels), dim3(64), 0, st, Gm, tauv, Tf);
     HIP_TRY(hipGetLastError());
-    gemm_desc gy;                // Y_p = V_p T_p
+    for (int w = NB; w < EB_WY; w *= 2) {              // merge neighbours of width w into width 2 w
+      for (int a0 = 0; a0 + 2 * w <= EB_WY; a0 += 2 * w) {
+        const size_t offTa = (size_t)a0 * (EB_WY + 1), offTb = (size_t)(a0 + w) * (EB_WY + 1);
+        const size_t offX = (size_t)a0 + (size_t)(a0 + w) * EB_WY;          // rows of a, columns of b
+        gemm_desc m1;            // tmp = (V_a^T V_b) T_b
+        m1.ta = m1.tb = false;
+        m1.M = m1.N = m1.K = w;
+        m1.alpha = 1.0;
+        m1.beta = 0.0;
+        m1.A = Gm + offX;
+        m1.lda = EB_WY;
+        m1.B = Tf + offTb;
+        m1.ldb = EB_WY;
+        m1.C = Tt + offX;
+        m1.ldc = EB_WY;
+        m1.batch = nblk;
+        m1.sA = m1.sB = m1.sC = sWY;
+        HFMI_TRY(launch_dgemm(ctx, m1));
+        gemm_desc m2 = m1;       // T_ab = -T_a tmp
+        m2.alpha = -1.0;
+        m2.A = Tf + offTa;
+        m2.B = Tt + offX;
+        m2.C = Tf + offX;
+        HFMI_TRY(launch_dgemm(ctx, m2));
+      }
+    }
+    gemm_desc gy;                // Y = V T, every block
     gy.ta = gy.tb = false;
     gy.M = n;
-    gy.N = gy.K = NB;
+    gy.N = gy.K = EB_WY;
     gy.alpha = 1.0;
     gy.beta = 0.0;
     gy.A = Vh;
     gy.lda = ld;
     gy.B = Tf;
-    gy.ldb = NB;
+    gy.ldb = EB_WY;
     gy.C = Y;
     gy.ldc = ld;
-    gy.batch = npanels;
-    gy.sA = gy.sC = (int64_t)NB * ld;
-    gy.sB = (int64_t)NB * NB;
+    gy.batch = nblk;
+    gy.sA = gy.sC = (int64_t)EB_WY * ld;
+    gy.sB = sWY;
     HFMI_TRY(launch_dgemm(ctx, gy));
-    for (int pi = npanels - 1; pi >= 0; --pi) {
-      const int p0 = pi * NB, r0 = p0 + 1;
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+      const int p0 = bi * EB_WY, r0 = p0 + 1;
       if (r0 >= n || p0 >= n - 2) continue;
-      gemm_desc g1;              // W1 = V_p^T Z   (rows r0 ..)
+      gemm_desc g1;              // W1 = V^T Z   (rows r0 ..)
       g1.ta = true;
       g1.tb = false;
-      g1.M = NB;
+      g1.M = EB_WY;
       g1.N = n;
       g1.K = n - r0;
       g1.alpha = 1.0;
@@ -1106,19 +1161,19 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       g1.B = Z + r0;
       g1.ldb = ld;
       g1.C = W1;
-      g1.ldc = NB;
+      g1.ldc = EB_WY;
       HFMI_TRY(launch_dgemm(ctx, g1));
-      gemm_desc g2;              // Z -= Y_p W1
+      gemm_desc g2;              // Z -= Y W1
       g2.ta = g2.tb = false;
       g2.M = n - r0;
       g2.N = n;
-      g2.K = NB;
+      g2.K = EB_WY;
       g2.alpha = -1.0;
       g2.beta = 1.0;
       g2.A = Y + (size_t)p0 * ld + r0;
       g2.lda = ld;
       g2.B = W1;
-      g2.ldb = NB;
+      g2.ldb = EB_WY;
       g2.C = Z + r0;
       g2.ldc = ld;
       HFMI_TRY(launch_dgemm(ctx, g2));

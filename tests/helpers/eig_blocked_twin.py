@@ -102,15 +102,40 @@ def wy_factor(V, tau):
     return Tf
 
 
-def back_transform_blocked(Vh, tau, Z, nb=64):
-    """(H_0 H_1 ... H_{n-3}) Z, panel by panel from the last: Z <- Z - (V Tf) (V^T Z)."""
+def wy_factor_merged(V, tau, nb):
+    """The triangular factor of a block of several panels, assembled as the kernels do it: dlarft on the diagonal nb x nb
+    blocks, then neighbours merged pairwise, [V_a V_b] -> [[T_a, -T_a (V_a^T V_b) T_b], [0, T_b]], width nb -> 2 nb -> ..."""
+    b = V.shape[1]
+    assert b % nb == 0 and ((b // nb) & (b // nb - 1)) == 0
+    G = V.T @ V
+    Tf = np.zeros((b, b))
+    for a in range(0, b, nb):
+        Tf[a:a + nb, a:a + nb] = wy_factor(V[:, a:a + nb], tau[a:a + nb])
+    w = nb
+    while w < b:
+        for a in range(0, b, 2 * w):
+            Ta, Tb = Tf[a:a + w, a:a + w], Tf[a + w:a + 2 * w, a + w:a + 2 * w]
+            Tf[a:a + w, a + w:a + 2 * w] = -Ta @ (G[a:a + w, a + w:a + 2 * w] @ Tb)
+        w *= 2
+    return Tf
+
+
+def back_transform_blocked(Vh, tau, Z, nb=64, panels_per_block=4):
+    """(H_0 H_1 ... H_{n-3}) Z, block reflector by block reflector from the last: Z <- Z - (V Tf) (V^T Z); a block is
+    ``panels_per_block`` panels of nb columns (columns beyond n - 3 are zero reflectors with tau = 0)."""
     n = Z.shape[0]
     Z = Z.copy()
-    starts = list(range(0, max(n - 2, 0), nb))
-    for p0 in reversed(starts):
-        b = min(nb, n - 2 - p0)
-        V = Vh[:, p0:p0 + b]
-        Y = V @ wy_factor(V, tau[p0:p0 + b])
+    wb = nb * panels_per_block
+    npad = -(-n // wb) * wb
+    Vp = np.zeros((n, npad))
+    Vp[:, :n] = Vh
+    tp = np.zeros(npad)
+    tp[:n] = tau
+    for p0 in reversed(range(0, npad, wb)):
+        if p0 >= n - 2:
+            continue
+        V = Vp[:, p0:p0 + wb]
+        Y = V @ wy_factor_merged(V, tp[p0:p0 + wb], nb)
         r = slice(p0 + 1, n)
         Z[r, :] -= Y[r, :] @ (V[r, :].T @ Z[r, :])
     return Z

@@ -5,7 +5,9 @@
           rather than walk away with a half-reduced one.
   panels  a Gram-form fused solve with at least two rounds of row tiles, so that the rank reduction runs panel by panel on
           the auxiliary stream across REAL peers; the result with 4 panels must equal the result with one all-reduce bit for
-          bit, on every rank."""
+          bit, on every rank.
+  soak    200 block all-reduces in a row (alternating sum / avg, two block sizes) of the same rank-specific inputs: every
+          repetition must give the bits of the first one, on every rank (fixed summation order of the p2p reduction)."""
 import json
 import os
 import sys
@@ -64,6 +66,30 @@ def main():
             out[panels] = (d, U.to_dense()[:4000].copy(), ctx.profile_phases()["allreduce_overlapped"])
         np.savez(os.path.join(outdir, "panels_rank%d.npz" % rank), d0=out[0][0], U0=out[0][1], d4=out[4][0], U4=out[4][1],
                  overlapped0=out[0][2], overlapped4=out[4][2], transport=coll.transport, p2p_sync=res["p2p_sync"])
+        coll.barrier()
+        coll.close()
+        return 0
+    if mode == "soak":
+        import hashlib
+        reps = int(os.environ.get("HFMI_TEST_SOAK_REPS", "200"))
+        shapes = [(100003, 7), (33333, 74)]
+        srcs = []
+        for i, (N, k) in enumerate(shapes):
+            X = hf.MultiVector(N, k, ctx=ctx)
+            _ParRandom(70 + 10 * i + rank).normal(1.0, X)
+            srcs.append(X)
+        first, same = {}, True
+        for rep in range(reps):
+            i, op = rep & 1, ("sum", "avg")[(rep >> 1) & 1]
+            Y = hf.MultiVector(srcs[i])                     # a fresh copy of this rank's input
+            coll.allReduce(Y, op)
+            digest = hashlib.sha256(np.ascontiguousarray(Y.to_dense()).tobytes()).hexdigest()
+            if (i, op) in first:
+                same = same and first[(i, op)] == digest
+            else:
+                first[(i, op)] = digest
+        with open(os.path.join(outdir, "soak_rank%d.json" % rank), "w") as f:
+            json.dump(dict(res, reps=reps, same=bool(same), digests={"%d%s" % key: v for key, v in first.items()}), f)
         coll.barrier()
         coll.close()
         return 0

@@ -171,3 +171,16 @@ def test_row_panels_across_real_peers_are_bit_identical(tmp_path, world):
         assert float(r["overlapped0"]) == 0.0 and float(r["overlapped4"]) > 0.0
         np.testing.assert_array_equal(r["d4"], rs[0]["d4"])
         np.testing.assert_array_equal(r["U4"], rs[0]["U4"])
+
+
+def test_p2p_reduction_is_bit_identical_over_200_repetitions(tmp_path):
+    """Determinism soak: 4 ranks sharing the GPU, stream-ordered p2p, 200 all-reduces of the same inputs --
+    every repetition and every rank ends with the bits of the first one."""
+    import json
+    from hippyflow_amd.launch import spawn_ranks
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="120", HFMI_P2P_SYNC="stream")
+    assert spawn_ranks([WORKER2, str(tmp_path), "soak"], 4, env=env, timeout=900) == 0
+    rs = [json.load(open(os.path.join(str(tmp_path), "soak_rank%d.json" % r))) for r in range(4)]
+    for r in rs:
+        assert r["transport"] == "p2p" and r["p2p_sync"] == "stream" and r["reps"] == 200
+        assert r["same"] and r["digests"] == rs[0]["digests"] and len(r["digests"]) == 4
