@@ -285,7 +285,7 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
                   op = hf_o.SnapshotGramOperator(X_s)
                   units, units_s = wl.n, n_s
               else:
-                  rows_s = 500
+                  rows_s = min(500, N)
                   C_s = wl.C.view(0, rows_s).to_vectors()[:, :N_s].copy()
 
                   class _Rows:                       # rows_s rows of y = C x per call (dense mat-vec, as npToDolfinOperator.mult)
@@ -331,7 +331,7 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
                   t_apply *= wl.n / n_b
                   note_b = "snapshot-Gram apply as two GEMMs on %d of %d snapshots at full N, scaled linearly, x2" % (n_b, wl.n)
               else:
-                  rows_b = 4000
+                  rows_b = min(4000, N)
                   Ch = wl.C.view(0, rows_b).to_vectors()
                   _, t_c = _timed(lambda: Ch @ Omega_host)
                   _, t_m = _timed(lambda: wl.M @ Omega_host)

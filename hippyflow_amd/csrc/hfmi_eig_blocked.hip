@@ -279,10 +279,23 @@ __global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
     ww[u] = ok ? W[(size_t)r + (size_t)k * ld] : 0.0;
   }
   const double tprev = fin ? p.tauv[j - 1] : 0.0;
+  // ... and what wave 0 needs to finish the row: requested now, used after the second barrier
+  double vr_pre = 0.0, y_pre = 0.0, a_pre = 0.0;
+  if (w == 0 && live) {
+    if (fin) {
+      vr_pre = Vp[(size_t)r + (size_t)kf * ld];
+      y_pre = p.ybuf[r];
+    }
+    if (col) a_pre = p.A[(size_t)r + (size_t)j * ld];
+  }
   if (w == 0) {
     if (fin) {
-      double s = 0.0;
-      for (int q = l; q < p.npvy; q += 64) s += p.pvy[q];
+      // up to 512 partial sums of v . y: eight loads per lane, all in flight at once (a loop over a run-time count waits for
+      // every load before it issues the next: 8 x an L2 round trip per column at n = 4096)
+      double s8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] = (l + 64 * u < p.npvy) ? p.pvy[l + 64 * u] : 0.0;
+      const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
       const double x1v = l < kf ? p.x1[l] : 0.0, x2v = l < kf ? p.x2[l] : 0.0;
       const double vjk = (col && l < kf) ? Vp[(size_t)j + (size_t)l * ld] : 0.0, wjk = (col && l < kf) ? W[(size_t)j + (size_t)l * ld] : 0.0;
       const double vjl = col ? Vp[(size_t)j + (size_t)kf * ld] : 0.0, yj = col ? p.ybuf[j] : 0.0;
@@ -322,13 +335,13 @@ __global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
   double colv = 0.0;
   if (live) {
     if (fin) {
-      const double vr = Vp[(size_t)r + (size_t)kf * ld];
-      const double wr = fma(tprev, p.ybuf[r] - accy, s_alpha * vr);
+      const double vr = vr_pre;
+      const double wr = fma(tprev, y_pre - accy, s_alpha * vr);
       W[(size_t)r + (size_t)kf * ld] = wr;
       if (col) accc = fma(vr, s_wj[kf], fma(wr, s_vj[kf], accc));
     }
     if (col) {
-      colv = p.A[(size_t)r + (size_t)j * ld] - accc;
+      colv = a_pre - accc;
       p.colbuf[r] = colv;
       if (r == j) p.dvec[j] = colv;
     }
@@ -340,14 +353,42 @@ __global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
 }
 
 // 512 threads; dynamic LDS: v on rows [rs, ld), rs = (j + 1) rounded down to 64
+template <int UNR>
 __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   extern __shared__ __attribute__((aligned(16))) double s_v[];
   __shared__ double s_part[8];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
   const int64_t ld = p.ld;
   const int rs = (j + 1) & ~63;
-  const double xn2 = wave_sum(l < p.npn ? p.pn[l] : 0.0);       // at most 64 partial sums (one per 64 rows), one per lane
+  const int nA = n - j - 1, nc = nA + 2 * jj;
+  const int npair = ((int)ld - rs) >> 1;
+  auto column = [&](int q) -> const d2* {
+    const double* colp;
+    if (q < nA) colp = p.A + (size_t)(j + 1 + q) * ld;
+    else if (q < nA + jj) colp = p.Vh + (size_t)(p.p0 + q - nA) * ld;
+    else colp = p.W + (size_t)(q - nA - jj) * ld;
+    return (const d2*)(colp + rs);
+  };
+  // the first 2 KB of this wave's first column are requested before anything else: they do not depend on the reflector, and
+  // at n <= 1024 (a column is one or two such requests) the kernel is a chain of memory round trips -- this one now runs
+  // beside those of the reflector scalars and of v
+  const int qfirst = blockIdx.x * 8 + w;
+  d2 pre[4];
+  {
+    const d2* __restrict__ c2 = column(qfirst < nc ? qfirst : 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pre[u] = (qfirst < nc && l + 64 * u < npair) ? c2[l + 64 * u] : d2{0.0, 0.0};
+  }
+  // column j of the reduced matrix: every load of it is requested before the first use (a loop over a run-time count would wait
+  // for each load before issuing the next: 8 x an L2 round trip per column at n = 4096)
+  double cb[EB_MAXN / 512];
+#pragma unroll
+  for (int u = 0; u < EB_MAXN / 512; ++u) {
+    const int r = rs + tid + 512 * u;
+    cb[u] = (r > j + 1 && r < n) ? p.colbuf[r] : 0.0;
+  }
   const double alpha0 = p.colbuf[j + 1];
+  const double xn2 = wave_sum(l < p.npn ? p.pn[l] : 0.0);       // at most 64 partial sums (one per 64 rows), one per lane
   double tau = 0.0, beta = alpha0, scl = 0.0;
   if (xn2 > 1e-280) {      // entries are scaled to O(1): below this the column is zero to any precision that matters
     const double nrm = sqrt(fma(alpha0, alpha0, xn2));
@@ -355,41 +396,63 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
     tau = (beta - alpha0) / beta;
     scl = 1.0 / (alpha0 - beta);
   }
-  for (int r = rs + tid; r < (int)ld; r += 512) s_v[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : p.colbuf[r] * scl);
-  double* __restrict__ vcol = p.Vh + (size_t)j * ld;
-  for (int r = blockIdx.x * 512 + tid; r < n; r += gridDim.x * 512) vcol[r] = r <= j ? 0.0 : (r == j + 1 ? 1.0 : p.colbuf[r] * scl);
+#pragma unroll
+  for (int u = 0; u < EB_MAXN / 512; ++u) {
+    const int r = rs + tid + 512 * u;
+    if (r < (int)ld) s_v[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : cb[u] * scl);
+  }
   if (blockIdx.x == 0 && tid == 0) {
     p.evec[j] = beta;
     p.tauv[j] = tau;
   }
   __syncthreads();
-  const int nA = n - j - 1, nc = nA + 2 * jj;
-  const int npair = ((int)ld - rs) >> 1;
+  {      // column j of the reflector matrix (explicit zeros above the unit entry), this workgroup's share of the rows, from LDS
+    double* __restrict__ vcol = p.Vh + (size_t)j * ld;
+    for (int r = blockIdx.x * 512 + tid; r < n; r += gridDim.x * 512) vcol[r] = r < rs ? 0.0 : s_v[r - rs];
+  }
   const d2* __restrict__ v2 = (const d2*)s_v;
   double vyp = 0.0;
-  for (int q = blockIdx.x * 8 + w; q < nc; q += gridDim.x * 8) {
-    const double* colp;
-    if (q < nA) colp = p.A + (size_t)(j + 1 + q) * ld;
-    else if (q < nA + jj) colp = p.Vh + (size_t)(p.p0 + q - nA) * ld;
-    else colp = p.W + (size_t)(q - nA - jj) * ld;
-    const d2* __restrict__ c2 = (const d2*)(colp + rs);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int q = qfirst; q < nc; q += gridDim.x * 8) {
+    const d2* __restrict__ c2 = column(q);
+    // UNR 16-byte loads per lane in flight (UNR KB per wave): with one column per wave at n = 4096 the product is bound by the
+    // bytes in flight, not by the cache that holds the matrix (profiles/r05b: two loads in flight gave 3.7 TB/s)
+    double acc[2 * UNR];
+#pragma unroll
+    for (int u = 0; u < 2 * UNR; ++u) acc[u] = 0.0;
     int i = l;
-    for (; i + 64 < npair; i += 128) {
-      const d2 x = c2[i], xb = c2[i + 64];
-      const d2 vv = v2[i], vb = v2[i + 64];
-      a0 = fma(x.x, vv.x, a0);
-      a1 = fma(x.y, vv.y, a1);
-      a2 = fma(xb.x, vb.x, a2);
-      a3 = fma(xb.y, vb.y, a3);
+    if (q == qfirst) {       // wave-uniform: the prefetched head of the first column
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + 64 * u < npair) {
+          const d2 vv = v2[i + 64 * u];
+          acc[2 * u] = fma(pre[u].x, vv.x, acc[2 * u]);
+          acc[2 * u + 1] = fma(pre[u].y, vv.y, acc[2 * u + 1]);
+        }
+      }
+      i += 256;
     }
-    if (i < npair) {
+    for (; i + 64 * (UNR - 1) < npair; i += 64 * UNR) {
+      d2 x[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) x[u] = c2[i + 64 * u];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const d2 vv = v2[i + 64 * u];
+        acc[2 * u] = fma(x[u].x, vv.x, acc[2 * u]);
+        acc[2 * u + 1] = fma(x[u].y, vv.y, acc[2 * u + 1]);
+      }
+    }
+    for (; i < npair; i += 64) {
       const d2 x = c2[i];
       const d2 vv = v2[i];
-      a0 = fma(x.x, vv.x, a0);
-      a1 = fma(x.y, vv.y, a1);
+      acc[0] = fma(x.x, vv.x, acc[0]);
+      acc[1] = fma(x.y, vv.y, acc[1]);
     }
-    const double y = wave_sum((a0 + a1) + (a2 + a3));
+#pragma unroll
+    for (int st = 1; st < 2 * UNR; st *= 2)
+#pragma unroll
+      for (int u = 0; u + st < 2 * UNR; u += 2 * st) acc[u] += acc[u + st];
+    const double y = wave_sum(acc[0]);
     if (q < nA) {
       if (l == 0) p.ybuf[j + 1 + q] = y;
       vyp = fma(y, s_v[j + 1 + q - rs], vyp);
@@ -924,6 +987,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
 
   // ---- tridiagonalisation
   {
+    static const int tri_unr = [] {      // HFMI_EIG_TRI_UNR = 4 | 8: 16-byte loads in flight per lane of k_tri_b (A/B)
+      const char* e = getenv("HFMI_EIG_TRI_UNR");
+      return (e && atoi(e) == 4) ? 4 : 8;
+    }();
     tri_args ta;
     ta.n = n;
     ta.ld = ld;
@@ -955,7 +1022,8 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         const int nc = (n - j - 1) + 2 * jj;
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
-        hipLaunchKernelGGL(k_tri_b, dim3(gb), dim3(512), (size_t)(ld - rs0) * sizeof(double), st, ta);
+        if (tri_unr == 8) hipLaunchKernelGGL(k_tri_b<8>, dim3(gb), dim3(512), (size_t)(ld - rs0) * sizeof(double), st, ta);
+        else hipLaunchKernelGGL(k_tri_b<4>, dim3(gb), dim3(512), (size_t)(ld - rs0) * sizeof(double), st, ta);
         ta.npvy = gb;
       }
       const int t0 = p0 + ncols;
@@ -987,8 +1055,13 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   clk.mark(1);
 
   // ---- divide and conquer
+  static const int leaf_max = [] {      // HFMI_EIG_LEAF = 64 ... 256: largest leaf handed to the one-workgroup solver (A/B)
+    const char* e = getenv("HFMI_EIG_LEAF");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 64 && v <= 256) ? v : 256;
+  }();
   int Lf = 0;
-  while (((n + (1 << Lf) - 1) >> Lf) > 256) ++Lf;
+  while (((n + (1 << Lf) - 1) >> Lf) > leaf_max) ++Lf;
   HFMI_TRY(launch_dc_leaves(ctx, n, Lf, dvec, evec, D0, Q1, ld, fail));
   clk.mark(2);
   double *Dcur = D0, *Dnext = D1, *Qcur = Q1, *Qnext = Q2;

@@ -42,6 +42,13 @@ typedef const __attribute__((address_space(1))) double* gdptr;
 #else
 #define SS_LOAD(p) (*(p))
 #endif
+// Timing-only probes of the blocked kernel (round 5, profiles/r05_ssb_ridge_probe.txt; results are garbage; built with
+// scripts/build_variant.sh, never in the product library): what would a design gain that streams the LONGER operand HBM -> VGPR
+// and keeps only the shorter one in LDS?  SS_PROBE & 1: the staged columns of the second operand are fetched but not written to
+// LDS; SS_PROBE & 2: its fragments are not read from LDS either (registers instead) -- together the LDS traffic of that design.
+#ifndef SS_PROBE
+#define SS_PROBE 0
+#endif
 constexpr int SS_BK = 32;  // reduction indices per stage (16 chunks of 16 bytes per column)
 constexpr int SS_THREADS = 512;
 
@@ -277,9 +284,10 @@ template <int RB, int CB, int EN, int NQ>
 __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* __restrict__ Lnext, const int la, const int la1,
                                           const int (&toa)[RB], const int (&tob)[CB], const int (&etoa)[EN > 0 ? EN : 1],
                                           const int (&etob)[EN > 0 ? EN : 1], d4 (&acc)[RB][CB], d4 (&eacc)[EN > 0 ? EN : 1],
-                                          const d2 (&r)[NQ], const int dst0) {
+                                          const d2 (&r)[NQ], const int dst0, const int probe_acols = 0) {
   constexpr int CT = NQ * 32;
   constexpr int EA = EN > 0 ? EN : 1;
+  (void)probe_acols;
   d2 fa[2][RB], fb[2][CB], ea[2][EA], eb[2][EA];
 #pragma unroll
   for (int i = 0; i < RB; ++i) fa[0][i] = *reinterpret_cast<const d2*>(L + toa[i] + la);
@@ -297,7 +305,13 @@ __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* 
 #pragma unroll
       for (int i = 0; i < RB; ++i) fa[(it + 1) & 1][i] = *reinterpret_cast<const d2*>(L + toa[i] + lx);
 #pragma unroll
-      for (int j = 0; j < CB; ++j) fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(L + tob[j] + lx);
+      for (int j = 0; j < CB; ++j) {
+#if SS_PROBE & 2
+        fb[(it + 1) & 1][j] = d2{fb[it & 1][j].y, fb[it & 1][j].x};
+#else
+        fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(L + tob[j] + lx);
+#endif
+      }
 #pragma unroll
       for (int e = 0; e < EN; ++e) {
         ea[(it + 1) & 1][e] = *reinterpret_cast<const d2*>(L + etoa[e] + lx);
@@ -307,8 +321,15 @@ __device__ __forceinline__ void ssb_stage(const double* __restrict__ L, double* 
     if (it >= 2) {   // the next stage goes to the other LDS buffer under the MFMAs of the last two groups
       constexpr int H = (NQ + 1) / 2;
 #pragma unroll
-      for (int q = (it - 2) * H; q < ((it - 2) * H + H < NQ ? (it - 2) * H + H : NQ); ++q)
+      for (int q = (it - 2) * H; q < ((it - 2) * H + H < NQ ? (it - 2) * H + H : NQ); ++q) {
+#if SS_PROBE & 1
+        if ((int)(threadIdx.x >> 4) + 32 * q >= probe_acols) {
+          asm volatile("" ::"v"(r[q].x), "v"(r[q].y));
+          continue;
+        }
+#endif
         *reinterpret_cast<d2*>(Lnext + dst0 + q * 64) = r[q];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -339,8 +360,9 @@ __device__ __forceinline__ void ssb_stage_pipe(const double* __restrict__ L, dou
                                                const int (&toa)[RB], const int (&tob)[CB], const int (&etoa)[EN > 0 ? EN : 1],
                                                const int (&etob)[EN > 0 ? EN : 1], d4 (&acc)[RB][CB], d4 (&eacc)[EN > 0 ? EN : 1],
                                                const d2 (&r)[NQ], const int dst0, d2 (&fa)[2][RB], d2 (&fb)[2][CB],
-                                               d2 (&ea)[2][EN > 0 ? EN : 1], d2 (&eb)[2][EN > 0 ? EN : 1]) {
+                                               d2 (&ea)[2][EN > 0 ? EN : 1], d2 (&eb)[2][EN > 0 ? EN : 1], const int probe_acols = 0) {
   constexpr int CT = NQ * 32;
+  (void)probe_acols;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     if (it == 3) __syncthreads();
@@ -352,7 +374,13 @@ __device__ __forceinline__ void ssb_stage_pipe(const double* __restrict__ L, dou
 #pragma unroll
       for (int i = 0; i < RB; ++i) fa[(it + 1) & 1][i] = *reinterpret_cast<const d2*>(src + toa[i] + lx);
 #pragma unroll
-      for (int j = 0; j < CB; ++j) fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(src + tob[j] + lx);
+      for (int j = 0; j < CB; ++j) {
+#if SS_PROBE & 2
+        fb[(it + 1) & 1][j] = d2{fb[it & 1][j].y, fb[it & 1][j].x};
+#else
+        fb[(it + 1) & 1][j] = *reinterpret_cast<const d2*>(src + tob[j] + lx);
+#endif
+      }
 #pragma unroll
       for (int e = 0; e < EN; ++e) {
         ea[(it + 1) & 1][e] = *reinterpret_cast<const d2*>(src + etoa[e] + lx);
@@ -362,8 +390,15 @@ __device__ __forceinline__ void ssb_stage_pipe(const double* __restrict__ L, dou
     if (it < 2) {   // the next stage goes to the other LDS buffer under the MFMAs of the FIRST two groups
       constexpr int H = (NQ + 1) / 2;
 #pragma unroll
-      for (int q = it * H; q < (it * H + H < NQ ? it * H + H : NQ); ++q)
+      for (int q = it * H; q < (it * H + H < NQ ? it * H + H : NQ); ++q) {
+#if SS_PROBE & 1
+        if ((int)(threadIdx.x >> 4) + 32 * q >= probe_acols) {
+          asm volatile("" ::"v"(r[q].x), "v"(r[q].y));
+          continue;
+        }
+#endif
         *reinterpret_cast<d2*>(Lnext + dst0 + q * 64) = r[q];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -441,11 +476,11 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
       for (int s = 0; s < nstages; s += 2) {
         stage_load(reg[1], s + 2);
         __builtin_amdgcn_sched_barrier(0);
-        ssb_stage_pipe<RB, CB, EN, NQ>(lds, lds + BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0, fa, fb, ea, eb);
+        ssb_stage_pipe<RB, CB, EN, NQ>(lds, lds + BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0, fa, fb, ea, eb, RT * 16);
         if (s + 1 < nstages) {
           stage_load(reg[0], s + 3);
           __builtin_amdgcn_sched_barrier(0);
-          ssb_stage_pipe<RB, CB, EN, NQ>(lds + BUF, lds, la, la1, toa, tob, etoa, etob, acc, eacc, reg[1], dst0, fa, fb, ea, eb);
+          ssb_stage_pipe<RB, CB, EN, NQ>(lds + BUF, lds, la, la1, toa, tob, etoa, etob, acc, eacc, reg[1], dst0, fa, fb, ea, eb, RT * 16);
         }
       }
     } else {
@@ -453,19 +488,19 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
         stage_load(reg[0], s + 1);
         __builtin_amdgcn_sched_barrier(0);
         ssb_stage_pipe<RB, CB, EN, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, etoa, etob, acc, eacc,
-                                       reg[0], dst0, fa, fb, ea, eb);
+                                       reg[0], dst0, fa, fb, ea, eb, RT * 16);
       }
     }
   } else if constexpr (PF == 2) {
     for (int s = 0; s < nstages; s += 2) {
       stage_load(reg[1], s + 2);
       __builtin_amdgcn_sched_barrier(0);
-      ssb_stage<RB, CB, EN, NQ>(lds, lds + BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0);
+      ssb_stage<RB, CB, EN, NQ>(lds, lds + BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0, RT * 16);
       __syncthreads();
       if (s + 1 < nstages) {
         stage_load(reg[0], s + 3);
         __builtin_amdgcn_sched_barrier(0);
-        ssb_stage<RB, CB, EN, NQ>(lds + BUF, lds, la, la1, toa, tob, etoa, etob, acc, eacc, reg[1], dst0);
+        ssb_stage<RB, CB, EN, NQ>(lds + BUF, lds, la, la1, toa, tob, etoa, etob, acc, eacc, reg[1], dst0, RT * 16);
         __syncthreads();
       }
     }
@@ -473,7 +508,7 @@ __device__ __forceinline__ void ssb_run(double* __restrict__ lds, const gdptr* _
     for (int s = 0; s < nstages; ++s) {
       stage_load(reg[0], s + 1);
       __builtin_amdgcn_sched_barrier(0);
-      ssb_stage<RB, CB, EN, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0);
+      ssb_stage<RB, CB, EN, NQ>(lds + (s & 1) * BUF, lds + ((s + 1) & 1) * BUF, la, la1, toa, tob, etoa, etob, acc, eacc, reg[0], dst0, RT * 16);
       __syncthreads();
     }
   }

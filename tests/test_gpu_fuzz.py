@@ -82,7 +82,9 @@ def test_fuzz_double_pass_against_the_oracle(ctx, seed):
         Om = rng.standard_normal((N, k))
         d, U = hf.doublePass(op, hf.MultiVector.from_dense(Om), r, s=s)
         d_ref, U_ref = hp_o.double_pass_blas3(lambda W: np.asfortranarray(X.T @ (X @ W) / n), np.asfortranarray(Om), r, s=s)
-        big = d_ref > 1e-10 * d_ref[0]
+        # what the probe block still carries after s applications: components below (lambda / lambda_0)^s ~ 1e-10 are round-off in
+        # A^s Omega on both sides (two power iterations square the spectrum), so only eigenvalues above that are compared
+        big = d_ref > (1e-10 if s == 1 else 1e-5) * d_ref[0]
         e = np.max(np.abs(d[big] - d_ref[big]) / np.maximum(d_ref[big], 1e-7 * d_ref[0])) if big.any() else 0.0
         Ud = U.to_dense()
         o = np.linalg.norm(Ud[:, big].T @ Ud[:, big] - np.eye(int(big.sum())))
