@@ -95,6 +95,8 @@ SIGNATURES = {
     "hfmi_op_destroy": [_P],
     "hfmi_borth_qr": [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int)],
     "hfmi_sym_eig_small": [_P, _P, C.c_int, C.c_int, _P, _P],
+    "hfmi_sym_eig_leading": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "hfmi_block_gram_eig": [_P, _P, C.c_int, C.c_int, _P, _P],
     "hfmi_svd_small": [_P, _P, C.c_int, _P, _P, _P],
     "hfmi_double_pass": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "hfmi_double_pass_g": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P],

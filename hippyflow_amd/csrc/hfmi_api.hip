@@ -1709,6 +1709,42 @@ extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, in
 }
 
 // np.linalg.svd of the small triangular factor inside hp.accuracyEnhancedSVD
+// the same with only the nvec leading eigenvectors (in output order) returned: host_V is k x nvec row-major.  What the deterministic
+// POD needs of la.eigh(G) (PODProjector.py:821-826: U[:, :u_rank]); beyond 256 the back-transformation and the read-back then run
+// over nvec columns instead of k
+extern "C" int hfmi_sym_eig_leading(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, int nvec, double* host_d, double* host_V) {
+  if (!ctx || !host_T || !host_d || !host_V) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (k < 1 || k > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_leading: k=%d out of range [1,4096]", k);
+  if (nvec < 1 || nvec > k) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_leading: nvec=%d out of range [1,%d]", nvec, k);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (k > SM_MAXK) return sym_eig_large(ctx, host_T, k, sort_by_abs, host_d, host_V, nvec);
+  std::vector<double> full((size_t)k * k);
+  HFMI_TRY(hfmi_sym_eig_small(ctx, host_T, k, sort_by_abs, host_d, full.data()));
+  for (int i = 0; i < k; ++i) memcpy(host_V + (size_t)i * nvec, full.data() + (size_t)i * k, (size_t)nvec * sizeof(double));
+  return HFMI_OK;
+}
+
+// la.eigh(X^T (M X)) of the deterministic POD in one call (PODProjector.py:818-826: UtMU = u_data @ M @ u_data.T; eigh; U[:, :u_rank]):
+// the n x n Gram matrix of two blocks is formed on the device and goes straight into the eigensolver -- no n x n matrix crosses
+// PCIe in either direction, only the n eigenvalues and the nvec wanted eigenvectors come back (host_V: n x nvec row-major).
+extern "C" int hfmi_block_gram_eig(const hfmi_block* A, const hfmi_block* B, int sort_by_abs, int nvec, double* host_d, double* host_V) {
+  if (!A || !B || !host_d || !host_V) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (A->N != B->N) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: vector lengths differ (%lld vs %lld)", (long long)A->N, (long long)B->N);
+  if (A->nvec != B->nvec) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: the blocks hold %d and %d vectors", A->nvec, B->nvec);
+  const int n = A->nvec;
+  if (n < 1 || n > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: n=%d out of range [1,4096]", n);
+  if (nvec < 1 || nvec > n) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: nvec=%d out of range [1,%d]", nvec, n);
+  hfmi_ctx* ctx = A->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  void* out = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)n * n * sizeof(double), &out));
+  HFMI_TRY(launch_tsgemm_tn(ctx, A->p, A->ld, n, B->p, B->ld, n, A->N, 1.0, 0.0, (double*)out, n, 1, 0));
+  if (n > SM_MAXK) return sym_eig_large(ctx, nullptr, n, sort_by_abs, host_d, host_V, nvec, (const double*)out);
+  std::vector<double> G((size_t)n * n);
+  HFMI_TRY(read_back(ctx, (const double*)out, (size_t)n * n, G.data()));
+  return hfmi_sym_eig_leading(ctx, G.data(), n, sort_by_abs, nvec, host_d, host_V);
+}
+
 extern "C" int hfmi_svd_small(hfmi_ctx* ctx, const double* host_R, int k, double* host_sigma, double* host_U, double* host_V) {
   if (!ctx || !host_R || !host_sigma) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   if (k < 1 || k > SM_MAXK) HFMI_FAIL(HFMI_ERR_INVALID, "svd_small: k=%d out of range [1,%d]", k, SM_MAXK);

@@ -106,6 +106,8 @@ struct comm_slot {
   int32_t rccl_ok;            // librccl loaded and the id carries an RCCL id
   int32_t rccl_init;          // 0 = not tried, 1 = ncclCommInitRank succeeded, 2 = failed
   int32_t rccl_first;         // 0 = not tried, 1 = the first all-reduce gave the right sum, 2 = wrong / error / time-out
+  int32_t probe_ok;           // p2p_probe_stage: this rank saw every peer's token in its staging buffer
+  int32_t pad2;
 };
 struct alignas(64) comm_flag {
   unsigned long long v;       // written by ONE rank's GPU (system-scope store), polled by the others' GPUs
@@ -161,6 +163,8 @@ struct hfmi_comm {
   int* err_host;             // the same word from the host (pinned, mapped): read after any stream synchronisation, no copy
   bool distinct_devices;
   char why[256];             // how the transport was chosen (hfmi_comm_describe)
+  int probe_rounds;          // p2p_probe_stage: loop-back rounds the last (re)allocation of the staging buffers needed (1 = first try)
+  int probe_retries_total;   // ... rounds beyond the first, over the life of the communicator
   // device scratch for host payloads on the RCCL-only route
   double* scratch;
   size_t scratch_bytes;
@@ -295,6 +299,85 @@ static int p2p_alloc_stage(hfmi_comm* c, size_t want) {
   HIP_TRY(hipMalloc((void**)&c->stage, want));
   return HFMI_OK;
 }
+// Loop-back check of freshly mapped staging buffers (round 5).  The determinism soak (tests/test_gpu_comm.py, scripts/p2p_soak.py)
+// showed the FIRST collective after the staging buffers had been allocated and mapped returning, in ~5 % of the runs, this rank's own
+// contribution in the three quarters of the block its peers reduce: their stores through the new HIP-IPC mappings had not reached
+// what this rank then read, although their completion flags had (kernel copies and copy commands alike; never once the mappings had
+// been used: thousands of later collectives, no case).  So a new set of mappings is exercised before it carries data: every rank
+// fills a probe area of its own buffer with its own pattern, every rank then stores a round-specific token into its slot of every
+// PEER's probe area through the mapping (the store path of the reduction), and every rank reads its own area back through a kernel
+// copy (the load path of the copy-out) and checks all P tokens.  The round is repeated until every rank has seen every token
+// (usually the first; the count is in hfmi_comm_describe: "p2p_probe_rounds"); four failed rounds are an error, not silent data.
+__global__ void __launch_bounds__(256) k_p2p_copy(double* __restrict__ dst, const double* __restrict__ src, int64_t count) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int64_t n2 = count >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
+    reinterpret_cast<d2*>(dst)[i] = reinterpret_cast<const d2*>(src)[i];
+  if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[count - 1] = src[count - 1];
+}
+constexpr int PROBE_SLOT = 32;      // doubles per rank in the probe area (256 bytes: two 128-byte lines)
+__global__ void k_p2p_probe_fill(double* stage, int nranks, double value) {
+  for (int i = threadIdx.x; i < nranks * PROBE_SLOT; i += blockDim.x) stage[i] = value;
+}
+struct p2p_probe_ptrs {
+  double* p[COMM_MAX_RANKS];
+};
+__global__ void k_p2p_probe_store(p2p_probe_ptrs bufs, int nranks, int rank, double token) {
+  const int p = blockIdx.x;
+  if (p < nranks && threadIdx.x < PROBE_SLOT) bufs.p[p][rank * PROBE_SLOT + threadIdx.x] = token;
+}
+static int p2p_probe_stage(hfmi_comm* c) {
+  hfmi_ctx* ctx = c->ctx;
+  hipStream_t st = ctx->stream;
+  const int P = c->nranks, n = P * PROBE_SLOT;
+  double* scratch = nullptr;
+  HIP_TRY(hipMalloc((void**)&scratch, (size_t)n * sizeof(double)));
+  std::vector<double> host(n);
+  p2p_probe_ptrs bufs;
+  for (int p = 0; p < COMM_MAX_RANKS; ++p) bufs.p[p] = p < P ? c->peer[p] : nullptr;
+  int rounds = 0, rc = HFMI_OK;
+  bool all_ok = false;
+  for (int round = 0; round < 4 && !all_ok && rc == HFMI_OK; ++round) {
+    ++rounds;
+    const double own = -1.0 - c->rank - 100.0 * round;
+    hipLaunchKernelGGL(k_p2p_probe_fill, dim3(1), dim3(256), 0, st, c->stage, P, own);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = HFMI_ERR_HIP;
+    if (rc == HFMI_OK) rc = shm_barrier(c);                     // every rank's own pattern is in place
+    if (rc != HFMI_OK) break;
+    hipLaunchKernelGGL(k_p2p_probe_store, dim3(P), dim3(64), 0, st, bufs, P, c->rank, 1000.0 * (round + 1) + c->rank);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = HFMI_ERR_HIP;
+    if (rc == HFMI_OK) rc = shm_barrier(c);                     // every rank's tokens have been stored (kernels complete)
+    if (rc != HFMI_OK) break;
+    hipLaunchKernelGGL(k_p2p_copy, dim3(1), dim3(256), 0, st, scratch, (const double*)c->stage, (int64_t)n);
+    if (hipMemcpyAsync(host.data(), scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      rc = HFMI_ERR_HIP;
+    if (rc != HFMI_OK) break;
+    bool ok = true;
+    for (int p = 0; p < P && ok; ++p)
+      for (int i = 0; i < PROBE_SLOT; ++i)
+        if (host[p * PROBE_SLOT + i] != 1000.0 * (round + 1) + p) {
+          ok = false;
+          break;
+        }
+    c->sh->slot[c->rank].probe_ok = ok ? 1 : 0;
+    rc = shm_barrier(c);
+    if (rc != HFMI_OK) break;
+    all_ok = true;
+    for (int p = 0; p < P; ++p) all_ok = all_ok && c->sh->slot[p].probe_ok == 1;
+    rc = shm_barrier(c);                                         // everybody has read the table before the next round rewrites it
+  }
+  (void)hipFree(scratch);
+  if (rc == HFMI_ERR_HIP) hfmi_set_error("p2p staging probe: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc != HFMI_OK) return rc;
+  c->probe_rounds = rounds;
+  c->probe_retries_total += rounds - 1;
+  if (!all_ok)
+    HFMI_FAIL(HFMI_ERR_COMM, "rank %d: stores through the HIP-IPC mappings of the p2p staging buffers did not become visible in four "
+              "loop-back rounds: the transport cannot be trusted on this system", c->rank);
+  return HFMI_OK;
+}
+
 // Collective: every rank calls it with the same `bytes`.
 static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
   if (bytes <= c->stage_bytes) return HFMI_OK;
@@ -309,10 +392,27 @@ static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
   c->stage = nullptr;
   c->stage_bytes = 0;
   const size_t want = round_up((int64_t)(bytes + bytes / 8), 1 << 20);
-  HFMI_TRY(p2p_alloc_stage(c, want));
-  c->stage_bytes = want;
   comm_slot& me = c->sh->slot[c->rank];
-  HIP_TRY(hipIpcGetMemHandle(&me.handle, c->stage));
+  // The export of a fresh allocation was seen to fail once with "invalid argument" (round 5: rank 0 of four ranks sharing the GPU,
+  // right after another four-rank job had ended; neither the fine-grained nor the plain allocation could be exported, and an
+  // identical run a minute later was fine).  A failed export is retried on a new allocation of a slightly different size before
+  // it becomes an error: every rank still publishes the AGREED size `want`, which is what the peers check.
+  hipError_t exp_err = hipSuccess;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    const size_t actual = want + ((size_t)attempt << 21);
+    HFMI_TRY(p2p_alloc_stage(c, actual));
+    c->stage_bytes = actual;
+    exp_err = hipIpcGetMemHandle(&me.handle, c->stage);
+    if (exp_err == hipSuccess) break;
+    (void)hipGetLastError();
+    (void)hipFree(c->stage);
+    c->stage = nullptr;
+    c->stage_bytes = 0;
+  }
+  if (exp_err != hipSuccess) {
+    hfmi_set_error("hipIpcGetMemHandle of the p2p staging buffer failed four times: %s", hipGetErrorString(exp_err));
+    return HFMI_ERR_HIP;
+  }
   me.bytes = (int64_t)want;
   HFMI_TRY(shm_barrier(c));
   for (int p = 0; p < c->nranks; ++p) {
@@ -327,7 +427,9 @@ static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
     HIP_TRY(hipIpcOpenMemHandle(&q, c->sh->slot[p].handle, hipIpcMemLazyEnablePeerAccess));
     c->peer[p] = (double*)q;
   }
-  return shm_barrier(c);
+  HFMI_TRY(shm_barrier(c));
+  static const bool no_probe = env_flag("HFMI_P2P_NO_PROBE");    // A/B: the behaviour up to round 4
+  return no_probe ? HFMI_OK : p2p_probe_stage(c);
 }
 
 struct p2p_ptrs {
@@ -386,13 +488,35 @@ __global__ void k_p2p_wait(const comm_flag* flags, int nranks, unsigned long lon
   if (v == P2P_POISON) __hip_atomic_store(dev_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a plain store: the word lives in host memory, no PCIe atomic needed
 }
 
+// Copies between a block and the staging buffer.  Up to round 4 these were hipMemcpyAsync (device to device): a copy COMMAND, which
+// the runtime may hand to a blit kernel or to an SDMA engine.  The determinism soak of round 5 (tests/test_gpu_comm.py, 200
+// all-reduces x 40 runs) caught the FIRST collective on a freshly allocated staging buffer returning, in 2 runs of 40, this rank's
+// own contribution in the three quarters of the block its peers had reduced -- the copy-out had not seen the peers' stores although
+// their completion flags had been observed.  As plain kernels on the stream the two copies are ordered and made visible by the same
+// kernel-boundary acquire / release as the signal, wait and reduce kernels around them.  HFMI_P2P_COPY=memcpy restores the copy
+// commands (A/B).
+static int p2p_copy(hfmi_comm* c, double* dst, const double* src, int64_t count, hipStream_t stream) {
+  static const bool use_memcpy = [] {
+    const char* e = getenv("HFMI_P2P_COPY");
+    return e && !strcmp(e, "memcpy");
+  }();
+  if (use_memcpy || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) {
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return HFMI_OK;
+  }
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((count / 2 + 255) / 256, (int64_t)c->ctx->num_cus * 8));
+  hipLaunchKernelGGL(k_p2p_copy, dim3(blocks), dim3(256), 0, stream, dst, src, count);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
+
 static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, hipStream_t stream) {
   hfmi_ctx* ctx = c->ctx;
   const int64_t padded = round_up(count, 2);
   const size_t bytes = (size_t)padded * sizeof(double);
   HFMI_TRY(p2p_ensure_stage(c, bytes));
   if (padded != count) HIP_TRY(hipMemsetAsync(c->stage + count, 0, sizeof(double), stream));
-  HIP_TRY(hipMemcpyAsync(c->stage, data, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  HFMI_TRY(p2p_copy(c, c->stage, data, count, stream));
   const int64_t n2 = padded / 2;
   const int64_t lo = n2 * c->rank / c->nranks, hi = n2 * (c->rank + 1) / c->nranks;
   p2p_ptrs bufs;
@@ -409,7 +533,7 @@ static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, 
     hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(1), 0, stream, &c->sh_dev->done[c->rank], seq, (const int*)c->dev_err);
     hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, stream, c->sh_dev->done, c->nranks, seq, ticks, c->dev_err);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(data, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    HFMI_TRY(p2p_copy(c, data, c->stage, count, stream));
     // the next collective's copy-in is ordered behind this copy-out on the stream, and no peer touches this rank's buffer
     // before this rank has published the next sequence number
     return HFMI_OK;
@@ -422,7 +546,7 @@ static int p2p_allreduce_dev(hfmi_comm* c, double* data, int64_t count, int op, 
   }
   HIP_TRY(hipStreamSynchronize(stream));
   HFMI_TRY(shm_barrier(c));                       // every slice of every buffer is final
-  HIP_TRY(hipMemcpyAsync(data, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  HFMI_TRY(p2p_copy(c, data, c->stage, count, stream));
   // the staging buffer may be overwritten by the next collective only after this copy: the next collective
   // starts with a stream synchronise of its own copy-in, which is ordered behind this copy on the same stream
   return HFMI_OK;
@@ -789,7 +913,8 @@ extern "C" int hfmi_comm_describe(const hfmi_comm* c, char* buf, int len) {
                    c->transport != TRANSPORT_P2P || !c->stage ? "" : (c->stage_fine ? "fine-grained" : "coarse-grained"));
   for (int p = 0; p < c->nranks && o > 0 && o < len; ++p)
     o += snprintf(buf + o, (size_t)(len - o), "%s\"%s\"", p ? ", " : "", c->sh ? c->sh->slot[p].device_id : "");
-  if (o > 0 && o < len) snprintf(buf + o, (size_t)(len - o), "]}");
+  if (o > 0 && o < len) snprintf(buf + o, (size_t)(len - o), "], \"p2p_probe_rounds\": %d, \"p2p_probe_retries_total\": %d}", c->probe_rounds,
+                                 c->probe_retries_total);
   return HFMI_OK;
 }
 

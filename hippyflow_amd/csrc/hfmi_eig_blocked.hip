@@ -847,23 +847,30 @@ __global__ __launch_bounds__(64) void k_larft(const double* __restrict__ G, cons
   double* tf = Tf + off;
   for (int c = 0; c < EB_NB; ++c) tf[r + (size_t)c * EB_WY] = s_t[r][c];
 }
-// out (row-major n x n) [i][pos] = Z[i, order[pos]]: permutation of the columns + transposition through LDS
-__global__ __launch_bounds__(256) void k_out(const double* __restrict__ Z, int64_t ld, int n, const int* __restrict__ order,
-                                             double* __restrict__ out) {
+// out (row-major n x nv) [i][pos] = Z[i, pos]: transposition through LDS
+__global__ __launch_bounds__(256) void k_out(const double* __restrict__ Z, int64_t ld, int n, int nv, double* __restrict__ out) {
   __shared__ double t[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int i0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int a = ty + 8 * q;            // position p0 + a, row i0 + tx
-    t[a][tx] = (p0 + a < n && i0 + tx < n) ? Z[(size_t)(i0 + tx) + (size_t)order[p0 + a] * ld] : 0.0;
+    t[a][tx] = (p0 + a < nv && i0 + tx < n) ? Z[(size_t)(i0 + tx) + (size_t)(p0 + a) * ld] : 0.0;
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int a = ty + 8 * q;            // row i0 + a, position p0 + tx
-    if (i0 + a < n && p0 + tx < n) out[(size_t)(i0 + a) * n + (p0 + tx)] = t[tx][a];
+    if (i0 + a < n && p0 + tx < nv) out[(size_t)(i0 + a) * nv + (p0 + tx)] = t[tx][a];
   }
+}
+// Zs[:, pos] = Z[:, order[pos]] for pos < nv: the wanted eigenvectors of the tridiagonal matrix in output order, BEFORE the
+// back-transformation -- its products then run over nv columns only
+__global__ __launch_bounds__(256) void k_pick_columns(const double* __restrict__ Z, double* __restrict__ Zs, int64_t ld, int n,
+                                                      const int* __restrict__ order) {
+  const double* __restrict__ src = Z + (size_t)order[blockIdx.x] * ld;
+  double* __restrict__ dst = Zs + (size_t)blockIdx.x * ld;
+  for (int r = threadIdx.x; r < n; r += 256) dst[r] = src[r];
 }
 
 struct phase_clock {
@@ -891,13 +898,32 @@ struct phase_clock {
 
 // host_T: n x n row-major symmetric (the symmetric part is used); host_d: n eigenvalues descending (by |d| if
 // sort_by_abs); host_V: n x n row-major, eigenvectors in the columns (may be null).
-int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V) {
+// nvec: how many eigenvectors (the leading ones in output order) are wanted; host_V is n x nvec row-major.
+// dev_T != null: the matrix is already in device memory (n x n row-major, what hfmi_block_dot leaves in its workspace) and host_T is
+// ignored -- the Gram matrix of the deterministic POD then never crosses PCIe (hfmi_block_gram_eig).
+int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V, int nvec,
+                  const double* dev_T) {
   if (n > EB_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds %d", n, EB_MAXN);
+  if (nvec < 0 || nvec > n) nvec = n;
+  if (!host_V) nvec = 0;
   static const bool jacobi = [] {
     const char* e = getenv("HFMI_EIG_LARGE");
     return e && !strcmp(e, "jacobi");
   }();
-  if (jacobi || n < 3) return sym_eig_large_jacobi(ctx, host_T, n, sort_by_abs, host_d, host_V);
+  std::vector<double> staged;
+  if ((jacobi || n < 3) && dev_T) {      // the Jacobi route takes a host matrix
+    staged.resize((size_t)n * n);
+    HIP_TRY(hipMemcpyAsync(staged.data(), dev_T, staged.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    host_T = staged.data();
+  }
+  if (jacobi || n < 3) {
+    if (nvec == n || !host_V) return sym_eig_large_jacobi(ctx, host_T, n, sort_by_abs, host_d, host_V);
+    std::vector<double> full((size_t)n * n);
+    HFMI_TRY(sym_eig_large_jacobi(ctx, host_T, n, sort_by_abs, host_d, full.data()));
+    for (int i = 0; i < n; ++i) memcpy(host_V + (size_t)i * nvec, full.data() + (size_t)i * n, (size_t)nvec * sizeof(double));
+    return HFMI_OK;
+  }
   const int NB = EB_NB;
   const int64_t ld = round_up(n, 128);
   const int npad = (int)round_up(n, EB_WY), npanels = npad / NB, nblk = npad / EB_WY;
@@ -969,7 +995,8 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   phase_clock clk(ctx);
 
   // ---- load
-  HIP_TRY(hipMemcpyAsync(Qg, host_T, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (!dev_T) HIP_TRY(hipMemcpyAsync(Qg, host_T, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
+  const double* raw = dev_T ? dev_T : Qg;
   HIP_TRY(hipMemsetAsync(A, 0, mat * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(Vh, 0, mat * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(Q1, 0, 2 * mat * sizeof(double), st));          // Q1 and Q2 are adjacent
@@ -978,7 +1005,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   HIP_TRY(hipMemsetAsync(fail, 0, 16 * sizeof(int), st));
   {
     const int nt = (n + 31) / 32;
-    hipLaunchKernelGGL(k_sym_load, dim3(nt, nt), dim3(256), 0, st, Qg, n, A, ld, pmax);
+    hipLaunchKernelGGL(k_sym_load, dim3(nt, nt), dim3(256), 0, st, raw, n, A, ld, pmax);
     hipLaunchKernelGGL(k_scale_exp, dim3(1), dim3(1024), 0, st, pmax, nt * nt, sexp_dev);
     hipLaunchKernelGGL(k_scale_apply, dim3(n), dim3(256), 0, st, A, ld, n, sexp_dev);
     HIP_TRY(hipGetLastError());
@@ -1058,7 +1085,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   static const int leaf_max = [] {      // HFMI_EIG_LEAF = 64 ... 256: largest leaf handed to the one-workgroup solver (A/B)
     const char* e = getenv("HFMI_EIG_LEAF");
     const int v = e ? atoi(e) : 0;
-    return (v >= 64 && v <= 256) ? v : 256;
+    return (v >= 64 && v <= 256) ? v : 128;      // 128: n = 512 / 1024 5.65 / 11.5 ms against 6.06 / 11.9 with 256-row leaves, equal beyond
   }();
   int Lf = 0;
   while (((n + (1 << Lf) - 1) >> Lf) > leaf_max) ++Lf;
@@ -1149,7 +1176,13 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   std::iota(perm.begin(), perm.end(), 0);
   std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return sort_by_abs ? fabs(lam[x]) > fabs(lam[y]) : lam[x] > lam[y]; });
   for (int jx = 0; jx < n; ++jx) host_d[jx] = ldexp(lam[perm[jx]], hfail[1]);
-  if (!host_V) return HFMI_OK;
+  if (!host_V || nvec == 0) return HFMI_OK;
+  const int nv = nvec;
+  // the wanted eigenvectors of the tridiagonal matrix, in output order, into the other Q buffer: everything below works on nv columns
+  HIP_TRY(hipMemcpyAsync(order, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_pick_columns, dim3(nv), dim3(256), 0, st, Qcur, Qnext, ld, n, order);
+  HIP_TRY(hipGetLastError());
+  std::swap(Qcur, Qnext);
 
   // ---- back-transformation: Z <- (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) Z with block reflectors of EB_WY = 256
   // columns (four panels): 64-column products V^T Z would be 64 tiles on 256 compute units.  The triangular factor of a block is
@@ -1225,7 +1258,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       g1.ta = true;
       g1.tb = false;
       g1.M = EB_WY;
-      g1.N = n;
+      g1.N = nv;
       g1.K = n - r0;
       g1.alpha = 1.0;
       g1.beta = 0.0;
@@ -1239,7 +1272,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       gemm_desc g2;              // Z -= Y W1
       g2.ta = g2.tb = false;
       g2.M = n - r0;
-      g2.N = n;
+      g2.N = nv;
       g2.K = EB_WY;
       g2.alpha = -1.0;
       g2.beta = 1.0;
@@ -1252,12 +1285,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       HFMI_TRY(launch_dgemm(ctx, g2));
     }
     clk.mark(4);
-    HIP_TRY(hipMemcpyAsync(order, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
-    const int nt = (n + 31) / 32;
     double* out = Qnext;
-    hipLaunchKernelGGL(k_out, dim3(nt, nt), dim3(256), 0, st, Z, ld, n, order, out);
+    hipLaunchKernelGGL(k_out, dim3((n + 31) / 32, (nv + 31) / 32), dim3(256), 0, st, Z, ld, n, nv, out);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host_V, out, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host_V, out, (size_t)n * nv * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     clk.mark(5);
   }

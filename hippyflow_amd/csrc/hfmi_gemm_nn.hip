@@ -281,10 +281,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_tsgemm_nn(const doubl
 // workgroup, the workgroups are persistent (grid = number of CUs, row tiles dealt cyclically), there is no barrier
 // after the staging, and the streamed operand is prefetched three k-steps ahead ACROSS tile boundaries, so the next
 // tile's first fragments are in flight while the current tile's results are being stored.
-template <int TT, int NT, int R4>
+template <int TT, int NT, int R4, bool UP>
 __global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restrict__ A, int64_t lda, int m,
                                                           const double* __restrict__ S, int lds_, int r,
-                                                          double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles, int upper) {
+                                                          double* __restrict__ Y, int64_t ldy, int64_t N, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* L = reinterpret_cast<double*>(smem);  // [round_up(m, 4)][SLD]
   constexpr int WAVES = 8;
@@ -374,14 +374,15 @@ __global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restri
   // one k-step; the small-matrix fragments are single-buffered: as soon as the MFMAs of column tile nt have issued,
   // its register is refilled with the fragment of k-step ksn and the other tiles' MFMAs cover the LDS latency
   SFrag sf;
-  // upper != 0: S is upper triangular (S[i][j] = 0 for i > j: R^-1 of the QR).  At reduction step ks (rows 4 ks .. 4 ks + 3 of S)
+  // UP (a template parameter since round 5: as a run-time flag the test cost EVERY instance registers -- U = Q V's <4,4,3> spilled
+  // 100 bytes per lane for a branch it never takes): S is upper triangular (S[i][j] = 0 for i > j: R^-1 of the QR).  At reduction step ks (rows 4 ks .. 4 ks + 3 of S)
   // the column tiles nt < ks / 4 hold nothing but zeros: their MFMAs are skipped -- products with exact zeros, so the result
   // has the same bits -- which is 45 % of the matrix instructions at k = 138 (wave-uniform test, one scalar branch per tile).
   auto mma = [&](const AFrag& a, int ksn, int nt0) {
     const double* Ln = L + (ksn * 4 + kk) * SLD;
 #pragma unroll
     for (int nt = 0; nt < NTF; ++nt) {
-      if (nt >= nt0) {
+      if (!UP || nt >= nt0) {
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
           acc[2 * tp][nt] = MFMA_F64(sf.f[nt], a.p[tp].x, acc[2 * tp][nt]);
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void k_tsgemm_nn_res(const double* __restri
     for (int u = 0; u < RD; ++u) {
       if (q0 + u < total) {   // wave-uniform
         load_next(ring[(u + RD - 1) % RD]);
-        mma(ring[u], (cks + 1 == nk) ? 0 : cks + 1, upper ? (cks >> 2) : 0);
+        mma(ring[u], (cks + 1 == nk) ? 0 : cks + 1, UP ? (cks >> 2) : 0);
         if (++cks == nk) {
           store_tile(ctile);
           zero_acc();
@@ -697,16 +698,18 @@ static int nn_launch_res(hfmi_ctx* ctx, const double* A, int64_t lda, int m, con
                          int64_t ldy, int64_t N, size_t shmem) {
   const int rem = r - (NT - 1) * 16;
   const int r4 = (g_rem4 && rem <= 12) ? (rem + 3) / 4 : 0;
-  auto kern = r4 == 1 ? k_tsgemm_nn_res<TT, NT, 1> : r4 == 2 ? k_tsgemm_nn_res<TT, NT, 2>
-            : r4 == 3 ? k_tsgemm_nn_res<TT, NT, 3> : k_tsgemm_nn_res<TT, NT, 0>;
+  static const bool env_off = getenv("HFMI_NN_UPPER") && atoi(getenv("HFMI_NN_UPPER")) == 0;   // A/B switch
+  const bool up = ctx->nn_upper_hint && g_nn_upper && !env_off;
+  auto kern = up ? (r4 == 1 ? k_tsgemm_nn_res<TT, NT, 1, true> : r4 == 2 ? k_tsgemm_nn_res<TT, NT, 2, true>
+                    : r4 == 3 ? k_tsgemm_nn_res<TT, NT, 3, true> : k_tsgemm_nn_res<TT, NT, 0, true>)
+                 : (r4 == 1 ? k_tsgemm_nn_res<TT, NT, 1, false> : r4 == 2 ? k_tsgemm_nn_res<TT, NT, 2, false>
+                    : r4 == 3 ? k_tsgemm_nn_res<TT, NT, 3, false> : k_tsgemm_nn_res<TT, NT, 0, false>);
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const int tile_rows = 16 * TT * 8;
   const int ntiles = (int)((N + tile_rows - 1) / tile_rows);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   const int grid = ntiles < cus ? ntiles : cus;
-  static const bool env_off = getenv("HFMI_NN_UPPER") && atoi(getenv("HFMI_NN_UPPER")) == 0;   // A/B switch
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, ntiles,
-                     (ctx->nn_upper_hint && g_nn_upper && !env_off) ? 1 : 0);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, ctx->stream, A, lda, m, S, lds_, r, Y, ldy, N, ntiles);
   HIP_TRY(hipGetLastError());
   return HFMI_OK;
 }

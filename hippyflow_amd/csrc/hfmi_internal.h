@@ -286,7 +286,10 @@ int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, 
 
 // symmetric eigensolve for 256 < n <= 4096: host in, host out.  hfmi_eig_blocked.hip (panel tridiagonalisation on the MFMA, divide
 // and conquer, block-reflector back-transformation); HFMI_EIG_LARGE=jacobi selects the two-sided Jacobi of hfmi_eig_large.hip
-int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V);
+// nvec < 0 or > n: all eigenvectors; otherwise host_V is n x nvec (the leading eigenvectors in output order)
+// dev_T: the matrix in device memory (n x n row-major) instead of host_T
+int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V, int nvec = -1,
+                  const double* dev_T = nullptr);
 
 // micro-benchmarks
 int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs);

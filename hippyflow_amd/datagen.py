@@ -242,18 +242,30 @@ class DataGenerator:
         return max(1, min(n_samples, int(self.chunk_bytes // (8 * self.dQ * self.dM))))
 
     def _run_chunks(self, n_samples, sinks, points):
-        """``points(first, count)`` yields once per linearised sample of the chunk (index in hand)."""
+        """``points(first, count, materialise)`` linearises one sample after the other, calls ``materialise(index)`` -- the
+        derivative work of that sample: dense Jacobian rows or the matrix-free products -- INSIDE whatever retry scope it has
+        (dataGenerator.py:125-239 wraps the derivative computation in the same try as the forward solve and redraws the
+        sample), and yields what it returned."""
         done = 0
         chunk = self._chunk(sinks, n_samples)
         big, small = sinks.get('J'), sinks.get('Jz')
+
+        def materialise(index):
+            held = len(small._held) if small is not None else 0
+            try:
+                if small is not None:
+                    small.take(index)
+                return big.take(index) if big is not None else None
+            except Exception:
+                if small is not None:
+                    del small._held[held:]          # the sample is drawn again: nothing of this attempt may stay queued
+                raise
+
         while done < n_samples:
             count = min(chunk, n_samples - done)
 
             def rows():
-                for index in points(done, count):
-                    if small is not None:
-                        small.take(index)
-                    yield big.take(index) if big is not None else None
+                yield from points(done, count, materialise)
 
             if big is not None and big.on_device:
                 block = ingest_stream(rows(), count, self.dQ, self.dM, ctx=self.ctx)
@@ -278,9 +290,10 @@ class DataGenerator:
         sinks = self._make_sinks(plan, data_dir)
         allowed_failures = 10 * n_samples + 100        # upstream tries for ever
 
-        def points(first, count):
+        def points(first, count, materialise):
             index = first
             while index < first + count:
+                written = []
                 try:
                     self.parRandom.normal(1, self.noise)
                     self.m.zero()
@@ -293,12 +306,16 @@ class DataGenerator:
                         point.append(self.z)
                     self.observable.solveFwd(self.u, point)
                     self.observable.setLinearizationPoint(point)
-                    np.save(sample_dir + 'm_sample_%d.npy' % index, self.m.get_local())
-                    np.save(sample_dir + 'q_sample_%d.npy' % index, self.observable.evalu(self.u).get_local())
-                    if control:
-                        np.save(sample_dir + 'z_sample_%d.npy' % index, self.z.get_local())
+                    q = self.observable.evalu(self.u).get_local()
+                    row = materialise(index)            # a failing incremental / adjoint solve redraws the sample as well
+                    for stem, values in (('m', self.m.get_local()), ('q', q)) + ((('z', self.z.get_local()),) if control else ()):
+                        written.append(sample_dir + '%s_sample_%d.npy' % (stem, index))
+                        np.save(written[-1], values)
                 except Exception as exc:                # noqa: BLE001 -- "issue perhaps with the forward solve, moving on"
                     self.exceptions_count += 1
+                    for path in written:                # never leave m / q files of an index whose sample is drawn again
+                        if os.path.exists(path):
+                            os.remove(path)
                     if self.settings['save_failed_solves']:
                         skipped = _dir(data_dir, 'skipped')
                         np.save(skipped + 'm_sample_%d.npy' % self.exceptions_count, self.m.get_local())
@@ -308,7 +325,7 @@ class DataGenerator:
                         raise RuntimeError("DataGenerator.generate: %d failed forward solves (last: %r)"
                                            % (self.exceptions_count, exc)) from exc
                     continue
-                yield index
+                yield row
                 index += 1
 
         self._run_chunks(n_samples, sinks, points)
@@ -329,7 +346,7 @@ class DataGenerator:
         m_data, u_data = stored['m_data'], stored['q_data']
         z_data = stored['z_data'] if self.control_distribution is not None else None
 
-        def points(first, count):
+        def points(first, count, materialise):
             for index in range(first, first + count):
                 self.m.set_local(m_data[index])
                 self.u.set_local(u_data[index])
@@ -338,7 +355,7 @@ class DataGenerator:
                     self.z.set_local(z_data[index])
                     point.append(self.z)
                 self.observable.setLinearizationPoint(point)
-                yield index
+                yield materialise(index)
 
         self._run_chunks(m_data.shape[0], sinks, points)
         if compress:

@@ -32,7 +32,7 @@ from .multivector import ingest_stream, MatMvMult, MultiVector, mv_to_dense
 from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableJacobian, SeriallySampledJacobianOperator,
                         SnapshotGramOperator, Solver2Operator, as_device_operator)
-from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
+from .randomized import doublePass, doublePassG, parRandom
 
 
 class ParameterList(object):
@@ -983,8 +983,7 @@ class PODProjectorFromData:
             Mop = CsrOperator(self.M_csr, ctx=self.ctx)
             MX = MultiVector(X.size(), X.nvec(), ctx=self.ctx)
             Mop.matMvMult(X, MX)
-            UtMU = X.dot_mv(MX)                                        # :818
-            s, U = sym_eig_small(UtMU, ctx=self.ctx)                   # descending; :821-823
+            s, U = X.gram_eig(MX, u_rank)                              # :818-823: UtMU, eigh, descending; only U[:, :u_rank] is used
             d = s[:u_rank] / n_data
             U = np.ascontiguousarray(U[:, :u_rank])
             from .multivector import MvDSmatMult

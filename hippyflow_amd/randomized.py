@@ -95,17 +95,26 @@ class _ParRandom:
 parRandom = _ParRandom()
 
 
-def sym_eig_small(T, sort_by_abs=False, ctx=None, method="dc"):
+def sym_eig_small(T, sort_by_abs=False, ctx=None, method="dc", nvec=None):
     """np.linalg.eigh(T) + descending sort, on the device.  ``method="dc"``: Householder tridiagonalisation + divide
-    and conquer (the algorithm family of the LAPACK routine behind np.linalg.eigh); ``"jacobi"``: one-workgroup
-    cyclic Jacobi (high relative accuracy of small eigenvalues of graded positive definite matrices)."""
+    and conquer (the algorithm family of the LAPACK routine behind np.linalg.eigh; up to 256 rows on one compute unit,
+    up to 4096 over the whole GPU); ``"jacobi"``: one-workgroup cyclic Jacobi (high relative accuracy of small
+    eigenvalues of graded positive definite matrices).  ``nvec``: return only the leading ``nvec`` eigenvectors
+    (all eigenvalues still) -- ``la.eigh(G)[1][:, :u_rank]`` of PODProjector.py:821-826 without back-transforming
+    and reading back the rest."""
     if method not in ("dc", "jacobi"):
         raise ValueError("sym_eig_small: method must be 'dc' or 'jacobi'")
     T = L.as_f64(T)
     k = T.shape[0]
-    d, V = np.empty(k), np.empty((k, k))
     flags = (1 if sort_by_abs else 0) | (2 if method == "jacobi" else 0)
-    L.call("hfmi_sym_eig_small", (ctx or L.Context.default()).handle, L.ptr(T), k, flags, L.ptr(d), L.ptr(V))
+    handle = (ctx or L.Context.default()).handle
+    if nvec is not None and int(nvec) < k:
+        nvec = int(nvec)
+        d, V = np.empty(k), np.empty((k, nvec))
+        L.call("hfmi_sym_eig_leading", handle, L.ptr(T), k, flags, nvec, L.ptr(d), L.ptr(V))
+        return d, V
+    d, V = np.empty(k), np.empty((k, k))
+    L.call("hfmi_sym_eig_small", handle, L.ptr(T), k, flags, L.ptr(d), L.ptr(V))
     return d, V
 
 

@@ -246,12 +246,25 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
  * (hfmi_eig_dc.hip) -- the algorithm family of the LAPACK routine behind np.linalg.eigh, absolute
  * accuracy eps ||T||.  HFMI_EIG_JACOBI: one-workgroup parallel cyclic Jacobi in LDS (slower; small
  * eigenvalues of graded positive definite matrices to high RELATIVE accuracy).
- * 256 < k <= 4096: two-sided Jacobi over the whole GPU, one workgroup per index pair of a round
- * (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821). */
+ * 256 < k <= 4096 (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821, any number of
+ * snapshots): the same algorithm family over the whole GPU (hfmi_eig_blocked.hip) -- panel Householder
+ * tridiagonalisation with the trailing update on the fp64 MFMA, divide and conquer with the leaves on one compute unit
+ * each and the upper merges on all of them, block-reflector back-transformation.  HFMI_EIG_LARGE=jacobi in the
+ * environment selects the two-sided Jacobi of rounds 2-4 (hfmi_eig_large.hip). */
 #define HFMI_EIG_SORT_ABS 1
 #define HFMI_EIG_JACOBI 2
 int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,
                        double* host_V);
+/* The same with only the nvec leading eigenvectors (in output order) returned; host_V is k x nvec row-major.  What the
+ * deterministic POD uses of la.eigh(G): U[:, :u_rank] (PODProjector.py:821-826).  Beyond 256 the back-transformation and
+ * the read-back run over nvec columns instead of k. */
+int hfmi_sym_eig_leading(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, int nvec, double* host_d,
+                         double* host_V);
+/* la.eigh(X^T (M X)) of the deterministic POD in one call (PODProjector.py:818-826: UtMU = u_data @ M @ u_data.T, eigh,
+ * U[:, :u_rank]): the n x n Gram matrix of two blocks of n vectors is formed on the device and handed to the
+ * eigensolver there; host_d receives the n eigenvalues, host_V the nvec leading eigenvectors (n x nvec row-major). */
+int hfmi_block_gram_eig(const hfmi_block* A, const hfmi_block* B, int sort_by_abs, int nvec, double* host_d,
+                        double* host_V);
 
 /* np.linalg.svd(R) of the small factor inside hp.accuracyEnhancedSVD (activeSubspaceProjector.py:813-834,1026):
  * R (host, k x k row-major) = U diag(sigma) V^T, sigma descending; U, V row-major k x k (columns = vectors).

@@ -1,6 +1,6 @@
 """Wall time of hfmi_sym_eig_small beyond one workgroup (256 < n <= 4096: hfmi_eig_blocked.hip) next to numpy.linalg.eigh on
 the box's host, with the phase split the library prints under HFMI_EIG_LARGE_TIMING=1 (stderr).  Usage:
-python scripts/eig_large_time.py [n ...]; per-kernel times come from the rocprofv3 kernel trace of this script."""
+python scripts/eig_large_time.py [n ...] [--no-host] [--low-rank]; per-kernel times come from the rocprofv3 kernel trace of this script."""
 import sys
 import time
 
@@ -12,8 +12,12 @@ import hippyflow_amd as hf  # noqa: E402
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 1024, 2048, 4096]
 host = "--no-host" not in sys.argv
 rng = np.random.default_rng(0)
+lowrank = "--low-rank" in sys.argv          # Gram matrix of n snapshots that span n / 8 dimensions: most poles deflate in the merges
 for n in sizes:
-    X = rng.standard_normal((n, n + 50)) * np.exp(-0.01 * np.arange(n + 50))[None, :]
+    if lowrank:
+        X = rng.standard_normal((n, max(2, n // 8))) * np.exp(-0.05 * np.arange(max(2, n // 8)))[None, :]
+    else:
+        X = rng.standard_normal((n, n + 50)) * np.exp(-0.01 * np.arange(n + 50))[None, :]
     G = X @ X.T
     d, V = hf.sym_eig_small(G)                  # warm-up: workspace allocation
     ts = []
@@ -21,7 +25,7 @@ for n in sizes:
         t0 = time.perf_counter()
         d, V = hf.sym_eig_small(G)
         ts.append(time.perf_counter() - t0)
-    line = "n=%d  sym_eig_small %.2f ms (min of 3; %.2f max)" % (n, 1e3 * min(ts), 1e3 * max(ts))
+    line = ("low-rank " if lowrank else "") + "n=%d  sym_eig_small %.2f ms (min of 3; %.2f max)" % (n, 1e3 * min(ts), 1e3 * max(ts))
     if host:
         t0 = time.perf_counter()
         w, _ = np.linalg.eigh(G)

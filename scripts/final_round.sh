@@ -7,7 +7,8 @@
 #      one-rank RCCL communicator, 2 ranks sharing the GPU)                   -> <tag>_bench_*.json
 #   4. the un-profiled kernel point               -> <tag>_kernel_point.json
 #   5. kernel timeline of the shard step          -> scripts/shard_profile.sh
-#   6. the eigensolve beyond the BASELINE sizes   -> scripts/eig_corner_trace.sh
+#   6. the eigensolve beyond the BASELINE sizes   -> scripts/eig_corner_trace.sh; beyond 256: scripts/eig_large_time.py, eig_large_trace.sh
+#   7. the 8-rank rehearsal on one GPU and the driver's default command (headline + extras)
 # Summaries land in gpurun_out/; copy what is to be judged into profiles/.
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -24,10 +25,17 @@ done
 timeout 600 python bench.py --samples-total 64 --no-cpu-baseline > $out/${tag}_bench_as_shard64.json 2>/dev/null
 timeout 600 python bench.py --samples-total 64 --no-cpu-baseline --dist-single > $out/${tag}_bench_as_shard64_dist1.json 2>/dev/null
 timeout 600 python bench.py --gpus 2 --samples-total 128 --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_as_2ranks_one_gpu.json 2>/dev/null
+# the 8-rank rehearsal of the driver's --gpus 8 run: all 512 samples, 64 per rank, the eight ranks sharing this box's one GPU (p2p transport)
+timeout 900 python bench.py --gpus 8 --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_as_8ranks_one_gpu.json 2> $out/${tag}_bench_as_8ranks_one_gpu.err
+# the driver's own command: headline + the extra evidence keys (kernel point, configs 3 / 2, shard step) in ONE line
+timeout 900 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 timeout 600 python scripts/kernel_point.py > $out/${tag}_kernel_point.log 2>&1 && cp $out/kernel_point.json $out/${tag}_kernel_point.json
 bash scripts/shard_profile.sh ${tag}_shard64 > $out/${tag}_shard64_timeline.txt 2>&1
 bash scripts/shard_profile.sh ${tag}_shard64_dist1 --samples-total 64 --dist-single > $out/${tag}_shard64_dist1_timeline.txt 2>&1
 bash scripts/eig_corner_trace.sh $tag 138 160 192 224 256 > $out/${tag}_eig_corner.txt 2>&1
+# the whole-GPU eigensolver beyond 256 (hfmi_eig_blocked.hip): wall times next to numpy.linalg.eigh with the phase split, then traces
+HFMI_EIG_LARGE_TIMING=1 timeout 900 python scripts/eig_large_time.py 300 512 1024 2048 4096 > $out/${tag}_eig_large.txt 2>&1
+bash scripts/eig_large_trace.sh $tag 512 1024 2048 4096 > $out/${tag}_eig_large_trace.log 2>&1
 cd $R
 cat $out/${tag}_gputests.log
 ls $out | grep "^${tag}_" | wc -l

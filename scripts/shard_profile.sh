@@ -17,15 +17,24 @@ tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in 
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = [r for r in cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start") if "k_bench" not in r[0]]
-# last full step: find the last 3 launches of the big tn/nn and print the timeline from the first of them
+# The last TIMED step: bench.py runs its timed steps with events on the big contractions only and then up to three extra steps with an
+# event pair per phase (each pair costs ~5 us of idle GPU between two dependent kernels) -- the timeline of one of THOSE, which this
+# script printed up to round 4, overstates the gaps of the steps that are timed.  A step = 3 big launches (tn, nn, tn).
 big = [i for i, r in enumerate(rows) if ("k_tsgemm_tn" in r[0] or "k_tsgemm_nn" in r[0]) and (r[2] - r[1]) > 2e6]
-start = big[-3]
+extra = 3                                   # min(3, --steps) per-phase steps follow the timed region
+start, stop = big[-3 * (extra + 1)], big[-3 * extra]
 t0 = rows[start][1]
 prev_end = t0
-busy = 0
-print("timeline of the last step (us from its first big launch): name, start, duration, gap before")
-for r in rows[start:]:
+gaps = small = bigt = 0.0
+print("timeline of the last TIMED step (us from its first big launch): name, start, duration, gap before")
+for r in rows[start:stop]:
     name = r[0].split("(")[0][:60]
-    print("%-60s %10.1f %9.1f %8.1f" % (name, (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3))
+    dur, gap = (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3
+    print("%-60s %10.1f %9.1f %8.1f" % (name, (r[1] - t0) / 1e3, dur, gap))
+    if r[1] - t0 < 50e6:                    # (the tail of the list belongs to the next step's preparation)
+        gaps += max(gap, 0.0)
+        if dur > 2000: bigt += dur
+        elif "copyBuffer" not in name: small += dur
     prev_end = max(prev_end, r[2])
+print("sum: three contractions %.1f us, other kernels %.1f us, gaps %.1f us" % (bigt, small, gaps))
 PY

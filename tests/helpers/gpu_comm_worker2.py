@@ -78,18 +78,26 @@ def main():
             X = hf.MultiVector(N, k, ctx=ctx)
             _ParRandom(70 + 10 * i + rank).normal(1.0, X)
             srcs.append(X)
-        first, same = {}, True
+        first, ref, same, bad = {}, {}, True, []
         for rep in range(reps):
             i, op = rep & 1, ("sum", "avg")[(rep >> 1) & 1]
             Y = hf.MultiVector(srcs[i])                     # a fresh copy of this rank's input
             coll.allReduce(Y, op)
-            digest = hashlib.sha256(np.ascontiguousarray(Y.to_dense()).tobytes()).hexdigest()
+            got = np.ascontiguousarray(Y.to_dense())
+            digest = hashlib.sha256(got.tobytes()).hexdigest()
             if (i, op) in first:
-                same = same and first[(i, op)] == digest
+                if first[(i, op)] != digest:
+                    same = False
+                    diff = got != ref[(i, op)]
+                    rows = np.nonzero(diff.any(axis=1))[0]
+                    bad.append({"rep": rep, "shape": i, "op": op, "entries": int(diff.sum()), "first_row": int(rows[0]), "last_row": int(rows[-1]),
+                                "max_abs": float(np.abs(got - ref[(i, op)]).max())})
             else:
-                first[(i, op)] = digest
+                first[(i, op)], ref[(i, op)] = digest, got
+        desc = coll.describe()
         with open(os.path.join(outdir, "soak_rank%d.json" % rank), "w") as f:
-            json.dump(dict(res, reps=reps, same=bool(same), digests={"%d%s" % key: v for key, v in first.items()}), f)
+            json.dump(dict(res, reps=reps, same=bool(same), mismatches=bad[:20], digests={"%d%s" % key: v for key, v in first.items()},
+                           probe_rounds=desc.get("p2p_probe_rounds"), probe_retries_total=desc.get("p2p_probe_retries_total")), f)
         coll.barrier()
         coll.close()
         return 0

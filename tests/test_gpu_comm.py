@@ -183,4 +183,5 @@ def test_p2p_reduction_is_bit_identical_over_200_repetitions(tmp_path):
     rs = [json.load(open(os.path.join(str(tmp_path), "soak_rank%d.json" % r))) for r in range(4)]
     for r in rs:
         assert r["transport"] == "p2p" and r["p2p_sync"] == "stream" and r["reps"] == 200
-        assert r["same"] and r["digests"] == rs[0]["digests"] and len(r["digests"]) == 4
+        assert r["same"], r["mismatches"]
+        assert r["digests"] == rs[0]["digests"] and len(r["digests"]) == 4

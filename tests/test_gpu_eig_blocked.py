@@ -140,3 +140,40 @@ def test_sym_eig_small_on_already_reduced_inputs(ctx, k, kind):
         assert np.abs(d - w).max() <= 1e-13 * scale * k
         assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-12
         assert np.abs(T @ V - V * d).max() <= 1e-13 * scale * k
+
+
+@pytest.mark.parametrize("n,nvec", [(100, 7), (256, 256), (300, 1), (700, 64), (1300, 200), (2048, 128)])
+def test_sym_eig_leading_eigenvectors_only(ctx, n, nvec):
+    """hfmi_sym_eig_leading: all eigenvalues, the nvec leading eigenvectors -- what PODProjectorFromData uses of la.eigh(G)
+    (PODProjector.py:821-826); beyond 256 rows the back-transformation runs over nvec columns.  Same bits as the full call."""
+    rng = np.random.default_rng(n + nvec)
+    X = rng.standard_normal((n, 80)) * np.exp(-0.05 * np.arange(80))[None, :]
+    G = X @ X.T
+    d_full, V_full = hf.sym_eig_small(G)
+    d, V = hf.sym_eig_small(G, nvec=nvec)
+    assert V.shape == (n, min(nvec, n))
+    np.testing.assert_array_equal(d, d_full)
+    np.testing.assert_allclose(V, V_full[:, :nvec], atol=1e-13)
+    lead = min(nvec, 60)                                       # (beyond the rank of G the eigenvectors of the zero cluster are arbitrary)
+    assert np.abs(G @ V[:, :lead] - V[:, :lead] * d[:lead]).max() <= 1e-12 * d[0]
+
+
+@pytest.mark.parametrize("n,N,nvec", [(40, 3000, 10), (256, 2000, 256), (300, 5000, 20), (1000, 2500, 128)])
+def test_gram_eig_of_two_blocks_stays_on_the_device(ctx, n, N, nvec):
+    """hfmi_block_gram_eig = la.eigh(X^T (M X))[:, :u_rank] of PODProjectorFromData (PODProjector.py:818-826) without the n x n
+    matrix crossing PCIe: against numpy on the same blocks."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((N, min(n, 60))) @ (rng.standard_normal((min(n, 60), n)) * np.exp(-0.1 * np.arange(min(n, 60)))[:, None])
+    w = rng.uniform(0.5, 2.0, N)                                # a diagonal "mass matrix"
+    Xm, MXm = hf.MultiVector.from_dense(X), hf.MultiVector.from_dense(X * w[:, None])
+    d, V = Xm.gram_eig(MXm, nvec)
+    G = X.T @ (X * w[:, None])
+    wr = np.linalg.eigvalsh(G)[::-1]
+    assert V.shape == (n, nvec)
+    assert np.abs(d - wr).max() <= 1e-12 * wr[0]
+    lead = min(nvec, 40)
+    assert np.abs(G @ V[:, :lead] - V[:, :lead] * d[:lead]).max() <= 2e-12 * wr[0]
+    assert np.abs(V[:, :lead].T @ V[:, :lead] - np.eye(lead)).max() <= 1e-12
+    d2, V2 = hf.sym_eig_small(Xm.dot_mv(MXm), nvec=nvec)       # the two-call form: same eigenvalues, same leading subspace
+    np.testing.assert_allclose(d2, d, atol=1e-13 * wr[0])
+    np.testing.assert_allclose(np.abs(np.sum(V2[:, :lead] * V[:, :lead], axis=0)), 1.0, atol=1e-9)
