@@ -97,7 +97,7 @@ def main():
         desc = coll.describe()
         with open(os.path.join(outdir, "soak_rank%d.json" % rank), "w") as f:
             json.dump(dict(res, reps=reps, same=bool(same), mismatches=bad[:20], digests={"%d%s" % key: v for key, v in first.items()},
-                           probe_rounds=desc.get("p2p_probe_rounds"), probe_retries_total=desc.get("p2p_probe_retries_total")), f)
+                           probe_rounds=desc.get("p2p_probe_rounds"), probe_retries_total=desc.get("p2p_regenerations_total")), f)
         coll.barrier()
         coll.close()
         return 0
