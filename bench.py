@@ -557,7 +557,8 @@ def kernel_point_line(args):
 
 def _compact(line):
     """What an extra workload contributes to the headline line: time, dominant kernel against its roof, parity, a host baseline."""
-    out = {k: line.get(k) for k in ("value", "unit", "ms_per_step", "median_ms_per_step", "literal_T_ms_per_step", "steps", "warmup")}
+    out = {k: line.get(k) for k in ("value", "unit", "ms_per_step", "median_ms_per_step", "step_ms_min_max", "value_from_median",
+                                    "literal_T_ms_per_step", "steps", "warmup")}
     out["workload"] = (line.get("config") or {}).get("workload")
     rf = line.get("roofline") or {}
     out["roofline"] = {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic")}
@@ -582,7 +583,7 @@ def run_extras(args):
     import subprocess
     q = ["--quick"] if args.quick else []
     jobs = [("kernel_point", ["--kernel-point"] + q, 60),
-            ("config3", ["--workload", "pod", "--steps", "5", "--warmup", "2", "--cpu-baseline", "quick"] + q, 120),
+            ("config3", ["--workload", "pod", "--steps", "10", "--warmup", "3", "--cpu-baseline", "quick"] + q, 120),
             ("config2", ["--workload", "kle", "--steps", "5", "--warmup", "2", "--cpu-baseline", "quick"] + q, 180),
             ("shard64", ["--samples-total", "64", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90),
             ("shard64_rccl_1rank", ["--samples-total", "64", "--dist-single", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90)]

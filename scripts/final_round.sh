@@ -20,7 +20,7 @@ for w in as pod kle; do MIN_MS=0.05 bash scripts/pmc_workload.sh $w $tag > $out/
 cd $R
 python profiles/make_pmc_traffic.py $tag $out > $out/${tag}_make_pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 for w in as pod kle; do
-  timeout 900 python bench.py --workload $w > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err
+  timeout 900 python bench.py --workload $w --headline-only > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err
 done
 timeout 600 python bench.py --samples-total 64 --no-cpu-baseline > $out/${tag}_bench_as_shard64.json 2>/dev/null
 timeout 600 python bench.py --samples-total 64 --no-cpu-baseline --dist-single > $out/${tag}_bench_as_shard64_dist1.json 2>/dev/null

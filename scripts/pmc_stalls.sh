@@ -14,7 +14,7 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
-  ( cd $R && rocprofv3 --kernel-trace --output-format csv --pmc $grp -d /tmp/stalls/run_$i -- python3 bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-literal > /dev/null 2>/tmp/stalls/err_$i )
+  ( cd $R && rocprofv3 --kernel-trace --output-format csv --pmc $grp -d /tmp/stalls/run_$i -- python3 bench.py "$@" --headline-only --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-literal > /dev/null 2>/tmp/stalls/err_$i )
   mkdir -p /tmp/stalls/pmc_$i
   f=$(find /tmp/stalls/run_$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f /tmp/stalls/pmc_$i/counter_collection.csv || tail -3 /tmp/stalls/err_$i

@@ -8,7 +8,7 @@ out=$R/gpurun_out; mkdir -p $out/${tag}_pmc_$w
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $grp | cut -d' ' -f1)
   rm -rf /tmp/pmc_$name
-  ( cd $R && rocprofv3 --kernel-trace --output-format csv --pmc $grp -d /tmp/pmc_$name -- python3 bench.py --workload $w --steps 1 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2>&1 )
+  ( cd $R && rocprofv3 --kernel-trace --output-format csv --pmc $grp -d /tmp/pmc_$name -- python3 bench.py --workload $w --headline-only --steps 1 --warmup 1 --no-cpu-baseline --no-check > /dev/null 2>&1 )
   mkdir -p $out/${tag}_pmc_$w/pmc_$name
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $out/${tag}_pmc_$w/pmc_$name/counter_collection.csv

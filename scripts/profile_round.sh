@@ -10,7 +10,7 @@ out=$R/gpurun_out
 mkdir -p $out
 for w in as pod kle; do
   rm -rf /tmp/prof_$w
-  ( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-check > $out/${tag}_${w}_bench.json 2> $out/${tag}_${w}_prof.err )
+  ( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python3 bench.py --workload $w --headline-only --steps 3 --warmup 1 --no-cpu-baseline --no-check > $out/${tag}_${w}_bench.json 2> $out/${tag}_${w}_prof.err )
   db=$(find /tmp/prof_$w -name "*.db" | head -1)
   [ -n "$db" ] && python3 $R/profiles/summarize_rocpd.py $db > $out/${tag}_${w}_kernel_stats.csv
 done

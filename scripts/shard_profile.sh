@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out; mkdir -p $out
 rm -rf /tmp/prof_shard
-( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py $args --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-literal > $out/${name}_bench.json 2> $out/${name}_prof.err )
+( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -- python3 bench.py $args --headline-only --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-literal > $out/${name}_bench.json 2> $out/${name}_prof.err )
 db=$(find /tmp/prof_shard -name "*.db" | head -1)
 python3 $R/profiles/summarize_rocpd.py $db > $out/${name}_kernel_stats.csv
 python3 - <<PY
@@ -27,14 +27,18 @@ t0 = rows[start][1]
 prev_end = t0
 gaps = small = bigt = 0.0
 print("timeline of the last TIMED step (us from its first big launch): name, start, duration, gap before")
+in_step = True
 for r in rows[start:stop]:
     name = r[0].split("(")[0][:60]
     dur, gap = (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3
     print("%-60s %10.1f %9.1f %8.1f" % (name, (r[1] - t0) / 1e3, dur, gap))
-    if r[1] - t0 < 50e6:                    # (the tail of the list belongs to the next step's preparation)
+    side = "copyBuffer" in name or "fillBuffer" in name     # copies of the auxiliary stream / the next step's preparation: beside the solve
+    if not side and gap > 500.0:
+        in_step = False                     # the host is between two steps
+    if in_step and not side:
         gaps += max(gap, 0.0)
         if dur > 2000: bigt += dur
-        elif "copyBuffer" not in name: small += dur
-    prev_end = max(prev_end, r[2])
-print("sum: three contractions %.1f us, other kernels %.1f us, gaps %.1f us" % (bigt, small, gaps))
+        else: small += dur
+        prev_end = max(prev_end, r[2])
+print("sum over the kernels of the solve's stream: three contractions %.1f us, other kernels %.1f us, gaps between them %.1f us" % (bigt, small, gaps))
 PY
