@@ -71,6 +71,9 @@ def parse_args():
                          "shard step) that a default --gpus 1 run of config 4 appends as extra keys (A/B runs, profiling)")
     ap.add_argument("--kernel-point", action="store_true",
                     help="north-star kernel point instead of a solve: G = X^T Omega at N = 1e6, k = 138, n in {8 ... 2048}; one JSON line")
+    ap.add_argument("--eig-large", action="store_true",
+                    help="the whole-GPU symmetric eigensolver behind the deterministic POD (la.eigh(G), PODProjector.py:812-833) instead of a "
+                         "solve: n = 512 ... 4096, wall time of hfmi_sym_eig_small next to numpy.linalg.eigh on the host; one JSON line")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick"],
                     help="quick: the host legs at all threads and at one socket's cores only (no single-thread legs)")
     return ap.parse_args()
@@ -555,6 +558,47 @@ def kernel_point_line(args):
                                        "peaks": {"hbm_gbs": HBM_PEAK_GBS, "fp64_mfma_tflops": FP64_MFMA_PEAK_TFLOPS}}}), flush=True)
 
 
+def eig_large_line(args):
+    """--eig-large: la.eigh(G) of the deterministic POD for 256 < n <= 4096 snapshots on the device: Gram matrix of
+    n + 50 decaying snapshots, all eigenvectors, host matrix in and out (min of three calls after one warm-up), the POD form beside it
+    (hfmi_block_gram_eig: X^T X formed on the device, 128 leading eigenvectors returned), numpy.linalg.eigh on the host's threads as the
+    CPU baseline (not at n = 4096, where it takes 6-7 s) and the parity of the two: eigenvalues, orthonormality, residual."""
+    import hippyflow_amd as hf
+    hf.Context.default()
+    rng = np.random.default_rng(0)
+    rows = []
+    for n in ((300, 512) if args.quick else (512, 1024, 2048, 4096)):
+        X = rng.standard_normal((n, n + 50)) * np.exp(-0.01 * np.arange(n + 50))[None, :]
+        G = X @ X.T
+        hf.sym_eig_small(G)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            d, V = hf.sym_eig_small(G)
+            ts.append(time.perf_counter() - t0)
+        Xm = hf.MultiVector.from_vectors(X)             # n snapshots of length n + 50: one per vector
+        Xm.gram_eig(Xm, min(128, n))
+        tg = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dg, Vg = Xm.gram_eig(Xm, min(128, n))
+            tg.append(time.perf_counter() - t0)
+        row = {"n": n, "ms": 1e3 * min(ts), "ms_max": 1e3 * max(ts), "gram_eig_128_ms": 1e3 * min(tg),
+               "orthonormality": float(np.abs(V.T @ V - np.eye(n)).max()),
+               "residual_rel": float(np.abs(G @ V - V * d).max() / d[0]), "host_eigh_ms": None, "eig_err_rel_vs_host": None,
+               "gram_eig_err_rel": float(np.abs(dg - d).max() / d[0])}
+        if n <= 2048:
+            t0 = time.perf_counter()
+            w = np.linalg.eigh(G)[0]                  # eigenvalues AND eigenvectors, as the reference's la.eigh(G) computes them
+            row["host_eigh_ms"] = 1e3 * (time.perf_counter() - t0)
+            row["eig_err_rel_vs_host"] = float(np.abs(d - w[::-1]).max() / w[-1])
+        rows.append(row)
+    topo = _cpu_topology()
+    print(json.dumps({"eig_large": {"rows": rows, "dtype": "f64", "build_tag": hf.build_tag(), "host_threads": topo["threads"],
+                                    "what": "hfmi_sym_eig_small (all eigenvectors, host in / host out) and hfmi_block_gram_eig (POD form) "
+                                            "vs numpy.linalg.eigh"}}), flush=True)
+
+
 def _compact(line):
     """What an extra workload contributes to the headline line: time, dominant kernel against its roof, parity, a host baseline."""
     out = {k: line.get(k) for k in ("value", "unit", "ms_per_step", "median_ms_per_step", "step_ms_min_max", "value_from_median",
@@ -583,6 +627,7 @@ def run_extras(args):
     import subprocess
     q = ["--quick"] if args.quick else []
     jobs = [("kernel_point", ["--kernel-point"] + q, 60),
+            ("eig_large", ["--eig-large"] + q, 90),
             ("config3", ["--workload", "pod", "--steps", "10", "--warmup", "3", "--cpu-baseline", "quick"] + q, 120),
             ("config2", ["--workload", "kle", "--steps", "5", "--warmup", "2", "--cpu-baseline", "quick"] + q, 180),
             ("shard64", ["--samples-total", "64", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90),
@@ -601,7 +646,7 @@ def run_extras(args):
                 extras[name] = {"error": "exit code %d" % res.returncode, "stderr_tail": res.stderr.decode("utf-8", "replace")[-600:]}
             else:
                 line = json.loads(lines[-1])
-                extras[name] = line["kernel_point"] if name == "kernel_point" else _compact(line)
+                extras[name] = line[name] if name in ("kernel_point", "eig_large") else _compact(line)
         except subprocess.TimeoutExpired:
             extras[name] = {"error": "timed out after %d s" % limit}
         except Exception as exc:                          # never let an extra cost the headline
@@ -659,6 +704,8 @@ def main():
         return dipnet_line(args)
     if args.kernel_point:
         return kernel_point_line(args)
+    if args.eig_large:
+        return eig_large_line(args)
     if args.ingest:
         return ingest_line(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -687,7 +734,7 @@ def main():
         return
     if kernel_extras_wanted(args, world):
         out.update(run_extras(args))
-        out["extra_keys"] = ["kernel_point", "config3", "config2", "shard64", "shard64_rccl_1rank"]
+        out["extra_keys"] = ["kernel_point", "eig_large", "config3", "config2", "shard64", "shard64_rccl_1rank"]
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 def _args(**kw):
     base = dict(gpus=1, steps=10, warmup=3, workload="as", prior=False, quick=False, headline_only=False, dist_single=False,
-                samples_total=512, kernel_point=False)
+                samples_total=512, kernel_point=False, eig_large=False)
     base.update(kw)
     return argparse.Namespace(**base)
 
