@@ -177,3 +177,26 @@ def test_gram_eig_of_two_blocks_stays_on_the_device(ctx, n, N, nvec):
     d2, V2 = hf.sym_eig_small(Xm.dot_mv(MXm), nvec=nvec)       # the two-call form: same eigenvalues, same leading subspace
     np.testing.assert_allclose(d2, d, atol=1e-13 * wr[0])
     np.testing.assert_allclose(np.abs(np.sum(V2[:, :lead] * V[:, :lead], axis=0)), 1.0, atol=1e-9)
+
+
+@pytest.mark.parametrize("shifted", [True, False])
+@pytest.mark.parametrize("method", ["hep", "ghep", "inverse_ghep"])
+def test_pod_from_data_320_snapshots_matches_the_reference(ctx, golden_dir, method, shifted):
+    """PODProjectorFromData.construct_subspace on 320 snapshots -- the n x n Gram problem (la.eigh(G), PODProjector.py:812-833) now goes
+    through hfmi_block_gram_eig and the whole-GPU eigensolver -- against the outputs of the REFERENCE's own construct_subspace on the same
+    (integer-valued, hence bit-identical) snapshot matrix: tests/golden/pod_from_data_320.npz, made by tests/golden/make_pod_large_golden.py."""
+    import os
+    import scipy.sparse as sp
+    g = np.load(os.path.join(golden_dir, "pod_from_data_320.npz"))
+    N, r = int(g["N"]), int(g["r"])
+    M = sp.csr_matrix((g["M_data"], g["M_indices"], g["M_indptr"]), shape=(N, N))
+    u_data = g["u_int16"].astype(np.float64) * float(g["scale"])
+    d, phi, Mphi, shift = hf.PODProjectorFromData(None, M).construct_subspace(u_data.copy(), r, shifted=shifted, method=method)
+    tag = "%s_%d" % (method, int(shifted))
+    np.testing.assert_allclose(shift, g["shift_" + tag], atol=1e-14)
+    np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-8)
+    cos = np.abs(np.einsum("ij,ij->j", phi[:, :6], M @ g["phi_" + tag][:, :6]))
+    np.testing.assert_allclose(cos, 1.0, atol=1e-8)
+    eye = np.eye(r)
+    assert np.linalg.norm(eye - phi.T @ Mphi) / np.linalg.norm(eye) < 1e-8        # test_PODProjector.py:154-168
+    assert np.linalg.norm(M @ phi - Mphi) / np.linalg.norm(Mphi) < 1e-8           # :170-174

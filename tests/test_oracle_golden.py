@@ -122,3 +122,20 @@ def test_mass_preconditioned_covariance_and_consumers(golden_dir):
     np.testing.assert_allclose(U @ (U.T @ (M @ g["x"])), g["prior_precond_proj"], rtol=1e-12)
     np.testing.assert_allclose(U @ (s * (V.T @ g["x13"])), g["lowrank_mult"], rtol=1e-12)
     np.testing.assert_allclose(V @ (s * (U.T @ g["x"])), g["lowrank_transpmult"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("shifted", [True, False])
+@pytest.mark.parametrize("method", ["hep", "ghep", "inverse_ghep"])
+def test_pod_from_data_with_320_snapshots_matches_reference(golden_dir, method, shifted):
+    """The same pin on a snapshot set beyond 256 (tests/golden/make_pod_large_golden.py: the reference's construct_subspace on 320
+    integer-valued snapshots): the oracle here, the whole-GPU eigensolver path in tests/test_gpu_eig_blocked.py."""
+    g = _load(golden_dir, "pod_from_data_320.npz")
+    N, r = int(g["N"]), int(g["r"])
+    M = _csr(g, N)
+    u_data = g["u_int16"].astype(np.float64) * float(g["scale"])
+    tag = "%s_%d" % (method, int(shifted))
+    d, phi, Mphi, shift = hf_o.pod_from_data(u_data.copy(), M, r, shifted=shifted, method=method)
+    np.testing.assert_allclose(shift, g["shift_" + tag], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-8)
+    cosines = np.abs(np.einsum("ij,ij->j", phi[:, :6], M @ g["phi_" + tag][:, :6]))
+    np.testing.assert_allclose(cosines, 1.0, atol=1e-8)
