@@ -1691,7 +1691,9 @@ extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, in
   if (!ctx || !host_T || !host_d) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   if (k < 1 || k > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_small: k=%d out of range [1,4096]", k);
   HIP_TRY(hipSetDevice(ctx->device));
-  if (k > SM_MAXK) return sym_eig_large(ctx, host_T, k, sort_by_abs, host_d, host_V);   // whole-GPU one-sided Jacobi
+  if (k > SM_MAXK) return sym_eig_large(ctx, host_T, k, sort_by_abs, host_d, host_V);   // whole-GPU blocked solver (checks its input on the device)
+  for (size_t i = 0; i < (size_t)k * k; ++i)
+    if (!std::isfinite(host_T[i])) HFMI_FAIL(HFMI_ERR_NUMERIC, "sym_eig (n=%d): the matrix has non-finite entries", k);
   HFMI_TRY(upload_small(ctx, host_T, k, k, sm_ptr(ctx, SM_T), SM_LD));
   void* dv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_G, (size_t)SM_MAXK * sizeof(double), &dv));

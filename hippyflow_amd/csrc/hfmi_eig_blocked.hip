@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_sym_load(const double* __restrict__ raw
     const double v = 0.5 * (t1[tx][b] + t2[b][tx]);
     if (i0 + tx < n && j0 + b < n) {
       A[(size_t)(i0 + tx) + (size_t)(j0 + b) * ld] = v;
-      mx = fmax(mx, fabs(v));
+      mx = fmax(mx, v == v ? fabs(v) : INFINITY);
     }
   }
   mx = wave_max(mx);
@@ -225,13 +225,15 @@ __global__ __launch_bounds__(1024) void k_scale_exp(const double* __restrict__ p
     for (int q = 0; q < 16; ++q) amax = fmax(amax, s_red[q]);
     int sexp = 0;
     if (amax > 0.0 && isfinite(amax)) sexp = ilogb(amax);
-    *sexp_out = sexp;
+    sexp_out[0] = sexp;
+    sexp_out[1] = isfinite(amax) ? 0 : 1;        // (fmax drops NaNs: the per-tile pass counts them into the maximum as +inf)
   }
 }
 __global__ __launch_bounds__(256) void k_scale_apply(double* __restrict__ A, int64_t ld, int n, const int* __restrict__ sexp) {
-  const double sc = ldexp(1.0, -*sexp);
+  const double sc = ldexp(1.0, -sexp[0]);
+  const bool bad = sexp[1] != 0;               // non-finite input: the solve runs on zeros (bounded work), the host reports the error
   double* col = A + (size_t)blockIdx.x * ld;
-  for (int r = threadIdx.x; r < n; r += 256) col[r] *= sc;
+  for (int r = threadIdx.x; r < n; r += 256) col[r] = bad ? 0.0 : col[r] * sc;
 }
 
 // ------------------------------------------------------------------------------------------------ tridiagonalisation
@@ -606,13 +608,14 @@ __global__ __launch_bounds__(256) void k_dcl_rank(dcl_args p) {
 // Then the kept poles are gathered and the new column order of the node is fixed: kept poles first (ascending), the deflated
 // columns behind them (ascending).
 __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
-  // dynamic LDS, cap = the largest node of the level rounded up to 64: 26 bytes per pole (106 KB at 4096)
+  // dynamic LDS, cap = the largest node of the level rounded up to 64: 30 bytes per pole (123 KB at 4096)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   double* s_d = (double*)s_raw;
   double* s_z = s_d + cap;
   int* s_ks = (int*)(s_z + cap);
   int* s_kp = s_ks + cap;
-  unsigned char* s_kept = (unsigned char*)(s_kp + cap);
+  int* s_li = s_kp + cap;                      // sorted position -> index in the live list (-1: deflated by the first test)
+  unsigned char* s_kept = (unsigned char*)(s_li + cap);
   unsigned char* s_lv = s_kept + cap;
   __shared__ int s_scan[1024];
   __shared__ int s_any, s_K, s_nrot;
@@ -633,7 +636,12 @@ __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
     s_kp[i] = i;
     s_kept[i] = 1;
   }
-  for (int q = tid; q < nn; q += 1024) s_lv[q] = (unsigned char)p.Live[lo + q];
+  for (int q = tid; q < nn; q += 1024) {
+    s_lv[q] = (unsigned char)p.Live[lo + q];
+    s_li[q] = -1;
+  }
+  __syncthreads();
+  for (int i = tid; i < K0; i += 1024) s_li[s_ks[i] - lo] = i;
   __syncthreads();
   for (int i = 1 + tid; i < K0; i += 1024) {
     const double zs = s_z[i], zp = s_z[i - 1], t = s_d[i] - s_d[i - 1];
@@ -708,15 +716,12 @@ __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
     __syncthreads();
   }
   int pos = s_scan[tid] - dead;
-  // the eigenvalue of a deflated column: its (possibly rotated) pole.  Rotated poles sit in s_d under their live index: map back
-  // through a second pass over the live list (a dead-by-rotation position is a live-list member with kept = 0)
-  for (int i = tid; i < K0; i += 1024)
-    if (!s_kept[i]) p.Ds[s_ks[i]] = s_d[i];
-  __syncthreads();
+  // the eigenvalue of a deflated column: its pole -- the rotated one (in LDS under its live index) if a rotation deflated it
   for (int q = tid * per; q < min(nn, (tid + 1) * per); ++q) {
     if (!s_lv[q]) {
+      const int li = s_li[q];
       p.Src[lo + K + pos] = p.Col[lo + q];
-      p.Dnew[lo + K + pos] = p.Ds[lo + q];
+      p.Dnew[lo + K + pos] = li >= 0 ? s_d[li] : p.Ds[lo + q];
       ++pos;
     }
   }
@@ -1130,7 +1135,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       hipLaunchKernelGGL(k_dcl_z, dim3(nn), dim3(1024), 0, st, da);
       hipLaunchKernelGGL(k_dcl_rank, dim3((n + 63) / 64), dim3(256), 0, st, da);
       const int cap = (int)round_up((n + nn - 1) / nn + 1, 64);
-      const size_t defl_lds = (size_t)cap * 26;
+      const size_t defl_lds = (size_t)cap * 30;
       HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
       hipLaunchKernelGGL(k_dcl_deflate, dim3(nn), dim3(1024), defl_lds, st, da, cap);
       HIP_TRY(hipGetLastError());
@@ -1167,10 +1172,11 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
 
   // ---- eigenvalues to the host, output order
   std::vector<double> lam(n);
-  int hfail[2] = {0, 0};
+  int hfail[3] = {0, 0, 0};
   HIP_TRY(hipMemcpyAsync(lam.data(), Dcur, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(hfail, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hfail, fail, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (hfail[2]) HFMI_FAIL(HFMI_ERR_NUMERIC, "sym_eig (n=%d): the matrix has non-finite entries", n);
   if (hfail[0]) HFMI_FAIL(HFMI_ERR_NOT_CONVERGED, "sym_eig (n=%d): a secular equation did not converge", n);
   std::vector<int> perm(n);
   std::iota(perm.begin(), perm.end(), 0);

@@ -179,6 +179,29 @@ def test_gram_eig_of_two_blocks_stays_on_the_device(ctx, n, N, nvec):
     np.testing.assert_allclose(np.abs(np.sum(V2[:, :lead] * V[:, :lead], axis=0)), 1.0, atol=1e-9)
 
 
+@pytest.mark.parametrize("n", [40, 300, 1100])
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_sym_eig_refuses_non_finite_input(ctx, n, bad):
+    """numpy.linalg.eigh raises on NaN / inf input; so does the device solver (HFMI_ERR_NUMERIC), on both sides of n = 256, through
+    the host-matrix entry and through the on-device Gram form -- and the context stays usable."""
+    rng = np.random.default_rng(n)
+    T = rng.standard_normal((n, n))
+    T = T + T.T
+    Tb = T.copy()
+    Tb[n // 3, n // 2] = bad
+    with pytest.raises(hf.HfmiError, match="non-finite"):
+        hf.sym_eig_small(Tb)
+    with pytest.raises(hf.HfmiError, match="non-finite"):
+        hf.sym_eig_small(Tb, nvec=5)
+    if n > 256:
+        X = rng.standard_normal((2000, n))
+        X[17, 5] = bad
+        Xm = hf.MultiVector.from_dense(X)
+        with pytest.raises(hf.HfmiError, match="non-finite"):
+            Xm.gram_eig(Xm, 5)
+    _check(T, 2e-12)
+
+
 @pytest.mark.parametrize("shifted", [True, False])
 @pytest.mark.parametrize("method", ["hep", "ghep", "inverse_ghep"])
 def test_pod_from_data_320_snapshots_matches_the_reference(ctx, golden_dir, method, shifted):
