@@ -930,8 +930,9 @@ def weighted_l2_norm_vector(x, W):
 class PODProjectorFromData:
     """Deterministic mass-weighted POD from a snapshot matrix (PODProjector.py:666-852).
     ``method='hep'`` (n << N) runs on the device: the n x n Gram matrix X^T M X and the back-transform
-    phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is a Jacobi kernel (one workgroup up to
-    256 snapshots, one workgroup per column pair over the whole GPU up to 4096) -- same steps as :812-833.
+    phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is tridiagonalisation + divide and conquer
+    (one workgroup up to 256 snapshots; panels, merges and block reflectors over the whole GPU up to 4096:
+    ``hfmi_block_gram_eig``, only the u_rank wanted eigenvectors come back) -- same steps as :812-833.
 
     ``method='ghep'`` (H = M X (M X)^T / n against M, :743-773) and ``'inverse_ghep'`` (H = X X^T / n against
     M^-1, :775-810) are ARPACK Lanczos iterations on the host in the reference.  Both pencils have their
