@@ -1689,7 +1689,7 @@ extern "C" int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* 
 // ------------------------------------------------------------------ Rayleigh-Ritz
 extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d, double* host_V) {
   if (!ctx || !host_T || !host_d) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
-  if (k < 1 || k > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_small: k=%d out of range [1,4096]", k);
+  if (k < 1 || k > HFMI_EIG_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_small: k=%d out of range [1,%d]", k, HFMI_EIG_MAXN);
   HIP_TRY(hipSetDevice(ctx->device));
   if (k > SM_MAXK) return sym_eig_large(ctx, host_T, k, sort_by_abs, host_d, host_V);   // whole-GPU blocked solver (checks its input on the device)
   for (size_t i = 0; i < (size_t)k * k; ++i)
@@ -1716,7 +1716,7 @@ extern "C" int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, in
 // over nvec columns instead of k
 extern "C" int hfmi_sym_eig_leading(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, int nvec, double* host_d, double* host_V) {
   if (!ctx || !host_T || !host_d || !host_V) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
-  if (k < 1 || k > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_leading: k=%d out of range [1,4096]", k);
+  if (k < 1 || k > HFMI_EIG_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_leading: k=%d out of range [1,%d]", k, HFMI_EIG_MAXN);
   if (nvec < 1 || nvec > k) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig_leading: nvec=%d out of range [1,%d]", nvec, k);
   HIP_TRY(hipSetDevice(ctx->device));
   if (k > SM_MAXK) return sym_eig_large(ctx, host_T, k, sort_by_abs, host_d, host_V, nvec);
@@ -1734,7 +1734,7 @@ extern "C" int hfmi_block_gram_eig(const hfmi_block* A, const hfmi_block* B, int
   if (A->N != B->N) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: vector lengths differ (%lld vs %lld)", (long long)A->N, (long long)B->N);
   if (A->nvec != B->nvec) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: the blocks hold %d and %d vectors", A->nvec, B->nvec);
   const int n = A->nvec;
-  if (n < 1 || n > 4096) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: n=%d out of range [1,4096]", n);
+  if (n < 1 || n > HFMI_EIG_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: n=%d out of range [1,%d]", n, HFMI_EIG_MAXN);
   if (nvec < 1 || nvec > n) HFMI_FAIL(HFMI_ERR_INVALID, "block_gram_eig: nvec=%d out of range [1,%d]", nvec, n);
   hfmi_ctx* ctx = A->ctx;
   HIP_TRY(hipSetDevice(ctx->device));

@@ -1,4 +1,4 @@
-// Whole-GPU symmetric eigensolver for 256 < n <= 4096: the n x n Gram problem of the deterministic POD (la.eigh(G),
+// Whole-GPU symmetric eigensolver for 256 < n <= 8192: the n x n Gram problem of the deterministic POD (la.eigh(G),
 // PODProjector.py:812-833 -- any number of snapshots; dataGenerator.py:278-279 hands it the whole training set), i.e. LAPACK
 // dsyevd's algorithm family spread over the 256 compute units instead of the one-workgroup kernels of hfmi_eig_dc.hip:
 //
@@ -40,7 +40,7 @@ int sym_eig_large_jacobi(hfmi_ctx* ctx, const double* host_T, int n, int sort_by
 
 namespace {
 constexpr int EB_NB = 64;          // panel width of the tridiagonalisation and of the block reflectors
-constexpr int EB_MAXN = 4096;
+constexpr int EB_MAXN = HFMI_EIG_MAXN;      // 8192: v of k_tri_b (64 KB) and the poles of the top merge (16 bytes each) live in LDS
 constexpr int GT = 64;             // k_dgemm: C tile
 constexpr int GK = 16;             // reduction depth of an LDS stage
 constexpr int GLD = 80;            // LDS row stride: = 16 mod 32 doubles, so the four k-rows of an MFMA operand fall into two bank halves
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
 }
 
 // 512 threads; dynamic LDS: v on rows [rs, ld), rs = (j + 1) rounded down to 64
-template <int UNR>
+template <int UNR, int CB>
 __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   extern __shared__ __attribute__((aligned(16))) double s_v[];
   __shared__ double s_part[8];
@@ -383,14 +383,17 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   }
   // column j of the reduced matrix: every load of it is requested before the first use (a loop over a run-time count would wait
   // for each load before issuing the next: 8 x an L2 round trip per column at n = 4096)
-  double cb[EB_MAXN / 512];
+  double cb[CB];           // CB = 8: n <= 4096, 16: n <= 8192
 #pragma unroll
-  for (int u = 0; u < EB_MAXN / 512; ++u) {
+  for (int u = 0; u < CB; ++u) {
     const int r = rs + tid + 512 * u;
     cb[u] = (r > j + 1 && r < n) ? p.colbuf[r] : 0.0;
   }
   const double alpha0 = p.colbuf[j + 1];
-  const double xn2 = wave_sum(l < p.npn ? p.pn[l] : 0.0);       // at most 64 partial sums (one per 64 rows), one per lane
+  // one partial sum per 64 rows: at most 64 (one per lane) up to n = 4096, two per lane beyond
+  double pnl = l < p.npn ? p.pn[l] : 0.0;
+  if (CB > 8) pnl += l + 64 < p.npn ? p.pn[l + 64] : 0.0;
+  const double xn2 = wave_sum(pnl);
   double tau = 0.0, beta = alpha0, scl = 0.0;
   if (xn2 > 1e-280) {      // entries are scaled to O(1): below this the column is zero to any precision that matters
     const double nrm = sqrt(fma(alpha0, alpha0, xn2));
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
     scl = 1.0 / (alpha0 - beta);
   }
 #pragma unroll
-  for (int u = 0; u < EB_MAXN / 512; ++u) {
+  for (int u = 0; u < CB; ++u) {
     const int r = rs + tid + 512 * u;
     if (r < (int)ld) s_v[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : cb[u] * scl);
   }
@@ -490,6 +493,8 @@ struct dcl_args {
   double *Q, *Qout, *Qg, *S;
   double *Zv, *Ds, *Zs, *dl, *wv, *tauS, *zhat, *rc, *rs;
   int *Col, *Live, *Ks, *Src, *orgv, *ra, *rb;
+  int *xkp, *xli;               // k_dcl_deflate<true>: its index lists in global memory
+  unsigned char *xkept, *xlv;
   dcl_node* nodes;
   int* fail;
 };
@@ -607,22 +612,26 @@ __global__ __launch_bounds__(256) void k_dcl_rank(dcl_args p) {
 // pairs in parallel; only if some pair is close, one thread redoes the scan sequentially with the rotations (everything in LDS).
 // Then the kept poles are gathered and the new column order of the node is fixed: kept poles first (ascending), the deflated
 // columns behind them (ascending).
+// BIG (a node of more than 4160 poles, i.e. the top merge beyond n = 4096): only the poles and the rank-one vector stay in LDS (16
+// bytes per pole, 132 KB at 8192), the index lists live in global memory at the node's offset -- every access pattern below is
+// "written, workgroup barrier, read by other threads of the SAME workgroup", which global memory serves like LDS.
+template <bool BIG>
 __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
-  // dynamic LDS, cap = the largest node of the level rounded up to 64: 30 bytes per pole (123 KB at 4096)
+  // dynamic LDS, cap = the largest node of the level rounded up to 64: 30 bytes per pole (125 KB at 4096)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  double* s_d = (double*)s_raw;
-  double* s_z = s_d + cap;
-  int* s_ks = (int*)(s_z + cap);
-  int* s_kp = s_ks + cap;
-  int* s_li = s_kp + cap;                      // sorted position -> index in the live list (-1: deflated by the first test)
-  unsigned char* s_kept = (unsigned char*)(s_li + cap);
-  unsigned char* s_lv = s_kept + cap;
   __shared__ int s_scan[1024];
   __shared__ int s_any, s_K, s_nrot;
   const int node = blockIdx.x, tid = threadIdx.x;
   const dcl_node nd = p.nodes[node];
   const int lo = nd.lo, hi = nd.hi, nn = hi - lo, K0 = nd.K;
   const double tol = nd.tol;
+  double* s_d = (double*)s_raw;
+  double* s_z = s_d + cap;
+  int* s_ks = BIG ? p.Ks + lo : (int*)(s_z + cap);
+  int* s_kp = BIG ? p.xkp + lo : s_ks + cap;
+  int* s_li = BIG ? p.xli + lo : s_kp + cap;   // sorted position -> index in the live list (-1: deflated by the first test)
+  unsigned char* s_kept = BIG ? p.xkept + lo : (unsigned char*)(s_li + cap);
+  unsigned char* s_lv = BIG ? p.xlv + lo : s_kept + cap;
   if (tid == 0) {
     s_any = 0;
     s_K = K0;
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
   }
   for (int i = tid; i < K0; i += 1024) {
     const int s = p.Ks[lo + i];
-    s_ks[i] = s;
+    if (!BIG) s_ks[i] = s;
     s_d[i] = p.Ds[s];
     s_z[i] = p.Zs[s];
     s_kp[i] = i;
@@ -911,10 +920,11 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   if (n > EB_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds %d", n, EB_MAXN);
   if (nvec < 0 || nvec > n) nvec = n;
   if (!host_V) nvec = 0;
-  static const bool jacobi = [] {
+  static const bool jacobi_env = [] {
     const char* e = getenv("HFMI_EIG_LARGE");
     return e && !strcmp(e, "jacobi");
   }();
+  const bool jacobi = jacobi_env && n <= 4096;      // (the A/B route of round 4 stops there)
   std::vector<double> staged;
   if ((jacobi || n < 3) && dev_T) {      // the Jacobi route takes a host matrix
     staged.resize((size_t)n * n);
@@ -936,9 +946,9 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   const size_t vlen = (size_t)npad + 128;
   // ---- workspace
   const size_t n_mats = 5;
-  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)EB_WY * npad + 3 * (size_t)nblk * EB_WY * EB_WY + 16 * vlen + 2 * 64 + 64 + 512 +
+  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)EB_WY * npad + 3 * (size_t)nblk * EB_WY * EB_WY + 16 * vlen + 2 * 64 + EB_MAXN / 64 + 512 +
                          (size_t)(npad / 32 + 1) * (npad / 32 + 1);
-  const size_t i_count = 8 * vlen + 64;
+  const size_t i_count = 11 * vlen + 64;
   const size_t bytes = d_count * sizeof(double) + i_count * sizeof(int) + 64 * sizeof(dcl_node) + 256;
   void* wv = nullptr;
   HFMI_TRY(ctx_ws(ctx, WS_STAGE, bytes, &wv));
@@ -976,7 +986,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   double* rs = take(vlen);
   double* x1 = take(64);
   double* x2 = take(64);
-  double* pn = take(64);           // one partial norm per 64 rows: at most 64
+  double* pn = take(EB_MAXN / 64);  // one partial norm per 64 rows
   double* pvy = take(512);
   double* pmax = take((size_t)(npad / 32 + 1) * (npad / 32 + 1));
   int* ip = (int*)dp;
@@ -993,6 +1003,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   int* ra = take_i(vlen);
   int* rb = take_i(vlen);
   int* order = take_i(vlen);
+  int* xkp = take_i(vlen);
+  int* xli = take_i(vlen);
+  unsigned char* xkept = (unsigned char*)take_i(vlen / 2);
+  unsigned char* xlv = (unsigned char*)take_i(vlen / 2);
   int* fail = take_i(16);
   int* sexp_dev = fail + 1;
   dcl_node* nodes = (dcl_node*)round_up((int64_t)(uintptr_t)(ip + 48), 16);
@@ -1040,6 +1054,8 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     ta.tauv = tauv;
     ta.npvy = 0;
     ta.npn = 0;
+    if (n > 4096)      // v of the first columns is 64 KB: beyond what a kernel gets without asking
+      HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
     for (int p0 = 0; p0 < n - 2; p0 += NB) {
       const int ncols = std::min(NB, n - 2 - p0);
       ta.p0 = p0;
@@ -1054,8 +1070,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         const int nc = (n - j - 1) + 2 * jj;
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
-        if (tri_unr == 8) hipLaunchKernelGGL(k_tri_b<8>, dim3(gb), dim3(512), (size_t)(ld - rs0) * sizeof(double), st, ta);
-        else hipLaunchKernelGGL(k_tri_b<4>, dim3(gb), dim3(512), (size_t)(ld - rs0) * sizeof(double), st, ta);
+        const size_t v_lds = (size_t)(ld - rs0) * sizeof(double);
+        if (n > 4096) hipLaunchKernelGGL((k_tri_b<8, 16>), dim3(gb), dim3(512), v_lds, st, ta);
+        else if (tri_unr == 8) hipLaunchKernelGGL((k_tri_b<8, 8>), dim3(gb), dim3(512), v_lds, st, ta);
+        else hipLaunchKernelGGL((k_tri_b<4, 8>), dim3(gb), dim3(512), v_lds, st, ta);
         ta.npvy = gb;
       }
       const int t0 = p0 + ncols;
@@ -1123,6 +1141,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     da.orgv = orgv;
     da.ra = ra;
     da.rb = rb;
+    da.xkp = xkp;
+    da.xli = xli;
+    da.xkept = xkept;
+    da.xlv = xlv;
     da.nodes = nodes;
     da.fail = fail;
     for (int L = Lf - 1; L >= 0; --L) {
@@ -1135,9 +1157,15 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       hipLaunchKernelGGL(k_dcl_z, dim3(nn), dim3(1024), 0, st, da);
       hipLaunchKernelGGL(k_dcl_rank, dim3((n + 63) / 64), dim3(256), 0, st, da);
       const int cap = (int)round_up((n + nn - 1) / nn + 1, 64);
-      const size_t defl_lds = (size_t)cap * 30;
-      HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
-      hipLaunchKernelGGL(k_dcl_deflate, dim3(nn), dim3(1024), defl_lds, st, da, cap);
+      if (cap > 4160) {      // the top merge beyond n = 4096
+        const size_t defl_lds = (size_t)cap * 16;
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
+        hipLaunchKernelGGL(k_dcl_deflate<true>, dim3(nn), dim3(1024), defl_lds, st, da, cap);
+      } else {
+        const size_t defl_lds = (size_t)cap * 30;
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
+        hipLaunchKernelGGL(k_dcl_deflate<false>, dim3(nn), dim3(1024), defl_lds, st, da, cap);
+      }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(hnodes, nodes, (size_t)nn * sizeof(dcl_node), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(ctx->ev_side, st));

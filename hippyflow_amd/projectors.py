@@ -931,7 +931,7 @@ class PODProjectorFromData:
     """Deterministic mass-weighted POD from a snapshot matrix (PODProjector.py:666-852).
     ``method='hep'`` (n << N) runs on the device: the n x n Gram matrix X^T M X and the back-transform
     phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is tridiagonalisation + divide and conquer
-    (one workgroup up to 256 snapshots; panels, merges and block reflectors over the whole GPU up to 4096:
+    (one workgroup up to 256 snapshots; panels, merges and block reflectors over the whole GPU up to 8192:
     ``hfmi_block_gram_eig``, only the u_rank wanted eigenvectors come back) -- same steps as :812-833.
 
     ``method='ghep'`` (H = M X (M X)^T / n against M, :743-773) and ``'inverse_ghep'`` (H = X X^T / n against
@@ -951,14 +951,14 @@ class PODProjectorFromData:
         self.ctx = ctx or L.Context.default()
 
     def _randomized(self, u_data, u_rank, oversampling=20):
-        """More than 4096 snapshots (the n x n eigensolve on the device stops there; the reference's :812-833 takes any n): the
+        """More than 8192 snapshots (the n x n eigensolve on the device stops there; the reference's :812-833 takes any n): the
         same modes from the N-dimensional form of the problem, (1/n) M X X^T M phi = lambda M phi with phi^T M phi = 1, by the
         randomized double pass this library is built around (``doublePassG`` with B = M, B^-1 = the device mass solve).  The
         eigenpairs are those of the randomized method (oversampling 20, one pass): exact to rounding when the snapshots have
         numerical rank <= u_rank + 20, otherwise as accurate as the decay of the spectrum beyond that allows."""
         import warnings
         from .operators import ComposedOperator
-        warnings.warn("PODProjectorFromData: %d snapshots > 4096 -- using the randomized double pass on the N-dimensional "
+        warnings.warn("PODProjectorFromData: %d snapshots > 8192 -- using the randomized double pass on the N-dimensional "
                       "generalized problem instead of the n x n Gram eigensolve" % u_data.shape[0])
         X = MultiVector.from_vectors(u_data, ctx=self.ctx)
         Mop = CsrOperator(self.M_csr, ctx=self.ctx)
@@ -977,7 +977,7 @@ class PODProjectorFromData:
             u_data = u_data - u_shift
         else:
             u_shift = np.zeros(u_data.shape[1])
-        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > 4096:
+        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > 8192:
             d, phi, Mphi = self._randomized(u_data, u_rank)
         elif method in ('hep', 'ghep', 'inverse_ghep'):
             X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector

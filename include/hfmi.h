@@ -246,11 +246,12 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
  * (hfmi_eig_dc.hip) -- the algorithm family of the LAPACK routine behind np.linalg.eigh, absolute
  * accuracy eps ||T||.  HFMI_EIG_JACOBI: one-workgroup parallel cyclic Jacobi in LDS (slower; small
  * eigenvalues of graded positive definite matrices to high RELATIVE accuracy).
- * 256 < k <= 4096 (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821, any number of
+ * 256 < k <= 8192 (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821, any number of
  * snapshots): the same algorithm family over the whole GPU (hfmi_eig_blocked.hip) -- panel Householder
  * tridiagonalisation with the trailing update on the fp64 MFMA, divide and conquer with the leaves on one compute unit
- * each and the upper merges on all of them, block-reflector back-transformation.  HFMI_EIG_LARGE=jacobi in the
- * environment selects the two-sided Jacobi of rounds 2-4 (hfmi_eig_large.hip). */
+ * each and the upper merges on all of them, block-reflector back-transformation.  Non-finite entries: HFMI_ERR_NUMERIC
+ * (np.linalg.eigh raises LinAlgError).  HFMI_EIG_LARGE=jacobi in the environment selects the two-sided Jacobi of
+ * rounds 2-4 (hfmi_eig_large.hip; up to 4096). */
 #define HFMI_EIG_SORT_ABS 1
 #define HFMI_EIG_JACOBI 2
 int hfmi_sym_eig_small(hfmi_ctx* ctx, const double* host_T, int k, int sort_by_abs, double* host_d,

@@ -1,4 +1,4 @@
-"""Wall time of hfmi_sym_eig_small beyond one workgroup (256 < n <= 4096: hfmi_eig_blocked.hip) next to numpy.linalg.eigh on
+"""Wall time of hfmi_sym_eig_small beyond one workgroup (256 < n <= 8192: hfmi_eig_blocked.hip) next to numpy.linalg.eigh on
 the box's host, with the phase split the library prints under HFMI_EIG_LARGE_TIMING=1 (stderr).  Usage:
 python scripts/eig_large_time.py [n ...] [--no-host] [--low-rank]; per-kernel times come from the rocprofv3 kernel trace of this script."""
 import sys

@@ -34,8 +34,8 @@ bash scripts/shard_profile.sh ${tag}_shard64 > $out/${tag}_shard64_timeline.txt 
 bash scripts/shard_profile.sh ${tag}_shard64_dist1 --samples-total 64 --dist-single > $out/${tag}_shard64_dist1_timeline.txt 2>&1
 bash scripts/eig_corner_trace.sh $tag 138 160 192 224 256 > $out/${tag}_eig_corner.txt 2>&1
 # the whole-GPU eigensolver beyond 256 (hfmi_eig_blocked.hip): wall times next to numpy.linalg.eigh with the phase split, then traces
-HFMI_EIG_LARGE_TIMING=1 timeout 900 python scripts/eig_large_time.py 300 512 1024 2048 4096 > $out/${tag}_eig_large.txt 2>&1
-bash scripts/eig_large_trace.sh $tag 512 1024 2048 4096 > $out/${tag}_eig_large_trace.log 2>&1
+HFMI_EIG_LARGE_TIMING=1 timeout 900 python scripts/eig_large_time.py 300 512 1024 2048 4096 8192 > $out/${tag}_eig_large.txt 2>&1
+bash scripts/eig_large_trace.sh $tag 512 1024 2048 4096 8192 > $out/${tag}_eig_large_trace.log 2>&1
 cd $R
 cat $out/${tag}_gputests.log
 ls $out | grep "^${tag}_" | wc -l

@@ -298,13 +298,13 @@ def test_low_rank_operator_with_a_general_diagonal(ctx):
     assert np.abs(Ud.T @ Bd @ Ud - np.eye(6)).max() < 1e-10
 
 
-def test_pod_from_data_beyond_4096_snapshots_goes_through_the_randomized_pass(ctx):
-    """The reference's deterministic POD takes any number of snapshots (PODProjector.py:812-833); beyond the 4096 of the
+def test_pod_from_data_beyond_8192_snapshots_goes_through_the_randomized_pass(ctx):
+    """The reference's deterministic POD takes any number of snapshots (PODProjector.py:812-833); beyond the 8192 of the
     device's n x n eigensolve the same modes come from the N-dimensional generalized problem by doublePassG.  Snapshots of
     numerical rank 30 <= rank + oversampling: the result equals the oracle's 'hep' to rounding."""
     from hippyflow_amd import workloads
     rng = np.random.default_rng(8)
-    n, nx, ny, r = 4200, 30, 20, 18
+    n, nx, ny, r = 8300, 30, 20, 18
     N = nx * ny
     M = workloads.grid_mass_matrix(nx, ny)
     W0, _ = np.linalg.qr(rng.standard_normal((N, 30)))
@@ -325,9 +325,9 @@ def test_pod_from_data_beyond_4096_snapshots_goes_through_the_randomized_pass(ct
 def test_round2_entry_points_reject_bad_arguments(ctx):
     import ctypes as C
     L = hf._lib
-    # sym_eig beyond 4096
+    # sym_eig beyond 8192
     with pytest.raises(hf.HfmiError) as e:
-        hf.sym_eig_small(np.eye(4097))
+        hf.sym_eig_small(np.eye(8193))
     assert "out of range" in str(e.value)
     # host-callback slab size: negative, and on an operator that is not a host callback
     cb = hf.HostCallbackOperator(lambda W: W, 64)

@@ -1,7 +1,7 @@
-"""hfmi_sym_eig_small for 256 < n <= 4096 (hfmi_eig_blocked.hip: panel tridiagonalisation on the MFMA, divide and conquer over
+"""hfmi_sym_eig_small for 256 < n <= 8192 (hfmi_eig_blocked.hip: panel tridiagonalisation on the MFMA, divide and conquer over
 the whole GPU, block-reflector back-transformation) against numpy.linalg.eigh -- what the reference calls at
 PODProjector.py:821 (la.eigh(G)).  Bar: eigenvalues to 1e-12 ||T||, ||V^T V - I|| <= 1e-12,
-residual <= 1e-12 ||T|| (max-abs entries; n eps grows to 9e-13 at n = 4096, so the largest sizes get 4e-12)."""
+residual <= 1e-12 ||T|| (max-abs entries; n eps grows to 9e-13 at n = 4096, so the largest sizes get 4e-12, 8e-12 beyond 4096)."""
 import numpy as np
 import pytest
 
@@ -98,6 +98,58 @@ def test_sym_eig_blocked_4096_and_sort_by_abs(ctx):
     w = w[np.argsort(-np.abs(w), kind="stable")]
     assert np.abs(d2 - w).max() <= 4e-12 * np.abs(w).max()
     assert np.abs(S @ V2 - V2 * d2).max() <= 4e-12 * np.abs(w).max()
+
+
+def _hard_matrix(n, kind, rng):
+    if kind == "clustered":
+        return _spectrum_matrix(n, np.repeat(np.arange(1.0, 1.0 + (n + 15) // 16), 16)[:n], rng)
+    if kind == "rank-deficient":
+        X = rng.standard_normal((n, n // 5))
+        return X @ X.T
+    if kind == "two-clusters":
+        return _spectrum_matrix(n, np.where(np.arange(n) < n // 2, 1.0, -1.0) + 1e-13 * rng.standard_normal(n), rng)
+    if kind == "tridiagonal":
+        T = np.diag(rng.standard_normal(n)) + np.diag(rng.standard_normal(n - 1), 1)
+        return T + np.triu(T, 1).T
+    if kind == "identity":
+        return np.eye(n)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["clustered", "rank-deficient", "two-clusters", "tridiagonal", "identity"])
+def test_sym_eig_blocked_beyond_4096_hard_spectra(ctx, kind):
+    """4096 < n <= 8192: the top merge's deflation keeps its index lists in global memory (k_dcl_deflate<true>) and k_tri_b holds twice
+    the column share per thread -- the spectra that exercise the rotations and the mass deflation, just past the switch."""
+    n = 4200
+    T = _hard_matrix(n, kind, np.random.default_rng(len(kind) + n))
+    _check(T, 8e-12)
+
+
+@pytest.mark.parametrize("n", [4097, 6000])
+def test_sym_eig_blocked_beyond_4096_random_and_gram(ctx, n):
+    rng = np.random.default_rng(n)
+    S = rng.standard_normal((n, n))
+    _check(S + S.T, 8e-12)                                                        # indefinite, nothing deflates
+    X = rng.standard_normal((n, 700)) * np.exp(-0.01 * np.arange(700))[None, :]
+    _check(X @ X.T, 8e-12)                                                        # the POD case: rank 700
+
+
+def test_sym_eig_blocked_8192_gram_and_leading(ctx):
+    """The largest size: Gram matrix of 8192 decaying snapshots formed on the device (hfmi_block_gram_eig, 100 leading eigenvectors)
+    against numpy on the same blocks, and the full solve of an indefinite matrix."""
+    n, N, nvec = 8192, 3000, 100
+    rng = np.random.default_rng(8192)
+    X = rng.standard_normal((N, 900)) @ (rng.standard_normal((900, n)) * np.exp(-0.01 * np.arange(900))[:, None])
+    Xm = hf.MultiVector.from_dense(X)
+    d, V = Xm.gram_eig(Xm, nvec)
+    G = X.T @ X
+    w = np.linalg.eigvalsh(G)[::-1]
+    assert V.shape == (n, nvec)
+    assert np.abs(d - w).max() <= 8e-12 * w[0]
+    assert np.abs(G @ V - V * d[:nvec]).max() <= 8e-12 * w[0]
+    assert np.abs(V.T @ V - np.eye(nvec)).max() <= 1e-12
+    S = rng.standard_normal((n, n))
+    _check(S + S.T, 1.6e-11)
 
 
 def test_sym_eig_blocked_is_bit_reproducible(ctx):
