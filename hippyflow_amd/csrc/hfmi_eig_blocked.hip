@@ -251,6 +251,8 @@ struct tri_args {
   double* pn;                   // partial sums of |col[j + 2 ..]|^2, one per workgroup of k_tri_a
   int npn;
   double *dvec, *evec, *tauv;
+  double* part;                 // k_tri_bs: partial products, part[k * ld + row], k < nb
+  int nb;                       // 128-row blocks of the trailing matrix seen from rs2 = (j + 1) rounded down to 128
 };
 
 // 64 rows per workgroup (row r = j + 64 blockIdx.x + lane), the panel columns dealt to the 8 waves (wave w takes k = w, w + 8, ...):
@@ -472,6 +474,131 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   if (tid == 0) p.pvy[blockIdx.x] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) + ((s_part[4] + s_part[5]) + (s_part[6] + s_part[7]));
 }
 // the last 2 x 2 block of the reduced matrix
+// The same products from the LOWER TRIANGLE only (large trailing blocks: the stream of the matrix is what a column costs there, so
+// half the bytes is nearly half the time).  128 x 128 tiles (I, J), I >= J, rows / columns counted from rs2 = (j + 1) rounded down
+// to 128; one workgroup per tile: wave w takes columns w, w + 8, ... of the tile (one 16-byte load per lane and column), and a tile
+// below the diagonal serves both  y_I += A_IJ v_J  (accumulated per lane over the wave's columns, the 8 waves summed through LDS in
+// a fixed order) and  y_J += A_IJ^T v_I  (one wave sum per column).  Nothing is accumulated across workgroups: tile (I, J) leaves its
+// two partial vectors in slots k = J (rows of I) and k = I (rows of J) of `part`, so that every row finds exactly nb partial values,
+// one per slot, which k_tri_yred adds in slot order -- bit-reproducible.  The last 2 jj workgroups are the panel's columns of V and
+// W (V^T v, W^T v): one column per workgroup, an eighth of the rows per wave.  v is not staged: tiles need 2 x 128 entries, taken
+// from column j of the reduced matrix with the reflector's scaling (same arithmetic in every workgroup).
+constexpr int TS = 128;
+template <int CB>
+__global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
+  __shared__ double s_vi[TS], s_vj[TS];
+  __shared__ double s_pr[8][TS];
+  __shared__ double s_dot[8];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
+  const int64_t ld = p.ld;
+  const int rs2 = (j + 1) & ~(TS - 1);
+  const double alpha0 = p.colbuf[j + 1];
+  double pnl = l < p.npn ? p.pn[l] : 0.0;
+  if (CB > 8) pnl += l + 64 < p.npn ? p.pn[l + 64] : 0.0;
+  const double xn2 = wave_sum(pnl);
+  double tau = 0.0, beta = alpha0, scl = 0.0;
+  if (xn2 > 1e-280) {
+    const double nrm = sqrt(fma(alpha0, alpha0, xn2));
+    beta = -copysign(nrm, alpha0);
+    tau = (beta - alpha0) / beta;
+    scl = 1.0 / (alpha0 - beta);
+  }
+  auto vrow = [&](int r, double c) { return (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : c * scl); };
+  if (blockIdx.x == 0 && tid == 0) {
+    p.evec[j] = beta;
+    p.tauv[j] = tau;
+  }
+  if ((int)blockIdx.x >= ntiles) {
+    // ---- a panel column: x1[q] = V[:, q] . v  or  x2[q] = W[:, q] . v
+    const int q = blockIdx.x - ntiles;
+    const double* colp = q < jj ? p.Vh + (size_t)(p.p0 + q) * ld : p.W + (size_t)(q - jj) * ld;
+    const int npair = ((int)ld - rs2) >> 1;            // pairs of rows from rs2
+    const int per = (npair + 7) >> 3;                  // per wave (<= 512: at most 8 per lane)
+    const d2* __restrict__ c2 = (const d2*)(colp + rs2);
+    const d2* __restrict__ b2 = (const d2*)(p.colbuf + rs2);
+    d2 x[8], c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = w * per + l + 64 * u;
+      const bool ok = l + 64 * u < per && i < npair;
+      x[u] = ok ? c2[i] : d2{0.0, 0.0};
+      c[u] = ok ? b2[i] : d2{0.0, 0.0};
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rs2 + 2 * (w * per + l + 64 * u);
+      acc = fma(x[u].x, vrow(r, c[u].x), acc);
+      acc = fma(x[u].y, vrow(r + 1, c[u].y), acc);
+    }
+    acc = wave_sum(acc);
+    if (l == 0) s_dot[w] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      const double s = ((s_dot[0] + s_dot[1]) + (s_dot[2] + s_dot[3])) + ((s_dot[4] + s_dot[5]) + (s_dot[6] + s_dot[7]));
+      if (q < jj) p.x1[q] = s;
+      else p.x2[q - jj] = s;
+    }
+    return;
+  }
+  // ---- tile (I, J), I >= J: blockIdx = I (I + 1) / 2 + J
+  int I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) ++I;
+  while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
+  const int J = blockIdx.x - I * (I + 1) / 2;
+  const int r0 = rs2 + TS * I, c0 = rs2 + TS * J;
+  // the wave's 16 columns first: nothing below waits for them until they are used
+  const double* __restrict__ Ab = p.A + (size_t)r0 + (size_t)c0 * ld;
+  d2 x[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) x[u] = ((const d2*)(Ab + (size_t)(w + 8 * u) * ld))[l];
+  if (tid < TS) s_vi[tid] = vrow(r0 + tid, p.colbuf[r0 + tid]);
+  else if (tid < 2 * TS) s_vj[tid - TS] = vrow(c0 + tid - TS, p.colbuf[c0 + tid - TS]);
+  __syncthreads();
+  if (I == J && tid < TS) p.Vh[(size_t)(r0 + tid) + (size_t)j * ld] = s_vi[tid];      // column j of the reflector matrix (rows above rs2 are zero already)
+  const double vi0 = s_vi[2 * l], vi1 = s_vi[2 * l + 1];
+  double a0 = 0.0, a1 = 0.0;
+  double* __restrict__ pcol = p.part + (size_t)I * ld + c0;       // slot I, rows of block J
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const double vc = s_vj[w + 8 * u];
+    a0 = fma(x[u].x, vc, a0);
+    a1 = fma(x[u].y, vc, a1);
+    if (I != J) {        // workgroup-uniform
+      const double dsum = wave_sum(fma(x[u].x, vi0, x[u].y * vi1));
+      if (l == 0) pcol[w + 8 * u] = dsum;
+    }
+  }
+  s_pr[w][2 * l] = a0;
+  s_pr[w][2 * l + 1] = a1;
+  __syncthreads();
+  if (tid < TS) {
+    const double s = ((s_pr[0][tid] + s_pr[1][tid]) + (s_pr[2][tid] + s_pr[3][tid])) + ((s_pr[4][tid] + s_pr[5][tid]) + (s_pr[6][tid] + s_pr[7][tid]));
+    p.part[(size_t)J * ld + r0 + tid] = s;                         // slot J, rows of block I
+  }
+}
+// y = sum of the nb <= 64 partial vectors; v . y per workgroup (what k_tri_a reads as pvy).  64 rows per workgroup, the slots dealt
+// to its 8 waves (slot w, w + 8, ...: at most 8 loads per lane, all in flight at once), the 8 sums of a row added in wave order.
+__global__ __launch_bounds__(512) void k_tri_yred(tri_args p) {
+  __shared__ double s_y[8][64];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, j = p.j;
+  const int64_t ld = p.ld;
+  const int rs2 = (j + 1) & ~(TS - 1);
+  const int r = rs2 + blockIdx.x * 64 + l;          // < ld: the grid covers [rs2, ld) exactly
+  const double* __restrict__ pp = p.part + r;
+  double q[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) q[u] = (w + 8 * u < p.nb) ? pp[(size_t)(w + 8 * u) * ld] : 0.0;
+  const double v = w == 0 ? p.Vh[(size_t)r + (size_t)j * ld] : 0.0;
+  s_y[w][l] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+  __syncthreads();
+  if (w != 0) return;
+  double y = ((s_y[0][l] + s_y[1][l]) + (s_y[2][l] + s_y[3][l])) + ((s_y[4][l] + s_y[5][l]) + (s_y[6][l] + s_y[7][l]));
+  if (r <= j || r >= p.n) y = 0.0;
+  p.ybuf[r] = y;
+  const double vy = wave_sum(y * v);
+  if (l == 0) p.pvy[blockIdx.x] = vy;
+}
 __global__ void k_tri_tail(const double* __restrict__ A, int64_t ld, int n, double* __restrict__ dvec, double* __restrict__ evec) {
   if (threadIdx.x == 0) {
     dvec[n - 2] = A[(size_t)(n - 2) + (size_t)(n - 2) * ld];
@@ -1037,7 +1164,14 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       const char* e = getenv("HFMI_EIG_TRI_UNR");
       return (e && atoi(e) == 4) ? 4 : 8;
     }();
+    static const int sym_min = [] {      // HFMI_EIG_SYM_MIN: trailing blocks from this size on take the lower-triangle products (0: never)
+      const char* e = getenv("HFMI_EIG_SYM_MIN");
+      const int v = e ? atoi(e) : 3072;
+      return v <= 0 ? (1 << 30) : std::max(v, 256);
+    }();
     tri_args ta;
+    ta.part = Qg;                        // free between the load and the merges: nb <= 64 partial vectors of ld doubles
+    ta.nb = 0;
     ta.n = n;
     ta.ld = ld;
     ta.A = A;
@@ -1071,10 +1205,21 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
         const size_t v_lds = (size_t)(ld - rs0) * sizeof(double);
-        if (n > 4096) hipLaunchKernelGGL((k_tri_b<8, 16>), dim3(gb), dim3(512), v_lds, st, ta);
-        else if (tri_unr == 8) hipLaunchKernelGGL((k_tri_b<8, 8>), dim3(gb), dim3(512), v_lds, st, ta);
-        else hipLaunchKernelGGL((k_tri_b<4, 8>), dim3(gb), dim3(512), v_lds, st, ta);
-        ta.npvy = gb;
+        if (n - j - 1 >= sym_min) {
+          // large trailing block: the lower triangle only (k_tri_bs), then the partial vectors summed (k_tri_yred)
+          const int rs2 = (j + 1) & ~(TS - 1);
+          const int nb = ((int)ld - rs2) / TS, ntiles = nb * (nb + 1) / 2, gy = ((int)ld - rs2) / 64;
+          ta.nb = nb;
+          if (n > 4096) hipLaunchKernelGGL(k_tri_bs<16>, dim3(ntiles + 2 * jj), dim3(512), 0, st, ta, ntiles);
+          else hipLaunchKernelGGL(k_tri_bs<8>, dim3(ntiles + 2 * jj), dim3(512), 0, st, ta, ntiles);
+          hipLaunchKernelGGL(k_tri_yred, dim3(gy), dim3(512), 0, st, ta);
+          ta.npvy = gy;
+        } else {
+          if (n > 4096) hipLaunchKernelGGL((k_tri_b<8, 16>), dim3(gb), dim3(512), v_lds, st, ta);
+          else if (tri_unr == 8) hipLaunchKernelGGL((k_tri_b<8, 8>), dim3(gb), dim3(512), v_lds, st, ta);
+          else hipLaunchKernelGGL((k_tri_b<4, 8>), dim3(gb), dim3(512), v_lds, st, ta);
+          ta.npvy = gb;
+        }
       }
       const int t0 = p0 + ncols;
       ta.j = t0;
