@@ -1,4 +1,4 @@
-"""CPU twin of the whole-GPU symmetric eigensolver for 256 < n <= 4096 (hippyflow_amd/csrc/hfmi_eig_blocked.hip):
+"""CPU twin of the whole-GPU symmetric eigensolver for 256 < n <= 8192 (hippyflow_amd/csrc/hfmi_eig_blocked.hip):
 panel Householder tridiagonalisation (LAPACK dlatrd's recurrences, with the last column of W finalised lazily so that a
 column costs two launches), divide and conquer with leaves of at most 256 solved independently and the upper merges on the
 whole GPU, blocked (compact WY) back-transformation.
@@ -87,6 +87,40 @@ def tridiagonalize_blocked(T, nb=64):
         e[n - 2] = A[n - 1, n - 2]
     d[n - 1] = A[n - 1, n - 1]
     return d, e, Vh, tau
+
+
+def lower_triangle_products(A, v, j, ts=128):
+    """Twin of k_tri_bs + k_tri_yred: y = A v for a symmetric A and a v that vanishes on rows <= j, touching only the tiles
+    (I, J), I >= J, of the trailing block counted from rs2 = (j + 1) rounded down to ``ts`` -- a tile below the diagonal serves
+    y_I += A_IJ v_J and y_J += A_IJ^T v_I; tile (I, J) leaves the first product in slot J (rows of I), the second in slot I
+    (rows of J), so that every row receives exactly nb partial values, one per slot, added in a fixed order.  Returns (y with
+    rows <= j set to 0, number of matrix entries read)."""
+    n = A.shape[0]
+    ld = -(-n // ts) * ts
+    rs2 = ((j + 1) // ts) * ts
+    nb = (ld - rs2) // ts
+    Ap = np.zeros((ld, ld))
+    Ap[:n, :n] = A
+    vp = np.zeros(ld)
+    vp[:n] = v
+    part = np.full((nb, ld), np.nan)                    # every (slot, row >= rs2) must be written exactly once
+    reads = 0
+    for I in range(nb):
+        for J in range(I + 1):
+            r0, c0 = rs2 + ts * I, rs2 + ts * J
+            tile = Ap[r0:r0 + ts, c0:c0 + ts]
+            reads += tile.size
+            assert np.all(np.isnan(part[J, r0:r0 + ts]))
+            part[J, r0:r0 + ts] = tile @ vp[c0:c0 + ts]
+            if I != J:
+                assert np.all(np.isnan(part[I, c0:c0 + ts]))
+                part[I, c0:c0 + ts] = tile.T @ vp[r0:r0 + ts]
+    assert not np.isnan(part[:, rs2:]).any()
+    y = np.zeros(ld)
+    for k in range(nb):
+        y[rs2:] += part[k, rs2:]
+    y[:j + 1] = 0.0
+    return y[:n], reads
 
 
 def wy_factor(V, tau):

@@ -46,3 +46,22 @@ def test_blocked_tridiagonalisation_is_the_unblocked_factorisation():
     # the block reflectors reproduce the product of the single ones
     Z = rng.standard_normal((n, 9))
     assert np.abs(bt.back_transform_blocked(Vh, tau, Z, 16) - dct.back_transform(V0, tau0, Z)).max() < 1e-11
+
+
+@pytest.mark.parametrize("n,j", [(500, 0), (500, 126), (500, 127), (513, 200), (700, 383), (640, 511)])
+def test_lower_triangle_products_cover_every_row_once_per_slot(n, j):
+    """The tile / slot scheme of k_tri_bs + k_tri_yred: half the matrix is read, every row finds one partial value in each of its nb
+    slots, and their sum is A v on the rows below j (v vanishes on rows <= j; rows and columns <= j inside the first block hold
+    older data: they must not leak into the result)."""
+    rng = np.random.default_rng(n + j)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    v = rng.standard_normal(n)
+    v[:j + 1] = 0.0
+    y, reads = bt.lower_triangle_products(A, v, j)
+    ref = A @ v
+    ref[:j + 1] = 0.0
+    np.testing.assert_allclose(y, ref, atol=1e-11)
+    m = -(-n // 128) * 128 - ((j + 1) // 128) * 128
+    assert reads == 128 * 128 * (m // 128) * (m // 128 + 1) // 2
+    assert reads <= 0.5 * m * m + 128 * m                                  # half the block + its diagonal tiles
