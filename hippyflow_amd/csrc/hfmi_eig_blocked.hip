@@ -260,9 +260,14 @@ struct tri_args {
 // memory latencies instead of a 63-step dependent loop; the 8 partial sums of a row meet in LDS and wave 0 finishes the row.
 constexpr int TA_WAVES = 8;
 constexpr int TA_KPT = EB_NB / TA_WAVES;      // panel columns per thread
+// SLOTS: the last step's products were made by k_tri_bs -- y[r] is the sum of the nb <= 64 partial values in part[k * ld + r] (the slots
+// dealt to the 8 waves, at most 8 loads per lane, the 8 sums of a row added in wave order; row j, which every workgroup needs, by the
+// same tree: same bits everywhere), and v . y the sum of its per-tile terms v_I . (A_IJ v_J) (pvy, up to 2080 of them).
+template <bool SLOTS>
 __global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
   __shared__ double s_x1[EB_NB], s_x2[EB_NB], s_vj[EB_NB], s_wj[EB_NB];
   __shared__ double s_py[TA_WAVES][64], s_pc[TA_WAVES][64];
+  __shared__ double s_yq[SLOTS ? TA_WAVES : 1][64], s_yj[TA_WAVES];
   __shared__ double s_alpha;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
   const int64_t ld = p.ld;
@@ -288,21 +293,43 @@ __global__ __launch_bounds__(64 * TA_WAVES) void k_tri_a(tri_args p) {
   if (w == 0 && live) {
     if (fin) {
       vr_pre = Vp[(size_t)r + (size_t)kf * ld];
-      y_pre = p.ybuf[r];
+      if (!SLOTS) y_pre = p.ybuf[r];
     }
     if (col) a_pre = p.A[(size_t)r + (size_t)j * ld];
   }
+  if (SLOTS) {
+    if (fin) {
+      double yq[8], jq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = w + TA_WAVES * u;
+        yq[u] = (live && k < p.nb) ? p.part[(size_t)k * ld + r] : 0.0;
+        jq[u] = (col && k < p.nb) ? p.part[(size_t)k * ld + j] : 0.0;
+      }
+      s_yq[w][l] = ((yq[0] + yq[1]) + (yq[2] + yq[3])) + ((yq[4] + yq[5]) + (yq[6] + yq[7]));
+      if (l == 0) s_yj[w] = ((jq[0] + jq[1]) + (jq[2] + jq[3])) + ((jq[4] + jq[5]) + (jq[6] + jq[7]));
+    }
+    __syncthreads();
+    if (fin && w == 0)
+      y_pre = ((s_yq[0][l] + s_yq[1][l]) + (s_yq[2][l] + s_yq[3][l])) + ((s_yq[4][l] + s_yq[5][l]) + (s_yq[6][l] + s_yq[7][l]));
+  }
   if (w == 0) {
     if (fin) {
-      // up to 512 partial sums of v . y: eight loads per lane, all in flight at once (a loop over a run-time count waits for
-      // every load before it issues the next: 8 x an L2 round trip per column at n = 4096)
-      double s8[8];
+      // the partial sums of v . y (up to 512 workgroups of k_tri_b / 2080 tiles of k_tri_bs): all loads of a lane in flight at once
+      // (a loop over a run-time count waits for every load before it issues the next: 8 x an L2 round trip per column at n = 4096)
+      constexpr int NS = SLOTS ? 33 : 8;
+      double s8[NS];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s8[u] = (l + 64 * u < p.npvy) ? p.pvy[l + 64 * u] : 0.0;
-      const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      for (int u = 0; u < NS; ++u) s8[u] = (l + 64 * u < p.npvy) ? p.pvy[l + 64 * u] : 0.0;
+      double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      if (SLOTS) {
+#pragma unroll
+        for (int u = 8; u < NS; ++u) s += s8[u];
+      }
       const double x1v = l < kf ? p.x1[l] : 0.0, x2v = l < kf ? p.x2[l] : 0.0;
       const double vjk = (col && l < kf) ? Vp[(size_t)j + (size_t)l * ld] : 0.0, wjk = (col && l < kf) ? W[(size_t)j + (size_t)l * ld] : 0.0;
-      const double vjl = col ? Vp[(size_t)j + (size_t)kf * ld] : 0.0, yj = col ? p.ybuf[j] : 0.0;
+      const double vjl = col ? Vp[(size_t)j + (size_t)kf * ld] : 0.0;
+      const double yj = !col ? 0.0 : SLOTS ? ((s_yj[0] + s_yj[1]) + (s_yj[2] + s_yj[3])) + ((s_yj[4] + s_yj[5]) + (s_yj[6] + s_yj[7])) : p.ybuf[j];
       const double vy = wave_sum(s);
       s_x1[l] = x1v;
       s_x2[l] = x2v;
@@ -480,7 +507,7 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
 // below the diagonal serves both  y_I += A_IJ v_J  (accumulated per lane over the wave's columns, the 8 waves summed through LDS in
 // a fixed order) and  y_J += A_IJ^T v_I  (one wave sum per column).  Nothing is accumulated across workgroups: tile (I, J) leaves its
 // two partial vectors in slots k = J (rows of I) and k = I (rows of J) of `part`, so that every row finds exactly nb partial values,
-// one per slot, which k_tri_yred adds in slot order -- bit-reproducible.  The last 2 jj workgroups are the panel's columns of V and
+// one per slot, which the next k_tri_a<true> adds in a fixed order -- bit-reproducible.  The last 2 jj workgroups are the panel's columns of V and
 // W (V^T v, W^T v): one column per workgroup, an eighth of the rows per wave.  v is not staged: tiles need 2 x 128 entries, taken
 // from column j of the reduced matrix with the reflector's scaling (same arithmetic in every workgroup).
 constexpr int TS = 128;
@@ -572,32 +599,15 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
   s_pr[w][2 * l] = a0;
   s_pr[w][2 * l + 1] = a1;
   __syncthreads();
-  if (tid < TS) {
+  if (tid < TS) {      // waves 0 and 1
     const double s = ((s_pr[0][tid] + s_pr[1][tid]) + (s_pr[2][tid] + s_pr[3][tid])) + ((s_pr[4][tid] + s_pr[5][tid]) + (s_pr[6][tid] + s_pr[7][tid]));
     p.part[(size_t)J * ld + r0 + tid] = s;                         // slot J, rows of block I
+    // this tile's term of v . y = v^T A v: v_I . (A_IJ v_J), twice below the diagonal (the mirrored tile is never visited)
+    const double tv = wave_sum(s * s_vi[tid]);
+    if (l == 0) s_dot[w] = tv;
   }
-}
-// y = sum of the nb <= 64 partial vectors; v . y per workgroup (what k_tri_a reads as pvy).  64 rows per workgroup, the slots dealt
-// to its 8 waves (slot w, w + 8, ...: at most 8 loads per lane, all in flight at once), the 8 sums of a row added in wave order.
-__global__ __launch_bounds__(512) void k_tri_yred(tri_args p) {
-  __shared__ double s_y[8][64];
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, j = p.j;
-  const int64_t ld = p.ld;
-  const int rs2 = (j + 1) & ~(TS - 1);
-  const int r = rs2 + blockIdx.x * 64 + l;          // < ld: the grid covers [rs2, ld) exactly
-  const double* __restrict__ pp = p.part + r;
-  double q[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) q[u] = (w + 8 * u < p.nb) ? pp[(size_t)(w + 8 * u) * ld] : 0.0;
-  const double v = w == 0 ? p.Vh[(size_t)r + (size_t)j * ld] : 0.0;
-  s_y[w][l] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
   __syncthreads();
-  if (w != 0) return;
-  double y = ((s_y[0][l] + s_y[1][l]) + (s_y[2][l] + s_y[3][l])) + ((s_y[4][l] + s_y[5][l]) + (s_y[6][l] + s_y[7][l]));
-  if (r <= j || r >= p.n) y = 0.0;
-  p.ybuf[r] = y;
-  const double vy = wave_sum(y * v);
-  if (l == 0) p.pvy[blockIdx.x] = vy;
+  if (tid == 0) p.pvy[blockIdx.x] = (I == J ? 1.0 : 2.0) * (s_dot[0] + s_dot[1]);
 }
 __global__ void k_tri_tail(const double* __restrict__ A, int64_t ld, int n, double* __restrict__ dvec, double* __restrict__ evec) {
   if (threadIdx.x == 0) {
@@ -1073,7 +1083,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   const size_t vlen = (size_t)npad + 128;
   // ---- workspace
   const size_t n_mats = 5;
-  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)EB_WY * npad + 3 * (size_t)nblk * EB_WY * EB_WY + 16 * vlen + 2 * 64 + EB_MAXN / 64 + 512 +
+  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)EB_WY * npad + 3 * (size_t)nblk * EB_WY * EB_WY + 16 * vlen + 2 * 64 + EB_MAXN / 64 + 2112 +
                          (size_t)(npad / 32 + 1) * (npad / 32 + 1);
   const size_t i_count = 11 * vlen + 64;
   const size_t bytes = d_count * sizeof(double) + i_count * sizeof(int) + 64 * sizeof(dcl_node) + 256;
@@ -1114,7 +1124,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   double* x1 = take(64);
   double* x2 = take(64);
   double* pn = take(EB_MAXN / 64);  // one partial norm per 64 rows
-  double* pvy = take(512);
+  double* pvy = take(2112);         // partial sums of v . y: <= 512 workgroups of k_tri_b, <= 2080 tiles of k_tri_bs
   double* pmax = take((size_t)(npad / 32 + 1) * (npad / 32 + 1));
   int* ip = (int*)dp;
   auto take_i = [&](size_t count) {
@@ -1188,6 +1198,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     ta.tauv = tauv;
     ta.npvy = 0;
     ta.npn = 0;
+    bool prev_slots = false;             // the last column's products were left in slots by k_tri_bs
     if (n > 4096)      // v of the first columns is 64 KB: beyond what a kernel gets without asking
       HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
     for (int p0 = 0; p0 < n - 2; p0 += NB) {
@@ -1200,32 +1211,35 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         ta.mode = 3;
         const int ga = (n - j + 63) / 64;
         ta.npn = ga;
-        hipLaunchKernelGGL(k_tri_a, dim3(ga), dim3(64 * TA_WAVES), 0, st, ta);
+        if (prev_slots) hipLaunchKernelGGL(k_tri_a<true>, dim3(ga), dim3(64 * TA_WAVES), 0, st, ta);
+        else hipLaunchKernelGGL(k_tri_a<false>, dim3(ga), dim3(64 * TA_WAVES), 0, st, ta);
         const int nc = (n - j - 1) + 2 * jj;
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
         const size_t v_lds = (size_t)(ld - rs0) * sizeof(double);
         if (n - j - 1 >= sym_min) {
-          // large trailing block: the lower triangle only (k_tri_bs), then the partial vectors summed (k_tri_yred)
+          // large trailing block: the lower triangle only (k_tri_bs); the next k_tri_a adds the partial vectors
           const int rs2 = (j + 1) & ~(TS - 1);
-          const int nb = ((int)ld - rs2) / TS, ntiles = nb * (nb + 1) / 2, gy = ((int)ld - rs2) / 64;
+          const int nb = ((int)ld - rs2) / TS, ntiles = nb * (nb + 1) / 2;
           ta.nb = nb;
           if (n > 4096) hipLaunchKernelGGL(k_tri_bs<16>, dim3(ntiles + 2 * jj), dim3(512), 0, st, ta, ntiles);
           else hipLaunchKernelGGL(k_tri_bs<8>, dim3(ntiles + 2 * jj), dim3(512), 0, st, ta, ntiles);
-          hipLaunchKernelGGL(k_tri_yred, dim3(gy), dim3(512), 0, st, ta);
-          ta.npvy = gy;
+          ta.npvy = ntiles;
+          prev_slots = true;
         } else {
           if (n > 4096) hipLaunchKernelGGL((k_tri_b<8, 16>), dim3(gb), dim3(512), v_lds, st, ta);
           else if (tri_unr == 8) hipLaunchKernelGGL((k_tri_b<8, 8>), dim3(gb), dim3(512), v_lds, st, ta);
           else hipLaunchKernelGGL((k_tri_b<4, 8>), dim3(gb), dim3(512), v_lds, st, ta);
           ta.npvy = gb;
+          prev_slots = false;
         }
       }
       const int t0 = p0 + ncols;
       ta.j = t0;
       ta.jj = ncols;
       ta.mode = 1;
-      hipLaunchKernelGGL(k_tri_a, dim3((n - t0 + 63) / 64), dim3(64 * TA_WAVES), 0, st, ta);
+      if (prev_slots) hipLaunchKernelGGL(k_tri_a<true>, dim3((n - t0 + 63) / 64), dim3(64 * TA_WAVES), 0, st, ta);
+      else hipLaunchKernelGGL(k_tri_a<false>, dim3((n - t0 + 63) / 64), dim3(64 * TA_WAVES), 0, st, ta);
       HIP_TRY(hipGetLastError());
       // A[t0:, t0:] -= V W^T + W V^T
       gemm_desc g;

@@ -90,7 +90,7 @@ def tridiagonalize_blocked(T, nb=64):
 
 
 def lower_triangle_products(A, v, j, ts=128):
-    """Twin of k_tri_bs + k_tri_yred: y = A v for a symmetric A and a v that vanishes on rows <= j, touching only the tiles
+    """Twin of k_tri_bs + the slot sums of k_tri_a<true>: y = A v for a symmetric A and a v that vanishes on rows <= j, touching only the tiles
     (I, J), I >= J, of the trailing block counted from rs2 = (j + 1) rounded down to ``ts`` -- a tile below the diagonal serves
     y_I += A_IJ v_J and y_J += A_IJ^T v_I; tile (I, J) leaves the first product in slot J (rows of I), the second in slot I
     (rows of J), so that every row receives exactly nb partial values, one per slot, added in a fixed order.  Returns (y with

@@ -50,7 +50,7 @@ def test_blocked_tridiagonalisation_is_the_unblocked_factorisation():
 
 @pytest.mark.parametrize("n,j", [(500, 0), (500, 126), (500, 127), (513, 200), (700, 383), (640, 511)])
 def test_lower_triangle_products_cover_every_row_once_per_slot(n, j):
-    """The tile / slot scheme of k_tri_bs + k_tri_yred: half the matrix is read, every row finds one partial value in each of its nb
+    """The tile / slot scheme of k_tri_bs + k_tri_a<true>: half the matrix is read, every row finds one partial value in each of its nb
     slots, and their sum is A v on the rows below j (v vanishes on rows <= j; rows and columns <= j inside the first block hold
     older data: they must not leak into the result)."""
     rng = np.random.default_rng(n + j)
