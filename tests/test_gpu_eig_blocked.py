@@ -275,3 +275,47 @@ def test_pod_from_data_320_snapshots_matches_the_reference(ctx, golden_dir, meth
     eye = np.eye(r)
     assert np.linalg.norm(eye - phi.T @ Mphi) / np.linalg.norm(eye) < 1e-8        # test_PODProjector.py:154-168
     assert np.linalg.norm(M @ phi - Mphi) / np.linalg.norm(Mphi) < 1e-8           # :170-174
+
+
+_KNOB_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import hippyflow_amd as hf
+n = int(sys.argv[1])
+rng = np.random.default_rng(n)
+X = rng.standard_normal((n, 300)) * np.exp(-0.02 * np.arange(300))[None, :]
+G = X @ X.T + 1e-6 * np.eye(n)
+d, V = hf.sym_eig_small(G, nvec=64)
+w = np.linalg.eigvalsh(G)[::-1]
+assert np.abs(d - w).max() <= 8e-12 * w[0], np.abs(d - w).max() / w[0]
+assert np.abs(G @ V - V * d[:64]).max() <= 8e-12 * w[0]
+assert np.abs(V.T @ V - np.eye(64)).max() <= 1e-12
+np.save(sys.argv[2], d)
+"""
+
+
+_KNOB_DEFAULT = {}
+
+
+def _knob_child(n, extra, out):
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, str(n), str(out)], env=dict(os.environ, **extra), capture_output=True, text=True,
+                       timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"},
+                                 {"HFMI_EIG_LARGE": "jacobi"}])
+def test_sym_eig_blocked_ab_knobs_give_the_same_spectrum(ctx, tmp_path, env):
+    """The A/B switches of the whole-GPU solver (read once per process, hence a child interpreter each): full-column products only
+    / lower-triangle products from 1024 rows on, 64-row leaves, four loads in flight, the Jacobi of rounds 2-4 -- every route passes the
+    same bars and agrees with the default route's eigenvalues to rounding."""
+    n = 1500 if "HFMI_EIG_LARGE" in env else 4300
+    if n not in _KNOB_DEFAULT:
+        _KNOB_DEFAULT[n] = _knob_child(n, {}, tmp_path / "default.npy")
+    d = _knob_child(n, env, tmp_path / "knob.npy")
+    assert np.abs(d - _KNOB_DEFAULT[n]).max() <= 1e-12 * d[0]
