@@ -619,6 +619,9 @@ def _compact(line):
     comm = line.get("communicator") or {}
     if comm.get("ranks"):
         out["communicator"] = comm
+    if line.get("sptrsv_feasibility"):
+        out["sptrsv_feasibility"] = line["sptrsv_feasibility"]
+        out["host_solver"] = (line.get("config") or {}).get("Binv")
     return out
 
 
@@ -632,9 +635,14 @@ def run_extras(args):
     jobs = [("kernel_point", ["--kernel-point"] + q, 60),
             ("eig_large", ["--eig-large"] + q, 90),
             ("config3", ["--workload", "pod", "--steps", "10", "--warmup", "3", "--cpu-baseline", "quick"] + q, 120),
-            ("config2", ["--workload", "kle", "--steps", "5", "--warmup", "2", "--cpu-baseline", "quick"] + q, 180),
+            ("config2", ["--workload", "kle", "--steps", "4", "--warmup", "1", "--cpu-baseline", "quick"] + q, 180),
             ("shard64", ["--samples-total", "64", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90),
-            ("shard64_rccl_1rank", ["--samples-total", "64", "--dist-single", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90)]
+            ("shard64_rccl_1rank", ["--samples-total", "64", "--dist-single", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90),
+            # the reference's DEFAULT active-subspace path (construct_input_subspace(prior_preconditioned=True), activeSubspaceProjector.py:400,
+            # :447-450: doublePassG(A, prior.R, prior.Rsolver)): the 64-sample shard with B = R as CSR on the device and B^-1 = the host
+            # sparse-LU pool (one worker process per pair of probe vectors, at most the box's physical cores), pinned-slab overlap on
+            ("as_prior_shard64", ["--prior", "--samples-total", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--host-workers",
+                                  str(max(1, min(37, _cpu_topology()["physical_cores"])))] + q, 150)]
     extras, seconds = {}, {}
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
@@ -737,7 +745,7 @@ def main():
         return
     if kernel_extras_wanted(args, world):
         out.update(run_extras(args))
-        out["extra_keys"] = ["kernel_point", "eig_large", "config3", "config2", "shard64", "shard64_rccl_1rank"]
+        out["extra_keys"] = ["kernel_point", "eig_large", "config3", "config2", "shard64", "shard64_rccl_1rank", "as_prior_shard64"]
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
@@ -932,6 +940,14 @@ def solve_line(args, world, rank):
         if "roofline" in out and out["roofline"]["bound"] == "mfma":
             out["roofline"]["frac_of_in_job_loaded_peak"] = (out["roofline"]["achieved"] /
                                                              out["device_peaks_measured"]["mfma_f64_tflops_while_streaming"])
+        # ... and against the same loop on Gaussian operands (the constant-operand loops above toggle almost no bits: their clock
+        # is one the solve's data never sees under the power limit)
+        out["device_peaks_measured"].update(ctx.bench_random_peaks())
+        if "roofline" in out and out["roofline"]["bound"] == "mfma":
+            pm = out["device_peaks_measured"]
+            out["roofline"]["frac_of_in_job_random_operand_peak"] = out["roofline"]["achieved"] / pm["mfma_f64_tflops_random_operands"]
+            out["roofline"]["frac_of_in_job_random_operand_peak_while_streaming"] = (
+                out["roofline"]["achieved"] / pm["mfma_f64_tflops_random_operands_while_streaming"])
     except Exception as exc:   # the micro-benchmark is informative only
         out.setdefault("device_peaks_measured", {})["error"] = str(exc)
 
@@ -959,6 +975,14 @@ def solve_line(args, world, rank):
                                  "the -m gpu tests and smoke() compare with at sizes it finishes in seconds.  Parity against hippylib "
                                  "itself is unpinned (hippylib is absent from the reference tree); LAPACK fixtures "
                                  "(tests/golden/independent_eig.npz) hold both the oracle and the device path to 1e-9"}
+    if prior is not None and not args.quick:
+        # feasibility estimate only (no kernel): what a level-scheduled device triangular solve would face in place of the host LU
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from sptrsv_feasibility import estimate
+            out["sptrsv_feasibility"] = estimate(prior.A, nrhs=r + p)
+        except Exception as exc:
+            out["sptrsv_feasibility"] = {"error": repr(exc)}
     if not args.no_cpu_baseline:
         # rank 0 alone (the other ranks have left the communicator): at N > 1 `wl` is rank 0's shard, the bounded sample is
         # drawn from it and scaled to the whole job exactly as at N = 1

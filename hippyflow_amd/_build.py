@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhfmi.so")
-SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip", "hfmi_comm.hip", "hfmi_eig_large.hip", "hfmi_eig_blocked.hip", "hfmi_eig_dc.hip", "hfmi_chol.hip", "hfmi_cheb.hip"]
+SOURCES = ["hfmi_api.hip", "hfmi_gemm.hip", "hfmi_gemm_nn.hip", "hfmi_misc.hip", "hfmi_small.hip", "hfmi_skinny.hip", "hfmi_comm.hip", "hfmi_eig_large.hip", "hfmi_eig_blocked.hip", "hfmi_eig_dc.hip", "hfmi_chol.hip", "hfmi_cheb.hip", "hfmi_xfer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + os.environ.get("HFMI_EXTRA_HIPCC_FLAGS", "").split()
 
 

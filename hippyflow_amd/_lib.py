@@ -104,6 +104,8 @@ SIGNATURES = {
     "hfmi_bench_tsgemm_nn": [_P, _P, _P, C.c_int, _D],
     "hfmi_bench_peaks": [_P, _D, _D, _D],
     "hfmi_bench_loaded_peak": [_P, _D, _D],
+    "hfmi_bench_random_peaks": [_P, _D, _D, _D],
+    "hfmi_bench_dgemm": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D, _D, _D, _D],
     "hfmi_profile_begin": [_P],
     "hfmi_profile_phases": [_P, _D],
     "hfmi_tuning_set": [C.c_char_p, C.c_int],
@@ -307,6 +309,26 @@ class Context:
         a, b = C.c_double(0), C.c_double(0)
         call("hfmi_bench_loaded_peak", self.handle, C.byref(a), C.byref(b))
         return {"mfma_f64_tflops_while_streaming": a.value, "hbm_copy_gbs_beside_it": b.value}
+
+    def bench_dgemm(self, A, B, ta=False, tb=False, reps=5, want_c=True):
+        """C = op(A) op(B) through the eigensolver's general fp64 MFMA product; returns (C or None, average ms of one launch)."""
+        import numpy as np
+        A, B = np.asfortranarray(A, dtype=np.float64), np.asfortranarray(B, dtype=np.float64)
+        M, K = (A.shape[1], A.shape[0]) if ta else A.shape
+        N = B.shape[0] if tb else B.shape[1]
+        assert (B.shape[1] if tb else B.shape[0]) == K
+        Cm = np.empty((M, N), order="F") if want_c else None
+        ms = C.c_double(0.0)
+        call("hfmi_bench_dgemm", self.handle, M, N, K, int(ta), int(tb), int(reps), A.ctypes.data_as(_D), B.ctypes.data_as(_D),
+             Cm.ctypes.data_as(_D) if want_c else None, C.byref(ms))
+        return Cm, ms.value
+
+    def bench_random_peaks(self):
+        """fp64 MFMA rate on Gaussian (full-mantissa) operands rotated through the registers, alone and beside the streaming copy."""
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        call("hfmi_bench_random_peaks", self.handle, C.byref(a), C.byref(b), C.byref(c))
+        return {"mfma_f64_tflops_random_operands": a.value, "mfma_f64_tflops_random_operands_while_streaming": b.value,
+                "hbm_copy_gbs_beside_random_operands": c.value}
 
     def profile_begin(self):
         call("hfmi_profile_begin", self.handle)

@@ -152,6 +152,7 @@ extern "C" int hfmi_ctx_create(int device, hfmi_ctx** out) {
   c->pinned_bytes = 0;
   c->pinned_cb = nullptr;
   c->pinned_cb_bytes = 0;
+  c->xfer = nullptr;
   c->pool_bytes = 0;
   for (int i = 0; i < HFMI_PHASE_COUNT; ++i) c->phase_ms[i] = 0.0;
   c->profiling = false;
@@ -199,6 +200,7 @@ extern "C" int hfmi_ctx_destroy(hfmi_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_cb) (void)hipHostFree(ctx->pinned_cb);
   if (ctx->late_pinned) (void)hipHostFree(ctx->late_pinned);
+  xfer_destroy(ctx);
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_cb[i]);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev_panel[i]);
   (void)hipEventDestroy(ctx->ev_join);
@@ -2100,6 +2102,18 @@ extern "C" int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, do
   if (!ctx || !mfma_f64_tflops || !hbm_copy_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   return launch_bench_loaded_peak(ctx, mfma_f64_tflops, hbm_copy_gbs);
+}
+extern "C" int hfmi_bench_dgemm(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, int reps, const double* host_A, const double* host_B,
+                                double* host_C, double* avg_ms) {
+  if (!ctx || !host_A || !host_B) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (M < 1 || N < 1 || K < 1 || reps < 0) HFMI_FAIL(HFMI_ERR_INVALID, "bench_dgemm: bad shape %d x %d x %d", M, N, K);
+  HIP_TRY(hipSetDevice(ctx->device));
+  return eig_dgemm_bench(ctx, M, N, K, ta, tb, reps, host_A, host_B, host_C, avg_ms);
+}
+extern "C" int hfmi_bench_random_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* mfma_f64_tflops_while_streaming, double* hbm_copy_gbs) {
+  if (!ctx || !mfma_f64_tflops || !mfma_f64_tflops_while_streaming || !hbm_copy_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_bench_random_peaks(ctx, mfma_f64_tflops, mfma_f64_tflops_while_streaming, hbm_copy_gbs);
 }
 extern "C" int hfmi_ctx_pci_bus_id(hfmi_ctx* ctx, char* buf, int len) {
   if (!ctx || !buf || len < 16) HFMI_FAIL(HFMI_ERR_INVALID, "ctx_pci_bus_id: bad argument");

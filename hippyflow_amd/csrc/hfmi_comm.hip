@@ -308,8 +308,11 @@ static int p2p_alloc_stage(hfmi_comm* c, size_t want, bool force_coarse = false)
 // been used: thousands of later collectives, no case).  So a new set of mappings is exercised before it carries data: every rank
 // fills a probe area of its own buffer with its own pattern, every rank then stores a round-specific token into its slot of every
 // PEER's probe area through the mapping (the store path of the reduction), and every rank reads its own area back through a kernel
-// copy (the load path of the copy-out) and checks all P tokens.  The round is repeated until every rank has seen every token
-// (usually the first; the count is in hfmi_comm_describe: "p2p_probe_rounds"); four failed rounds are an error, not silent data.
+// copy (the load path of the copy-out) and checks all P tokens.  A set of mappings gets at most two rounds (the count is in
+// hfmi_comm_describe: "p2p_probe_rounds"); when both fail the caller replaces the buffers, up to three generations -- six failed
+// rounds in all are an error, not silent data.  A HIP failure on ONE rank is published in the shared table as probe_ok = -1 and
+// that rank still takes every barrier of the round, so that all ranks return the error together instead of its peers waiting for
+// the communicator's time-out.
 __global__ void __launch_bounds__(256) k_p2p_copy(double* __restrict__ dst, const double* __restrict__ src, int64_t count) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int64_t n2 = count >> 1, stride = (int64_t)gridDim.x * blockDim.x;
@@ -339,38 +342,49 @@ static int p2p_probe_stage(hfmi_comm* c, bool* verdict) {
   for (int p = 0; p < COMM_MAX_RANKS; ++p) bufs.p[p] = p < P ? c->peer[p] : nullptr;
   int rounds = 0, rc = HFMI_OK;
   bool all_ok = false;
-  for (int round = 0; round < 2 && !all_ok && rc == HFMI_OK; ++round) {
+  bool hip_bad = false, peer_bad = false;       // a HIP call failed here / on some rank
+  for (int round = 0; round < 2 && !all_ok && rc == HFMI_OK && !peer_bad; ++round) {
     ++rounds;
     const double own = -1.0 - c->rank - 100.0 * round;
-    hipLaunchKernelGGL(k_p2p_probe_fill, dim3(1), dim3(256), 0, st, c->stage, P, own);
-    if (hipStreamSynchronize(st) != hipSuccess) rc = HFMI_ERR_HIP;
-    if (rc == HFMI_OK) rc = shm_barrier(c);                     // every rank's own pattern is in place
+    if (!hip_bad) {
+      hipLaunchKernelGGL(k_p2p_probe_fill, dim3(1), dim3(256), 0, st, c->stage, P, own);
+      if (hipStreamSynchronize(st) != hipSuccess) hip_bad = true;
+    }
+    rc = shm_barrier(c);                                         // every rank's own pattern is in place
     if (rc != HFMI_OK) break;
-    hipLaunchKernelGGL(k_p2p_probe_store, dim3(P), dim3(64), 0, st, bufs, P, c->rank, 1000.0 * (round + 1) + c->rank);
-    if (hipStreamSynchronize(st) != hipSuccess) rc = HFMI_ERR_HIP;
-    if (rc == HFMI_OK) rc = shm_barrier(c);                     // every rank's tokens have been stored (kernels complete)
+    if (!hip_bad) {
+      hipLaunchKernelGGL(k_p2p_probe_store, dim3(P), dim3(64), 0, st, bufs, P, c->rank, 1000.0 * (round + 1) + c->rank);
+      if (hipStreamSynchronize(st) != hipSuccess) hip_bad = true;
+    }
+    rc = shm_barrier(c);                                         // every rank's tokens have been stored (kernels complete)
     if (rc != HFMI_OK) break;
-    hipLaunchKernelGGL(k_p2p_copy, dim3(1), dim3(256), 0, st, scratch, (const double*)c->stage, (int64_t)n);
-    if (hipMemcpyAsync(host.data(), scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      rc = HFMI_ERR_HIP;
-    if (rc != HFMI_OK) break;
-    bool ok = true;
+    if (!hip_bad) {
+      hipLaunchKernelGGL(k_p2p_copy, dim3(1), dim3(256), 0, st, scratch, (const double*)c->stage, (int64_t)n);
+      if (hipMemcpyAsync(host.data(), scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        hip_bad = true;
+    }
+    bool ok = !hip_bad;
     for (int p = 0; p < P && ok; ++p)
       for (int i = 0; i < PROBE_SLOT; ++i)
         if (host[p * PROBE_SLOT + i] != 1000.0 * (round + 1) + p) {
           ok = false;
           break;
         }
-    c->sh->slot[c->rank].probe_ok = ok ? 1 : 0;
+    c->sh->slot[c->rank].probe_ok = hip_bad ? -1 : (ok ? 1 : 0);
     rc = shm_barrier(c);
     if (rc != HFMI_OK) break;
     all_ok = true;
-    for (int p = 0; p < P; ++p) all_ok = all_ok && c->sh->slot[p].probe_ok == 1;
+    for (int p = 0; p < P; ++p) {
+      all_ok = all_ok && c->sh->slot[p].probe_ok == 1;
+      peer_bad = peer_bad || c->sh->slot[p].probe_ok < 0;
+    }
     rc = shm_barrier(c);                                         // everybody has read the table before the next round rewrites it
   }
+  if (rc == HFMI_OK && (hip_bad || peer_bad)) rc = HFMI_ERR_HIP;
   (void)hipFree(scratch);
-  if (rc == HFMI_ERR_HIP) hfmi_set_error("p2p staging probe: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc == HFMI_ERR_HIP)
+    hfmi_set_error("p2p staging probe: a HIP call failed on %s: %s", hip_bad ? "this rank" : "another rank", hipGetErrorString(hipGetLastError()));
   if (rc != HFMI_OK) return rc;
   c->probe_rounds = rounds;
   c->probe_retries_total += rounds - 1;
@@ -405,7 +419,9 @@ static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
     for (int attempt = 0; attempt < 4; ++attempt) {
       const size_t actual = want + ((size_t)(4 * gen + attempt) << 21);
       HFMI_TRY(p2p_alloc_stage(c, actual, gen == 2));
-      c->stage_bytes = actual;
+      // the capacity the growth decision above compares with must be the same number on every rank: `attempt` is rank-local
+      // (an export retried on some ranks only), so it stays out of it -- the allocation is merely up to 6 MB larger than this
+      c->stage_bytes = want + ((size_t)(4 * gen) << 21);
       exp_err = hipIpcGetMemHandle(&me.handle, c->stage);
       if (exp_err == hipSuccess) break;
       (void)hipGetLastError();

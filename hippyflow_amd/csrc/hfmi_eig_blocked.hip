@@ -154,6 +154,169 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
       }
 }
 
+// ------------------------------------------------------------------------------------------------ fp64 MFMA GEMM, software-pipelined
+// The same contract as k_dgemm for the large products (trailing rank-2k updates, Q S of the upper merges, the block reflectors of
+// the back-transformation), built for the MFMA pipe to stay busy:
+//   * workgroup tile BM x 128 (BM = 128 | 64), 4 waves of (BM / 2) x 64: 4 x 4 (2 x 4) accumulator tiles per wave, so a reduction
+//     step of 4 costs 4 + 4 (2 + 4) eight-byte LDS reads for 16 (8) MFMAs of 64 cycles each;
+//   * the operand fragments of step k + 1 are read into a second register set while the MFMAs of step k issue (register double
+//     buffering: the 128 x 128 variant of round 5 read its fragments right before their use and lost to the 64 x 64 one);
+//   * the next 16-deep slab of both operands travels global -> registers (16-byte loads) during the whole slab, and is written to
+//     the other LDS buffer after the last MFMA: one barrier per 64 (32) MFMAs of a wave;
+//   * LDS layout by the operand's memory layout, both conflict-free for the 16-byte stores and the 8-byte fragment reads:
+//       own index contiguous in memory -> k-major rows of BT + 16 doubles (= 16 mod 32: the four k-rows of a fragment fall into
+//       two bank halves), reduction index contiguous -> own-index-major rows of 18 doubles (36 li mod 64 are 16 distinct multiples
+//       of 4: a fragment's 16 rows x 2 columns cover the 64 banks exactly once).
+// 16-byte loads need 16-byte aligned operands (even offsets and leading dimensions): `vec` says so, else 8-byte loads.
+constexpr int PK = 16;              // reduction depth of an LDS stage
+constexpr int PS_KC = 18;           // row stride (doubles) of a stage whose rows are the operand's own index
+template <bool KC, int BT>
+struct pstage {
+  static constexpr int ND2 = BT * PK / 2 / 256;            // 16-byte pieces per thread
+  static constexpr int LDK = BT + 16;                      // k-major row stride
+  static constexpr int DOUBLES = KC ? BT * PS_KC : PK * LDK;
+  // piece u of thread tid: own index t (pair t, t + 1 if !KC), reduction index k (pair k, k + 1 if KC)
+  static __device__ __forceinline__ void idx(int tid, int u, int& t, int& k) {
+    if (KC) {
+      k = 2 * (tid & 7);
+      t = (tid >> 3) + 32 * u;
+    } else {
+      t = 2 * (tid & (BT / 2 - 1));
+      k = tid / (BT / 2) + (512 / BT) * u;
+    }
+  }
+  static __device__ __forceinline__ void load(const double* __restrict__ X, int64_t ld, int t0, int k0, int Tdim, int Kdim, int tid, bool vec,
+                                              d2 (&r)[ND2]) {
+#pragma unroll
+    for (int u = 0; u < ND2; ++u) {
+      int t, k;
+      idx(tid, u, t, k);
+      const int tt = t0 + t, kk = k0 + k;
+      const int64_t off = KC ? (int64_t)kk + (int64_t)tt * ld : (int64_t)tt + (int64_t)kk * ld;
+      const bool ok0 = tt < Tdim && kk < Kdim;
+      const bool ok1 = KC ? (tt < Tdim && kk + 1 < Kdim) : (tt + 1 < Tdim && kk < Kdim);
+      if (vec && ok1) {
+        r[u] = *(const d2*)(X + off);
+      } else {
+        r[u].x = ok0 ? X[off] : 0.0;
+        r[u].y = ok1 ? X[off + 1] : 0.0;
+      }
+    }
+  }
+  static __device__ __forceinline__ void store(double* __restrict__ s, int tid, const d2 (&r)[ND2]) {
+#pragma unroll
+    for (int u = 0; u < ND2; ++u) {
+      int t, k;
+      idx(tid, u, t, k);
+      if (KC) *(d2*)(s + t * PS_KC + k) = r[u];
+      else *(d2*)(s + k * LDK + t) = r[u];
+    }
+  }
+  // fragment element (own index t, reduction index k)
+  static __device__ __forceinline__ double frag(const double* __restrict__ s, int t, int k) { return KC ? s[t * PS_KC + k] : s[k * LDK + t]; }
+};
+template <bool TA, bool TB, int BM>
+__global__ __launch_bounds__(256, 2) void k_dgemm_p(int M, int N, int K, double alpha, const double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ B, int64_t ldb, int K2, const double* __restrict__ A2,
+                                                    const double* __restrict__ B2, double beta, double* __restrict__ C, int64_t ldc,
+                                                    int64_t sA, int64_t sB, int64_t sC, int vec, int lower) {
+  constexpr int BN = 128, MI = BM / 32, NI = 4;
+  typedef pstage<TA, BM> SA;          // op(A) = A^T: the reduction index is the contiguous one
+  typedef pstage<!TB, BN> SB;
+  extern __shared__ __attribute__((aligned(16))) double s_p[];
+  auto s_a = [&](int b) { return s_p + b * SA::DOUBLES; };
+  auto s_b = [&](int b) { return s_p + 2 * SA::DOUBLES + b * SB::DOUBLES; };
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, li = l & 15, lk = l >> 4;
+  const int wm = w & 1, wn = w >> 1;
+  const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+  // symmetric update, lower part only: `lower` - 1 is the position of C's first row / column inside its 128 x 128 block of the matrix;
+  // a tile is skipped when it lies entirely above the diagonal 128-blocks (the lower-triangle products read those blocks whole)
+  if (lower && ((i0 + lower - 1 + BM - 1) >> 7) < ((j0 + lower - 1) >> 7)) return;
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  if (K2 > 0) {
+    A2 += (int64_t)blockIdx.z * sA;
+    B2 += (int64_t)blockIdx.z * sB;
+  }
+  d4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+  const int nk1 = (K + PK - 1) / PK, nk2 = (K2 + PK - 1) / PK, nk = nk1 + nk2;
+  d2 ra[SA::ND2], rb[SB::ND2];
+  auto gload = [&](int kt) {
+    const bool second = kt >= nk1;
+    const double* Ap = second ? A2 : A;
+    const double* Bp = second ? B2 : B;
+    const int Kc = second ? K2 : K, k0 = (second ? kt - nk1 : kt) * PK;
+    SA::load(Ap, lda, i0, k0, M, Kc, tid, vec != 0, ra);
+    SB::load(Bp, ldb, j0, k0, N, Kc, tid, vec != 0, rb);
+  };
+  if (nk > 0) {
+    gload(0);
+    SA::store(s_a(0), tid, ra);
+    SB::store(s_b(0), tid, rb);
+  }
+  __syncthreads();
+  const int ta0 = wm * (BM / 2) + li, tb0 = wn * 64 + li;
+  for (int kt = 0; kt < nk; ++kt) {
+    const double* __restrict__ pa = s_a(kt & 1);
+    const double* __restrict__ pb = s_b(kt & 1);
+    if (kt + 1 < nk) gload(kt + 1);
+    double fa[2][MI], fb[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fa[0][mi] = SA::frag(pa, ta0 + 16 * mi, lk);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fb[0][ni] = SB::frag(pb, tb0 + 16 * ni, lk);
+#pragma unroll
+    for (int k4 = 0; k4 < PK / 4; ++k4) {
+      const int cur = k4 & 1, nxt = cur ^ 1;
+      if (k4 + 1 < PK / 4) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = SA::frag(pa, ta0 + 16 * mi, 4 * (k4 + 1) + lk);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fb[nxt][ni] = SB::frag(pb, tb0 + 16 * ni, 4 * (k4 + 1) + lk);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(fb[cur][ni], fa[cur][mi], acc[mi][ni]);
+    }
+    if (kt + 1 < nk) {
+      SA::store(s_a((kt + 1) & 1), tid, ra);
+      SB::store(s_b((kt + 1) & 1), tid, rb);
+    }
+    __syncthreads();
+  }
+  // epilogue: lane (li, lk), register reg of tile (mi, ni) holds C[i0 + wm BM/2 + 16 mi + li, j0 + wn 64 + 16 ni + lk + 4 reg]
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = j0 + wn * 64 + ni * 16 + lk + 4 * reg;
+      if (j >= N) continue;
+      double* __restrict__ ccol = C + (int64_t)j * ldc;
+      double old[MI];
+      if (beta != 0.0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int i = i0 + wm * (BM / 2) + mi * 16 + li;
+          old[mi] = i < M ? ccol[i] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int i = i0 + wm * (BM / 2) + mi * 16 + li;
+        if (i < M) {
+          double v = alpha * acc[mi][ni][reg];
+          if (beta != 0.0) v = fma(beta, old[mi], v);
+          ccol[i] = v;
+        }
+      }
+    }
+}
 struct gemm_desc {
   bool ta, tb;
   int M, N, K;
@@ -166,9 +329,46 @@ struct gemm_desc {
   const double *A2 = nullptr, *B2 = nullptr;
   int batch = 1;
   int64_t sA = 0, sB = 0, sC = 0;
+  int lower = 0;            // symmetric update: > 0 = 1 + (first row of C mod 128): tiles above the diagonal 128-blocks are skipped (pipelined kernel only)
 };
+template <bool TA, bool TB, int BM>
+int launch_dgemm_p(hfmi_ctx* ctx, const gemm_desc& g, int vec) {
+  typedef pstage<TA, BM> SA;
+  typedef pstage<!TB, 128> SB;
+  const size_t lds = (size_t)2 * (SA::DOUBLES + SB::DOUBLES) * sizeof(double);
+  static bool attr_set = false;       // (one flag per instantiation)
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_dgemm_p<TA, TB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const dim3 grid((g.M + BM - 1) / BM, (g.N + 127) / 128, g.batch), block(256);
+  hipLaunchKernelGGL((k_dgemm_p<TA, TB, BM>), grid, block, lds, ctx->stream, g.M, g.N, g.K, g.alpha, g.A, g.lda, g.B, g.ldb, g.K2, g.A2, g.B2,
+                     g.beta, g.C, g.ldc, g.sA, g.sB, g.sC, vec, g.lower);
+  HIP_TRY(hipGetLastError());
+  return HFMI_OK;
+}
 int launch_dgemm(hfmi_ctx* ctx, const gemm_desc& g) {
   if (g.M <= 0 || g.N <= 0) return HFMI_OK;
+  static const int pipelined = [] {      // HFMI_EIG_GEMM = 0: the 64 x 64 kernel of round 5 everywhere (A/B)
+    const char* e = getenv("HFMI_EIG_GEMM");
+    return e ? atoi(e) : 1;
+  }();
+  // the pipelined kernel where its tiles fill the chip: 128 x 128 from 192 tiles on, 64 x 128 from 192 of those; the 64 x 64 kernel below
+  // for the small products (panel factors, merges of small nodes)
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+  const int64_t t64 = (int64_t)((g.M + 63) / 64) * ((g.N + 127) / 128) * g.batch;
+  if (pipelined && (t128 >= 192 || t64 >= 192) && g.K + g.K2 >= 32) {
+    auto even = [](int64_t v) { return (v & 1) == 0; };
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const int vec = even(g.lda) && even(g.ldb) && even(g.sA) && even(g.sB) && al16(g.A) && al16(g.B) && (g.K2 == 0 || (al16(g.A2) && al16(g.B2)));
+    const bool big = t128 >= 192;
+#define EB_GEMM_P(TAV, TBV) (big ? launch_dgemm_p<TAV, TBV, 128>(ctx, g, vec) : launch_dgemm_p<TAV, TBV, 64>(ctx, g, vec))
+    if (!g.ta && !g.tb) return EB_GEMM_P(false, false);
+    if (g.ta && !g.tb) return EB_GEMM_P(true, false);
+    if (!g.ta && g.tb) return EB_GEMM_P(false, true);
+    return EB_GEMM_P(true, true);
+#undef EB_GEMM_P
+  }
   const dim3 grid((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, g.batch), block(256);
 #define EB_GEMM(TAV, TBV)                                                                                                              \
   hipLaunchKernelGGL((k_dgemm<TAV, TBV>), grid, block, 0, ctx->stream, g.M, g.N, g.K, g.alpha, g.A, g.lda, g.B, g.ldb, g.K2, g.A2, g.B2, \
@@ -609,6 +809,148 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
   __syncthreads();
   if (tid == 0) p.pvy[blockIdx.x] = (I == J ? 1.0 : 2.0) * (s_dot[0] + s_dot[1]);
 }
+// ------------------------------------------------------------------------------------------------ unblocked tail: ONE launch per column
+// For trailing blocks of at most EB_UNB_CAP rows the tridiagonalisation is bound by the two kernel boundaries + two chains of
+// dependent memory round trips that a column of the panel algorithm costs (8.7-10 us per column at n <= 2048 whatever the size:
+// profiles/r05_eig_large_n2048_kernel_stats.csv), not by bytes.  LAPACK's unblocked recurrence (dsytd2) needs ONE device-wide
+// exchange per column when the rank-2 update of reflector j - 1 is delayed into the pass that forms A v_j:
+//   every workgroup (redundantly, same arithmetic, same bits) takes y = A v of the last step and v itself, whole:
+//     alpha = -tau^2/2 (v . y),  w = tau y + alpha v                                  (dsytd2's symmetric correction)
+//     c = A[:, j] - v w_j - w v_j   (column j of the reduced matrix: the delayed update applied to this one column),
+//     d_j = c_j, the reflector of c[j + 1:] -> e_j, tau_j, v_new                      (its norm from the whole column: no partial sums)
+//   then every WAVE owns columns q > j of the (full, symmetric) trailing block:
+//     A[:, q] -= v w_q + w v_q  (written back),  y_new[q] = A[:, q] . v_new           (a column is contiguous: 16-byte loads)
+// -- v, w and v_new live in LDS (24 bytes per row), the first column of a wave is requested before anything else.  The matrix is
+// read AND written once per column (the panel algorithm reads half of it and writes it once per 64 columns), which is why this
+// path stops at EB_UNB_CAP rows: below it the trailing block sits in the caches and the column time is latency, not bytes.
+constexpr int EB_UNB_CAP = 2304;      // rows of LDS vectors: (cap + 63 + 127 rounded to 128) * 24 bytes <= 64 KB
+template <int UNR>       // 16-byte loads per lane that cover one column: (ld - rs) / 2 <= 64 UNR pairs
+__global__ __launch_bounds__(512) void k_tri_u(tri_args p, const double* __restrict__ yprev, double* __restrict__ ynew, int has_prev) {
+  constexpr int CB = UNR / 4;         // rows per thread of the whole-vector part: (ld - rs) <= 512 CB
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  __shared__ double s_red[8], s_bc[4];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j;
+  const int64_t ld = p.ld;
+  const int rs = j & ~63;
+  const int L = (int)ld - rs, npair = L >> 1;
+  double* s_vp = s_dyn;
+  double* s_w = s_dyn + L;
+  double* s_vn = s_dyn + 2 * L;
+  const int nA = n - j - 1;           // columns of the trailing block
+  // this wave's first column: its loads depend on nothing
+  const int qstride = gridDim.x * 8;
+  const int q0 = j + 1 + blockIdx.x * 8 + w;
+  d2 x[UNR];
+  {
+    const d2* __restrict__ c2 = (const d2*)(p.A + (size_t)(q0 < n ? q0 : j) * ld + rs);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) x[u] = (q0 < n && l + 64 * u < npair) ? c2[l + 64 * u] : d2{0.0, 0.0};
+  }
+  // ---- the whole-vector part
+  double yv[CB], vp[CB], cj[CB];
+  const double* __restrict__ vprev = p.Vh + (size_t)(j > 0 ? j - 1 : 0) * ld;
+  const double* __restrict__ acol = p.A + (size_t)j * ld;
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    const int r = rs + tid + 512 * u;
+    const bool in = r >= j && r < n;
+    yv[u] = (has_prev && in) ? yprev[r] : 0.0;
+    vp[u] = (has_prev && in) ? vprev[r] : 0.0;
+    cj[u] = in ? acol[r] : 0.0;
+  }
+  const double tp = has_prev ? p.tauv[j - 1] : 0.0;
+  auto block_sum = [&](double v) {
+    v = wave_sum(v);
+    if (l == 0) s_red[w] = v;
+    __syncthreads();
+    const double t = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    __syncthreads();
+    return t;
+  };
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < CB; ++u) acc = fma(vp[u], yv[u], acc);
+  const double vy = block_sum(acc);
+  const double alpha = -0.5 * tp * tp * vy;
+  double wv[CB];
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    const int r = rs + tid + 512 * u;
+    wv[u] = fma(tp, yv[u], alpha * vp[u]);
+    if (r < (int)ld) {
+      s_vp[r - rs] = vp[u];
+      s_w[r - rs] = wv[u];
+    }
+  }
+  __syncthreads();
+  const double wj = s_w[j - rs];      // v_{j-1}[j] = 1
+  double c[CB];
+  acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    const int r = rs + tid + 512 * u;
+    c[u] = has_prev ? (cj[u] - fma(vp[u], wj, wv[u])) : cj[u];
+    if (r == j) s_bc[0] = c[u];
+    if (r == j + 1) s_bc[1] = c[u];
+    if (r >= j + 2 && r < n) acc = fma(c[u], c[u], acc);
+  }
+  const double xn2 = block_sum(acc);  // (its barriers publish s_bc as well)
+  const double dj = s_bc[0], alpha0 = j + 1 < n ? s_bc[1] : 0.0;
+  double tau = 0.0, beta = alpha0, scl = 0.0;
+  if (xn2 > 1e-280) {
+    const double nrm = sqrt(fma(alpha0, alpha0, xn2));
+    beta = -copysign(nrm, alpha0);
+    tau = (beta - alpha0) / beta;
+    scl = 1.0 / (alpha0 - beta);
+  }
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    const int r = rs + tid + 512 * u;
+    if (r < (int)ld) s_vn[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : c[u] * scl);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    p.dvec[j] = dj;
+    if (j + 1 < n) {
+      p.evec[j] = beta;
+      p.tauv[j] = tau;
+    }
+  }
+  __syncthreads();
+  if (nA <= 0) return;
+  {      // column j of the reflector matrix (rows above rs are zero already), this workgroup's share of the rows
+    double* __restrict__ vcol = p.Vh + (size_t)j * ld;
+    for (int r = rs + blockIdx.x * 512 + tid; r < n; r += gridDim.x * 512) vcol[r] = s_vn[r - rs];
+  }
+  const d2* __restrict__ vp2 = (const d2*)s_vp;
+  const d2* __restrict__ w2 = (const d2*)s_w;
+  const d2* __restrict__ vn2 = (const d2*)s_vn;
+  for (int q = q0; q < n; q += qstride) {
+    d2* __restrict__ c2 = (d2*)(p.A + (size_t)q * ld + rs);
+    if (q != q0) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) x[u] = l + 64 * u < npair ? c2[l + 64 * u] : d2{0.0, 0.0};
+    }
+    const double wq = s_w[q - rs], vq = s_vp[q - rs];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = l + 64 * u;
+      if (i < npair) {
+        const d2 vv = vp2[i], ww = w2[i], nn = vn2[i];
+        d2 a = x[u];
+        if (has_prev) {
+          a.x -= fma(vv.x, wq, ww.x * vq);
+          a.y -= fma(vv.y, wq, ww.y * vq);
+          c2[i] = a;
+        }
+        a0 = fma(a.x, nn.x, a0);
+        a1 = fma(a.y, nn.y, a1);
+      }
+    }
+    const double y = wave_sum(a0 + a1);
+    if (l == 0) ynew[q] = y;
+  }
+}
 __global__ void k_tri_tail(const double* __restrict__ A, int64_t ld, int n, double* __restrict__ dvec, double* __restrict__ evec) {
   if (threadIdx.x == 0) {
     dvec[n - 2] = A[(size_t)(n - 2) + (size_t)(n - 2) * ld];
@@ -1024,6 +1366,29 @@ __global__ __launch_bounds__(256) void k_pick_columns(const double* __restrict__
   for (int r = threadIdx.x; r < n; r += 256) dst[r] = src[r];
 }
 
+// upper triangle of the trailing block <- its lower triangle (A[c, r] = A[r, c], r > c >= t0): the rank-2k updates of the panels
+// whose columns take the lower-triangle products only touch the tiles on and below the diagonal; the full-column products
+// and the unblocked tail read whole columns
+__global__ __launch_bounds__(256) void k_mirror_lower(double* __restrict__ A, int64_t ld, int n, int t0) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.x, bj = blockIdx.y;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = t0 + bi * 32, c0 = t0 + bj * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = ty + 8 * q;            // element (r0 + tx, c0 + c) of the lower triangle
+    t[c][tx] = (r0 + tx < n && c0 + c < n) ? A[(size_t)(r0 + tx) + (size_t)(c0 + c) * ld] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = ty + 8 * q;           // destination (c0 + tx, r0 + rr): row index from the source's column range
+    const int dr = c0 + tx, dc = r0 + rr;
+    if (dr < n && dc < n && dc > dr) A[(size_t)dr + (size_t)dc * ld] = t[tx][rr];
+  }
+}
+
 struct phase_clock {
   hfmi_ctx* ctx;
   bool on;
@@ -1047,6 +1412,47 @@ struct phase_clock {
 };
 }  // namespace
 
+// instrumentation: C (M x N) = op(A) op(B) through launch_dgemm (the products of the eigensolver), host operands column-major with
+// their natural leading dimensions (A: ta ? K x M : M x K; B: tb ? N x K : K x N); average time of `reps` launches after one warm-up
+int eig_dgemm_bench(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, int reps, const double* host_A, const double* host_B,
+                    double* host_C, double* avg_ms) {
+  const int64_t ra = ta ? K : M, ca = ta ? M : K, rb = tb ? N : K, cb = tb ? K : N;
+  const int64_t lda = round_up(ra, 2), ldb = round_up(rb, 2), ldc = round_up(M, 2);
+  void* wv = nullptr;
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, (size_t)(lda * ca + ldb * cb + ldc * N) * sizeof(double), &wv));
+  double *A = (double*)wv, *B = A + lda * ca, *C = B + ldb * cb;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpy2DAsync(A, lda * sizeof(double), host_A, ra * sizeof(double), ra * sizeof(double), ca, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpy2DAsync(B, ldb * sizeof(double), host_B, rb * sizeof(double), rb * sizeof(double), cb, hipMemcpyHostToDevice, st));
+  gemm_desc g;
+  g.ta = ta != 0;
+  g.tb = tb != 0;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.alpha = 1.0;
+  g.beta = 0.0;
+  g.A = A;
+  g.B = B;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.C = C;
+  g.ldc = ldc;
+  HFMI_TRY(launch_dgemm(ctx, g));
+  HIP_TRY(hipEventRecord(ctx->ev0, st));
+  for (int r = 0; r < reps; ++r) HFMI_TRY(launch_dgemm(ctx, g));
+  HIP_TRY(hipEventRecord(ctx->ev1, st));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (avg_ms) *avg_ms = reps > 0 ? ms / reps : 0.0;
+  if (host_C) {
+    HIP_TRY(hipMemcpy2DAsync(host_C, (size_t)M * sizeof(double), C, ldc * sizeof(double), (size_t)M * sizeof(double), N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return HFMI_OK;
+}
+
 // host_T: n x n row-major symmetric (the symmetric part is used); host_d: n eigenvalues descending (by |d| if
 // sort_by_abs); host_V: n x n row-major, eigenvectors in the columns (may be null).
 // nvec: how many eigenvectors (the leading ones in output order) are wanted; host_V is n x nvec row-major.
@@ -1055,6 +1461,7 @@ struct phase_clock {
 int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V, int nvec,
                   const double* dev_T) {
   if (n > EB_MAXN) HFMI_FAIL(HFMI_ERR_INVALID, "sym_eig: n=%d exceeds %d", n, EB_MAXN);
+  sort_by_abs &= 1;      // the callers hand over their whole flags word (bit 1 = HFMI_EIG_JACOBI selects a method, not an order)
   if (nvec < 0 || nvec > n) nvec = n;
   if (!host_V) nvec = 0;
   static const bool jacobi_env = [] {
@@ -1151,7 +1558,6 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   phase_clock clk(ctx);
 
   // ---- load
-  if (!dev_T) HIP_TRY(hipMemcpyAsync(Qg, host_T, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, st));
   const double* raw = dev_T ? dev_T : Qg;
   HIP_TRY(hipMemsetAsync(A, 0, mat * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(Vh, 0, mat * sizeof(double), st));
@@ -1159,6 +1565,9 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   HIP_TRY(hipMemsetAsync(Wp, 0, (size_t)ld * NB * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(colbuf, 0, 16 * vlen * sizeof(double), st));    // the vectors (tau beyond n - 3 must read 0)
   HIP_TRY(hipMemsetAsync(fail, 0, 16 * sizeof(int), st));
+  clk.mark(6);
+  if (!dev_T) HFMI_TRY(xfer_h2d(ctx, Qg, host_T, (size_t)n * n * sizeof(double)));      // (the fills above run while the host side is read)
+  clk.mark(7);
   {
     const int nt = (n + 31) / 32;
     hipLaunchKernelGGL(k_sym_load, dim3(nt, nt), dim3(256), 0, st, raw, n, A, ld, pmax);
@@ -1201,7 +1610,26 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     bool prev_slots = false;             // the last column's products were left in slots by k_tri_bs
     if (n > 4096)      // v of the first columns is 64 KB: beyond what a kernel gets without asking
       HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
+    static const int unb_max = [] {      // HFMI_EIG_UNB_MAX: trailing blocks of at most this many rows take one launch per column (0: never)
+      const char* e = getenv("HFMI_EIG_UNB_MAX");
+      const int v = e ? atoi(e) : 2048;
+      return std::max(0, std::min(v, EB_UNB_CAP));
+    }();
+    int j_unb = -1;                      // first column of the unblocked tail
+    bool upper_valid = true;             // the upper triangle of the trailing block is up to date
+    static const bool lower_updates = !env_flag("HFMI_EIG_FULL_UPDATE");     // A/B: every rank-2k update over the full block
+    auto make_upper_valid = [&](int t0) {
+      if (upper_valid) return;
+      const int nt = (n - t0 + 31) / 32;
+      hipLaunchKernelGGL(k_mirror_lower, dim3(nt, nt), dim3(256), 0, st, A, ld, n, t0);
+      upper_valid = true;
+    };
     for (int p0 = 0; p0 < n - 2; p0 += NB) {
+      if (n - p0 <= unb_max) {
+        j_unb = p0;
+        make_upper_valid(p0);
+        break;
+      }
       const int ncols = std::min(NB, n - 2 - p0);
       ta.p0 = p0;
       for (int jj = 0; jj < ncols; ++jj) {
@@ -1256,9 +1684,35 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       g.lda = g.ldb = ld;
       g.C = A + (size_t)t0 * ld + t0;
       g.ldc = ld;
+      // every column of the NEXT panel takes the lower-triangle products (and there is a next panel): the tiles above the diagonal are
+      // not read again until the full-column / unblocked columns begin -- they are skipped and mirrored back once, there
+      const bool next_all_lower = n - (t0 + NB - 1) - 1 >= sym_min && n - t0 > unb_max;
+      g.lower = (lower_updates && (next_all_lower || !upper_valid)) ? 1 + (t0 & 127) : 0;
       HFMI_TRY(launch_dgemm(ctx, g));
+      if (g.lower) upper_valid = false;
+      if (!next_all_lower) make_upper_valid(t0);
     }
-    hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(64), 0, st, A, ld, n, dvec, evec);
+    make_upper_valid(0);
+    if (j_unb < 0) {
+      hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(64), 0, st, A, ld, n, dvec, evec);
+    } else {
+      // the matrix is fully updated at a panel boundary: nothing is pending at column j_unb.  Steps j_unb .. n - 1: step j applies
+      // reflector j - 1 and forms reflector j; the last two steps only collect d and e of the final 2 x 2 block.
+      double* yb[2] = {ybuf, colbuf};      // y of the last step / of this step (the panel kernels' colbuf is free here)
+      for (int j = j_unb; j < n; ++j) {
+        ta.j = j;
+        const int rs0 = j & ~63, L = (int)ld - rs0, nA = n - j - 1;
+        const int g = std::max(1, std::min(512, (nA + 7) / 8));
+        const size_t lds = (size_t)3 * L * sizeof(double);
+        const int has_prev = j > j_unb ? 1 : 0;
+        const double* yp = yb[(j - j_unb) & 1];
+        double* yn = yb[(j - j_unb + 1) & 1];
+        if (L <= 512) hipLaunchKernelGGL(k_tri_u<4>, dim3(g), dim3(512), lds, st, ta, yp, yn, has_prev);
+        else if (L <= 1024) hipLaunchKernelGGL(k_tri_u<8>, dim3(g), dim3(512), lds, st, ta, yp, yn, has_prev);
+        else if (L <= 2048) hipLaunchKernelGGL(k_tri_u<16>, dim3(g), dim3(512), lds, st, ta, yp, yn, has_prev);
+        else hipLaunchKernelGGL(k_tri_u<20>, dim3(g), dim3(512), lds, st, ta, yp, yn, has_prev);
+      }
+    }
     HIP_TRY(hipGetLastError());
   }
   clk.mark(1);
@@ -1445,8 +1899,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     gy.sB = sWY;
     HFMI_TRY(launch_dgemm(ctx, gy));
     for (int bi = nblk - 1; bi >= 0; --bi) {
-      const int p0 = bi * EB_WY, r0 = p0 + 1;
-      if (r0 >= n || p0 >= n - 2) continue;
+      // rows from p0 on: row p0 of the block's reflectors (and of Y = V T) is zero -- column p0 + c starts at row p0 + c + 1 --
+      // so the products are the same as from p0 + 1, and every operand keeps its 16-byte alignment
+      const int p0 = bi * EB_WY, r0 = p0;
+      if (p0 >= n - 2) continue;
       gemm_desc g1;              // W1 = V^T Z   (rows r0 ..)
       g1.ta = true;
       g1.tb = false;
@@ -1481,12 +1937,11 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     double* out = Qnext;
     hipLaunchKernelGGL(k_out, dim3((n + 31) / 32, (nv + 31) / 32), dim3(256), 0, st, Z, ld, n, nv, out);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host_V, out, (size_t)n * nv * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HFMI_TRY(xfer_d2h(ctx, host_V, out, (size_t)n * nv * sizeof(double)));
     clk.mark(5);
   }
   if (clk.on)
-    fprintf(stderr, "[hfmi eig n=%d] ms: load %.3f | tridiagonalisation %.3f | leaves %.3f | merges %.3f | back-transformation %.3f | output %.3f\n",
-            n, clk.ms[0], clk.ms[1], clk.ms[2], clk.ms[3], clk.ms[4], clk.ms[5]);
+    fprintf(stderr, "[hfmi eig n=%d] ms: workspace + fills %.3f | upload %.3f | load %.3f | tridiagonalisation %.3f | leaves %.3f | merges %.3f | back-transformation %.3f | output %.3f\n",
+            n, clk.ms[6], clk.ms[7], clk.ms[0], clk.ms[1], clk.ms[2], clk.ms[3], clk.ms[4], clk.ms[5]);
   return HFMI_OK;
 }

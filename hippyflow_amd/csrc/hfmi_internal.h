@@ -67,6 +67,7 @@ struct hfmi_status_words {  // device-resident, read back by the host after smal
 };
 
 struct hfmi_comm;
+struct xfer_state;
 struct hfmi_ctx {
   int device;
   hipStream_t stream;
@@ -120,7 +121,12 @@ struct hfmi_ctx {
   void* pinned_cb;
   size_t pinned_cb_bytes;
   hipEvent_t ev_cb[4];            // D2H done x2, H2D done x2
+  xfer_state* xfer;               // pinned ring + host threads of the large host <-> device transfers (hfmi_xfer.hip), lazily created
 };
+// large transfers between the caller's pageable arrays and device memory, pipelined through pinned chunks (hfmi_xfer.hip)
+int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes);   // returns when the host array is complete
+int xfer_h2d(hfmi_ctx* ctx, void* dev, const void* host, size_t bytes);   // returns when the host array has been read
+void xfer_destroy(hfmi_ctx* ctx);
 int phase_begin(hfmi_ctx* ctx, int phase);     // returns a record index or -1 when not profiling
 void phase_end(hfmi_ctx* ctx, int idx);
 int prof_start(hfmi_ctx* ctx, int kind, int64_t m, int64_t k, int64_t N);  // returns record index or -1
@@ -292,6 +298,9 @@ constexpr int HFMI_EIG_MAXN = 8192;      // largest symmetric eigenproblem (hfmi
 int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, double* host_d, double* host_V, int nvec = -1,
                   const double* dev_T = nullptr);
 
+int eig_dgemm_bench(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, int reps, const double* host_A, const double* host_B,
+                    double* host_C, double* avg_ms);
 // micro-benchmarks
 int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs);
 int launch_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_tflops, double* copy_gbs);
+int launch_bench_random_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* mfma_tflops_streaming, double* copy_gbs);

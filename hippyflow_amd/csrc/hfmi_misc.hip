@@ -724,6 +724,32 @@ int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, d
   return HFMI_OK;
 }
 
+// The same loop on FULL-MANTISSA operands: every lane holds eight Gaussian values per operand, and each MFMA of an iteration takes
+// another pair of them (the register pairs rotate through the eight accumulators), so operand and accumulator bits toggle like
+// those of the solve's contractions on Gaussian data.  The constant-operand loop above multiplies 1 +- tid 1e-9: almost no
+// toggling, a clock (2.35-2.40 GHz) that random data does not see under the power limit (MI355X_MICROARCH.md, "DVFS give-back").
+__global__ __launch_bounds__(256, 2) void k_bench_mfma_rand(const double* __restrict__ vals, double* out, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double a[8], b[8];
+  const double* src = vals + ((size_t)blockIdx.x % 64) * 4096 + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = src[256 * i];
+    b[i] = src[256 * (8 + i)];
+  }
+  for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(i + r) & 7], b[(i + 3 * r) & 7], acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;
+}
 __global__ void k_bench_copy_loop(const d2* __restrict__ src, d2* __restrict__ dst, int64_t n, int reps) {
   for (int rep = 0; rep < reps; ++rep)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -765,5 +791,49 @@ int launch_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_tflops, double* copy_gb
   (void)hipEventDestroy(c1);
   *mfma_tflops = (double)reps * g1 * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
   *copy_gbs = (double)copies * (double)bytes / (msc * 1e-3) / 1e9;   // over the whole copy window (part of it runs alone)
+  return HFMI_OK;
+}
+
+// fp64 MFMA rate on Gaussian operands: alone, and with the copy kernel streaming HBM beside it (the regime of the solve's big
+// contractions) -- the denominators bench.py reports as roofline.frac_of_in_job_random_operand_peak[_while_streaming]
+int launch_bench_random_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* mfma_tflops_streaming, double* copy_gbs) {
+  void* buf = nullptr;
+  const size_t bytes = (size_t)2 << 30;
+  const size_t nvals = (size_t)64 * 4096;
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, bytes + 4096 + nvals * sizeof(double), &buf));
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int64_t n = (int64_t)(bytes / 2 / sizeof(d2));
+  d2* src = (d2*)buf;
+  d2* dst = src + n;
+  double* out = (double*)(dst + n);
+  double* vals = out + 512;
+  HFMI_TRY(launch_randn(ctx, vals, (int64_t)nvals, 1, (int64_t)nvals, 0x5eedULL, 7u, 1.0));
+  const int it1 = 2000, g1 = cus * 16, copies = 24, reps = 3;
+  float ms = 0.f, msc = 0.f;
+  hipLaunchKernelGGL(k_bench_mfma_rand, dim3(g1), dim3(256), 0, ctx->stream, vals, out, 104);
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int rep = 0; rep < reps; ++rep) hipLaunchKernelGGL(k_bench_mfma_rand, dim3(g1), dim3(256), 0, ctx->stream, vals, out, it1);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *mfma_tflops = (double)reps * g1 * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+  hipEvent_t c0, c1;
+  HIP_TRY(hipEventCreate(&c0));
+  HIP_TRY(hipEventCreate(&c1));
+  HIP_TRY(hipEventRecord(c0, ctx->aux_stream));
+  hipLaunchKernelGGL(k_bench_copy_loop, dim3(cus * 4), dim3(256), 0, ctx->aux_stream, src, dst, n, copies);
+  HIP_TRY(hipEventRecord(c1, ctx->aux_stream));
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int rep = 0; rep < reps; ++rep) hipLaunchKernelGGL(k_bench_mfma_rand, dim3(g1), dim3(256), 0, ctx->stream, vals, out, it1);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventSynchronize(c1));
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&msc, c0, c1));
+  (void)hipEventDestroy(c0);
+  (void)hipEventDestroy(c1);
+  *mfma_tflops_streaming = (double)reps * g1 * 4 * it1 * 8 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+  *copy_gbs = (double)copies * (double)bytes / (msc * 1e-3) / 1e9;
   return HFMI_OK;
 }

@@ -1,0 +1,223 @@
+// Large host <-> device transfers of the C ABI's host-in / host-out calls (the n x n matrix of hfmi_sym_eig_small and its n x n
+// eigenvector matrix: 512 MB each way at n = 8192; PODProjector.py:812-833 hands numpy arrays over and takes numpy arrays back).
+//
+// The caller's arrays are pageable.  hipMemcpyAsync on pageable memory goes through the runtime's own staging / page-locking
+// path: measured (profiles/r05_eig_large.txt) 16-17 GB/s device -> host at every size, and 24-78 ms stalls on one call in four
+// in the phase that uploads the matrix.  Here the transfer is pipelined through a ring of pinned chunks owned by the context:
+//   device -> host: copy engine fills chunk c + 1 ... c + 3 while a few host threads move chunk c out of the ring into the caller's
+//                   array (the first touch of a fresh numpy array's pages is spread over those threads as well);
+//   host -> device: the threads fill chunk c + 1 ... while chunk c travels (not the default: see xfer_h2d).
+// Both are stream-ordered on the context's stream like the copies they replace.  xfer_d2h returns when the host array is
+// complete; xfer_h2d returns when the host array has been read and every chunk has left the ring.
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "hfmi_internal.h"
+
+namespace {
+constexpr size_t XF_CHUNK = (size_t)4 << 20;
+constexpr int XF_NBUF = 4;
+constexpr size_t XF_DIRECT = 2 * XF_CHUNK;      // below this the plain copy is as good
+
+struct pool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::function<void(int)> job;
+  uint64_t generation = 0;
+  int pending = 0;
+  bool stop = false;
+  void start(int n) {
+    for (int t = 0; t < n; ++t)
+      threads.emplace_back([this, t] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(int)> fn;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_job.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            fn = job;
+          }
+          fn(t);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+          }
+        }
+      });
+  }
+  void launch(const std::function<void(int)>& fn) {
+    std::lock_guard<std::mutex> lk(mu);
+    job = fn;
+    pending = (int)threads.size();
+    ++generation;
+    cv_job.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (auto& th : threads) th.join();
+  }
+};
+}  // namespace
+
+struct xfer_state {
+  char* pin = nullptr;
+  hipEvent_t ev[XF_NBUF];
+  bool have_events = false;
+  pool workers;
+  int nthreads = 0;
+};
+
+static int xfer_get(hfmi_ctx* ctx, xfer_state** out) {
+  if (!ctx->xfer) {
+    xfer_state* s = new (std::nothrow) xfer_state();
+    if (!s) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
+    ctx->xfer = s;
+    HIP_TRY(hipHostMalloc((void**)&s->pin, XF_NBUF * XF_CHUNK, hipHostMallocDefault));
+    for (int i = 0; i < XF_NBUF; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming));
+    s->have_events = true;
+    const char* e = getenv("HFMI_XFER_THREADS");
+    int nt = e ? atoi(e) : 0;
+    if (nt <= 0) nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));     // (first-touch page faults of a fresh output array scale with the threads)
+    s->nthreads = std::min(nt, 32);
+    s->workers.start(s->nthreads);
+  }
+  *out = ctx->xfer;
+  return HFMI_OK;
+}
+void xfer_destroy(hfmi_ctx* ctx) {
+  xfer_state* s = ctx->xfer;
+  if (!s) return;
+  if (s->have_events)
+    for (int i = 0; i < XF_NBUF; ++i) (void)hipEventDestroy(s->ev[i]);
+  if (s->pin) (void)hipHostFree(s->pin);
+  delete s;
+  ctx->xfer = nullptr;
+}
+
+// this thread's share [lo, hi) of a chunk of `len` bytes, in whole 4 KB pages except at the end
+static inline void slice_of(size_t len, int t, int T, size_t& lo, size_t& hi) {
+  const size_t pages = (len + 4095) / 4096, per = (pages + T - 1) / T;
+  lo = std::min(len, (size_t)t * per * 4096);
+  hi = std::min(len, (size_t)(t + 1) * per * 4096);
+}
+
+int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  static const bool plain = env_flag("HFMI_XFER_PLAIN");       // A/B: the runtime's pageable path
+  hipStream_t st = ctx->stream;
+  if (bytes < XF_DIRECT || plain) {
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HFMI_OK;
+  }
+  xfer_state* s = nullptr;
+  HFMI_TRY(xfer_get(ctx, &s));
+  const int nch = (int)((bytes + XF_CHUNK - 1) / XF_CHUNK), T = s->nthreads;
+  std::atomic<int> ready{0};
+  std::atomic<bool> abort_flag{false};
+  std::vector<std::atomic<int>> done(nch);
+  for (auto& d : done) d.store(0, std::memory_order_relaxed);
+  auto chunk_len = [&](int c) { return std::min(XF_CHUNK, bytes - (size_t)c * XF_CHUNK); };
+  s->workers.launch([&, T](int t) {
+    for (int c = 0; c < nch; ++c) {
+      while (ready.load(std::memory_order_acquire) <= c) {
+        if (abort_flag.load(std::memory_order_relaxed)) return;
+        std::this_thread::yield();
+      }
+      size_t lo, hi;
+      slice_of(chunk_len(c), t, T, lo, hi);
+      if (hi > lo) memcpy((char*)host + (size_t)c * XF_CHUNK + lo, s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK + lo, hi - lo);
+      done[c].fetch_add(1, std::memory_order_release);
+    }
+  });
+  hipError_t err = hipSuccess;
+  auto issue = [&](int c) {
+    err = hipMemcpyAsync(s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK, (const char*)dev + (size_t)c * XF_CHUNK, chunk_len(c), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipEventRecord(s->ev[c % XF_NBUF], st);
+  };
+  for (int c = 0; c < std::min(nch, XF_NBUF) && err == hipSuccess; ++c) issue(c);
+  for (int c = 0; c < nch && err == hipSuccess; ++c) {
+    err = hipEventSynchronize(s->ev[c % XF_NBUF]);
+    if (err != hipSuccess) break;
+    ready.store(c + 1, std::memory_order_release);
+    if (c + XF_NBUF < nch) {
+      while (done[c].load(std::memory_order_acquire) < T) std::this_thread::yield();       // the ring slot is free again
+      issue(c + XF_NBUF);
+    }
+  }
+  if (err != hipSuccess) abort_flag.store(true);
+  s->workers.wait();
+  if (err != hipSuccess) {
+    (void)hipStreamSynchronize(st);
+    hfmi_set_error("device -> host transfer of %zu bytes failed: %s", bytes, hipGetErrorString(err));
+    return HFMI_ERR_HIP;
+  }
+  return HFMI_OK;
+}
+
+int xfer_h2d(hfmi_ctx* ctx, void* dev, const void* host, size_t bytes) {
+  // Upload: the runtime's own pageable path is the faster one here (it pins the caller's pages and lets the copy engine read them:
+  // 49 GB/s at 512 MB against 34 GB/s through the ring, whose threads have to read AND write every byte first: profiles/r06a), so
+  // the ring is the A/B partner (HFMI_XFER_H2D_RING=1), not the default.
+  static const bool plain = !env_flag("HFMI_XFER_H2D_RING") || env_flag("HFMI_XFER_PLAIN");
+  hipStream_t st = ctx->stream;
+  if (bytes < XF_DIRECT || plain) {
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    return HFMI_OK;      // (pageable source: the call returns once the runtime has staged it)
+  }
+  xfer_state* s = nullptr;
+  HFMI_TRY(xfer_get(ctx, &s));
+  const int nch = (int)((bytes + XF_CHUNK - 1) / XF_CHUNK), T = s->nthreads;
+  std::atomic<int> freed{0};          // chunks whose copy has left the ring
+  std::atomic<bool> abort_flag{false};
+  std::vector<std::atomic<int>> filled(nch);
+  for (auto& d : filled) d.store(0, std::memory_order_relaxed);
+  auto chunk_len = [&](int c) { return std::min(XF_CHUNK, bytes - (size_t)c * XF_CHUNK); };
+  s->workers.launch([&, T](int t) {
+    for (int c = 0; c < nch; ++c) {
+      while (c >= freed.load(std::memory_order_acquire) + XF_NBUF) {
+        if (abort_flag.load(std::memory_order_relaxed)) return;
+        std::this_thread::yield();
+      }
+      size_t lo, hi;
+      slice_of(chunk_len(c), t, T, lo, hi);
+      if (hi > lo) memcpy(s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK + lo, (const char*)host + (size_t)c * XF_CHUNK + lo, hi - lo);
+      filled[c].fetch_add(1, std::memory_order_release);
+    }
+  });
+  hipError_t err = hipSuccess;
+  for (int c = 0; c < nch && err == hipSuccess; ++c) {
+    while (filled[c].load(std::memory_order_acquire) < T) std::this_thread::yield();
+    err = hipMemcpyAsync((char*)dev + (size_t)c * XF_CHUNK, s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK, chunk_len(c), hipMemcpyHostToDevice, st);
+    if (err == hipSuccess) err = hipEventRecord(s->ev[c % XF_NBUF], st);
+    if (err == hipSuccess && c + 1 >= XF_NBUF - 1) {
+      // keep XF_NBUF - 1 copies in flight: the oldest of them must have left its slot before the threads refill it
+      const int oldest = c + 1 - (XF_NBUF - 1);
+      err = hipEventSynchronize(s->ev[oldest % XF_NBUF]);
+      freed.store(oldest + 1, std::memory_order_release);
+    }
+  }
+  if (err != hipSuccess) abort_flag.store(true);
+  s->workers.wait();
+  if (err == hipSuccess) err = hipStreamSynchronize(st);      // the ring is idle when the call returns
+  if (err != hipSuccess) {
+    hfmi_set_error("host -> device transfer of %zu bytes failed: %s", bytes, hipGetErrorString(err));
+    return HFMI_ERR_HIP;
+  }
+  return HFMI_OK;
+}

@@ -289,11 +289,13 @@ class DataGenerator:
                                         output_decoder=output_decoder, output_encoder=output_encoder)
         sinks = self._make_sinks(plan, data_dir)
         allowed_failures = 10 * n_samples + 100        # upstream tries for ever
+        queued = sinks.get('Jz')
 
         def points(first, count, materialise):
             index = first
             while index < first + count:
                 written = []
+                held = len(queued._held) if queued is not None else 0
                 try:
                     self.parRandom.normal(1, self.noise)
                     self.m.zero()
@@ -313,6 +315,8 @@ class DataGenerator:
                         np.save(written[-1], values)
                 except Exception as exc:                # noqa: BLE001 -- "issue perhaps with the forward solve, moving on"
                     self.exceptions_count += 1
+                    if queued is not None:              # a save that fails AFTER materialise() returned: its queued control
+                        del queued._held[held:]         # Jacobian belongs to the attempt that is being thrown away
                     for path in written:                # never leave m / q files of an index whose sample is drawn again
                         if os.path.exists(path):
                             os.remove(path)

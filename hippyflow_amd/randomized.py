@@ -45,7 +45,7 @@ class _ParRandom:
         self.rank = L.launcher_rank() if rank is None else int(rank)
         self.stream = 0
         self.shared_stream = 0
-        self._keyed_by_collective = False
+        self._keyed = False
 
     def reseed(self, seed, stream=0):
         self.seed, self.stream, self.shared_stream = int(seed), int(stream), int(stream)
@@ -56,10 +56,10 @@ class _ParRandom:
         the reference, where hp.parRandom is seeded per MPI rank); collectives built later -- e.g. over a sub-group in which
         several processes hold the same group rank -- leave the key alone: re-keying there would collapse private streams
         onto one key and change the draws in the middle of a run."""
-        if by_collective and self._keyed_by_collective:
+        if by_collective and self._keyed:
             return
         self.rank = int(rank)
-        self._keyed_by_collective = bool(by_collective)
+        self._keyed = True          # an explicit split is final too: a collective constructed afterwards must not override it
 
     def key(self, shared):
         return (self.seed & 0xFFFFFFFF) | ((0 if shared else (self.rank + 1) & 0xFFFFFFFF) << 32)

@@ -293,11 +293,20 @@ int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* 
 int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, int reps, double* host_C,
                          double* avg_ms);
 int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms);
+/* the general fp64 MFMA product inside the whole-GPU eigensolver (trailing rank-2k updates, Q S of the merges, block reflectors of
+ * the back-transformation; la.eigh(G), PODProjector.py:812-833): C (M x N) = op(A) op(B), column-major host operands with their
+ * natural leading dimensions, average kernel time of `reps` launches; host_C may be null */
+int hfmi_bench_dgemm(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, int reps, const double* host_A, const double* host_B,
+                     double* host_C, double* avg_ms);
 /* fp64 MFMA / fp64 FMA / HBM-copy micro-benchmarks (peak denominators measured in the same job) */
 int hfmi_bench_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbs);
 /* the same MFMA loop with a copy kernel streaming HBM beside it on a second stream: the ceiling of the power-limited regime the
  * big contractions run in (bench.py: roofline.frac_of_in_job_loaded_peak) */
 int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbs);
+/* the MFMA loop on full-mantissa Gaussian operands rotated through the registers every iteration -- alone, and beside the streaming
+ * copy: the ceiling the contractions can reach on the solve's data under the power limit (SURVEY section 8d "fp64 MFMA
+ * micro-benchmark run in the same job"; bench.py: roofline.frac_of_in_job_random_operand_peak[_while_streaming]) */
+int hfmi_bench_random_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* mfma_f64_tflops_while_streaming, double* hbm_copy_gbs);
 /* per-launch HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from the
  * timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by events on
  * the context's stream.  end() synchronises and returns one record per distinct (kernel, shape):

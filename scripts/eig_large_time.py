@@ -1,6 +1,7 @@
 """Wall time of hfmi_sym_eig_small beyond one workgroup (256 < n <= 8192: hfmi_eig_blocked.hip) next to numpy.linalg.eigh on
 the box's host, with the phase split the library prints under HFMI_EIG_LARGE_TIMING=1 (stderr).  Usage:
-python scripts/eig_large_time.py [n ...] [--no-host] [--low-rank]; per-kernel times come from the rocprofv3 kernel trace of this script."""
+python scripts/eig_large_time.py [n ...] [--no-host] [--low-rank] [--reps=N]; per-kernel times come from the rocprofv3 kernel trace
+of this script.  --reps=N: N back-to-back timed calls per size (default 3); the line reports min, median and max and the max/min ratio."""
 import sys
 import time
 
@@ -12,6 +13,7 @@ import hippyflow_amd as hf  # noqa: E402
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 1024, 2048, 4096]
 host = "--no-host" not in sys.argv
 rng = np.random.default_rng(0)
+reps = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--reps=")] or [3])
 lowrank = "--low-rank" in sys.argv          # Gram matrix of n snapshots that span n / 8 dimensions: most poles deflate in the merges
 for n in sizes:
     if lowrank:
@@ -21,11 +23,12 @@ for n in sizes:
     G = X @ X.T
     d, V = hf.sym_eig_small(G)                  # warm-up: workspace allocation
     ts = []
-    for _ in range(3):
+    for _ in range(reps):
         t0 = time.perf_counter()
         d, V = hf.sym_eig_small(G)
         ts.append(time.perf_counter() - t0)
-    line = ("low-rank " if lowrank else "") + "n=%d  sym_eig_small %.2f ms (min of 3; %.2f max)" % (n, 1e3 * min(ts), 1e3 * max(ts))
+    line = ("low-rank " if lowrank else "") + "n=%d  sym_eig_small %.2f ms (min of %d; median %.2f, max %.2f, max/min %.3f)" % (
+        n, 1e3 * min(ts), reps, 1e3 * float(np.median(ts)), 1e3 * max(ts), max(ts) / min(ts))
     if host:
         t0 = time.perf_counter()
         w, _ = np.linalg.eigh(G)

@@ -26,10 +26,46 @@ def reflector_scalars(alpha0, xn2):
     return beta, tau, scl
 
 
-def tridiagonalize_blocked(T, nb=64):
+def unblocked_tail(A, j0, d, e, Vh, tau):
+    """Twin of k_tri_u (one launch per column): from column j0 on -- where A is fully updated -- LAPACK's unblocked recurrence
+    with the rank-2 update of reflector j - 1 DELAYED into step j: every step first turns y = A v of the last step into
+    w = tau y + alpha v (alpha = -tau^2/2 v.y), forms column j of the reduced matrix from the not-yet-updated one, builds
+    reflector j from it, and then, column by column of the full symmetric trailing block, applies the pending update and takes
+    the product with the new v.  The last two steps only collect d and e of the final 2 x 2 block (tau = 0 there)."""
+    n = A.shape[0]
+    y = v = None
+    for j in range(j0, n):
+        if j > j0:
+            t = tau[j - 1]
+            alpha = -0.5 * t * t * float(v[j:] @ y[j:])
+            w = np.zeros(n)
+            w[j:] = t * y[j:] + alpha * v[j:]
+            c = A[j:, j] - v[j:] * w[j] - w[j:] * v[j]          # v[j] = 1
+        else:
+            w = None
+            c = A[j:, j].copy()
+        d[j] = c[0]
+        vn = np.zeros(n)
+        if j + 1 < n:
+            beta, tj, scl = reflector_scalars(c[1], float(c[2:] @ c[2:]))
+            vn[j + 1] = 1.0
+            vn[j + 2:] = c[2:] * scl
+            e[j] = beta
+            tau[j] = tj
+            Vh[:, j] = vn
+        yn = np.zeros(n)
+        for q in range(j + 1, n):                               # a wave per column
+            if w is not None:
+                A[j + 1:, q] -= v[j + 1:] * w[q] + w[j + 1:] * v[q]
+            yn[q] = float(A[j + 1:, q] @ vn[j + 1:])
+        y, v = yn, vn
+
+
+def tridiagonalize_blocked(T, nb=64, unb_max=0):
     """Symmetric T -> (d, e, Vh, tau): the same factorisation as dc_eig_twin.tridiagonalize, computed panel by panel.
     Inside a panel the trailing block is NOT updated (dlatrd): column j is corrected with the panel's V and W, the
-    product with the trailing block is corrected likewise; one symmetric rank-2nb update per panel."""
+    product with the trailing block is corrected likewise; one symmetric rank-2nb update per panel.  Once the trailing block
+    has at most ``unb_max`` rows at a panel boundary the rest is left to unblocked_tail (one launch per column)."""
     A = np.array(T, dtype=np.float64)
     A = 0.5 * (A + A.T)
     n = A.shape[0]
@@ -39,6 +75,9 @@ def tridiagonalize_blocked(T, nb=64):
     e = np.zeros(max(n - 1, 0))
     p0 = 0
     while p0 < n - 2:
+        if n - p0 <= unb_max:
+            unblocked_tail(A, p0, d, e, Vh, tau)
+            return d, e, Vh, tau
         ncols = min(nb, n - 2 - p0)
         W = np.zeros((n, ncols))
         V = Vh[:, p0:p0 + ncols]                                  # a window: columns fill in as the panel advances

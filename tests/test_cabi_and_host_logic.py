@@ -190,3 +190,9 @@ def test_rank_and_device_follow_the_mpi_launchers_too(monkeypatch):
     k3 = g.key(False)
     g.split(1)                                                # an explicit split always applies
     assert g.rank == 1 and g.key(False) != k3 and g.key(True) == _ParRandom(rank=7).key(True)
+    g.split(6, by_collective=True)                            # ... and is final: a collective constructed later leaves it alone
+    assert g.rank == 1
+    h = _ParRandom(rank=0)
+    h.split(4)                                                # explicit first, collective second: the explicit key stays
+    h.split(2, by_collective=True)
+    assert h.rank == 4

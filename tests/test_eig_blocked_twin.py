@@ -48,6 +48,26 @@ def test_blocked_tridiagonalisation_is_the_unblocked_factorisation():
     assert np.abs(bt.back_transform_blocked(Vh, tau, Z, 16) - dct.back_transform(V0, tau0, Z)).max() < 1e-11
 
 
+@pytest.mark.parametrize("n,nb,unb", [(70, 16, 70), (70, 16, 30), (131, 32, 64), (90, 8, 1)])
+def test_unblocked_tail_with_the_delayed_update_is_the_same_factorisation(n, nb, unb):
+    """k_tri_u's recurrence (tests/helpers/eig_blocked_twin.py unblocked_tail): alone (unb >= n), behind some panels, and for a
+    tail of one panel's worth: d, e, reflectors and tau of LAPACK's factorisation, for every kind of matrix of the list above."""
+    rng = np.random.default_rng(n + unb)
+    for name, S in _cases(n, rng):
+        d, e, Vh, tau = bt.tridiagonalize_blocked(S, nb, unb_max=unb)
+        d0, e0, V0, tau0 = dct.tridiagonalize(S)
+        scale = max(np.abs(S).max(), 1e-300)
+        # the reflectors of a (numerically) rank-deficient matrix are not unique: compare what they produce
+        Q = dct.back_transform(Vh, tau, np.eye(n))
+        Tm = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-12 * n, name
+        assert np.abs(Q @ Tm @ Q.T - 0.5 * (S + S.T)).max() < 1e-12 * n * scale, name
+        if name == "indefinite":
+            # (step n - 2 leaves the unit vector e_{n-1} with tau = 0 in column n - 2 of the reflector matrix: the identity)
+            assert np.abs(d - d0).max() < 1e-10 and np.abs(e - e0).max() < 1e-10 and np.abs(tau - tau0).max() < 1e-10
+            assert np.abs(Vh[:, :n - 2] - V0[:, :n - 2]).max() < 1e-10 and tau[n - 2] == 0.0
+
+
 @pytest.mark.parametrize("n,j", [(500, 0), (500, 126), (500, 127), (513, 200), (700, 383), (640, 511)])
 def test_lower_triangle_products_cover_every_row_once_per_slot(n, j):
     """The tile / slot scheme of k_tri_bs + k_tri_a<true>: half the matrix is read, every row finds one partial value in each of its nb

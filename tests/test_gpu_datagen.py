@@ -145,6 +145,34 @@ def test_generate_for_a_control_problem(ctx, tmp_path):
         assert rel(fz["JzstarPhi_data"][i], Jzd.T @ Phi) < 1e-10 and rel(f["JstarPhi_data"][i], Jd.T @ Phi) < 1e-10
 
 
+def test_generate_for_a_control_problem_survives_a_failing_save(ctx, tmp_path, monkeypatch):
+    """An m / q / z save that raises AFTER the derivative work of the sample was queued: the sample is drawn again and the queued
+    control Jacobian of the discarded attempt must not stay behind (one matrix per stored sample, rows aligned with their index)."""
+    n, q, dz, nd = 40, 6, 4, 4
+    out = str(tmp_path) + "/"
+    obs, prior, settings = make(n, q, dz)
+    settings['rM'], settings['rZ'], settings['oversample'] = 3, 2, 10
+    gen = hf.DataGenerator(obs, prior, control_distribution=fp.ControlDistribution(dz), settings=settings)
+    real_save, fired = np.save, []
+
+    def flaky_save(path, values, *a, **k):
+        if str(path).endswith("q_sample_1.npy") and not fired:
+            fired.append(path)
+            raise OSError("disk full (injected)")
+        return real_save(path, values, *a, **k)
+
+    monkeypatch.setattr(np, "save", flaky_save)
+    Phi = np.linalg.qr(np.random.default_rng(3).standard_normal((q, 2)))[0]
+    gen.generate(nd, derivatives=(1, 1), output_decoder=Phi, data_dir=out, clean_up=True)
+    monkeypatch.undo()
+    assert fired and gen.exceptions_count == 1
+    fz, f, mzq = np.load(out + "JzstarPhi_data.npz"), np.load(out + "JstarPhi_data.npz"), np.load(out + "mzq_data.npz")
+    assert fz["JzstarPhi_data"].shape[0] == nd and mzq["m_data"].shape[0] == nd
+    for i, qi, Jd, Jzd in jacobians_at(obs, mzq["m_data"], mzq["z_data"]):
+        np.testing.assert_allclose(mzq["q_data"][i], qi, rtol=1e-12)
+        assert rel(fz["JzstarPhi_data"][i], Jzd.T @ Phi) < 1e-10 and rel(f["JstarPhi_data"][i], Jd.T @ Phi) < 1e-10
+
+
 def test_two_step_generate_for_a_full_state_problem(ctx, tmp_path):
     """States first, their POD (in the mass inner product), then J^T (M phi) at the stored samples (dataGenerator.py:251-356)."""
     n, nd, r = 40, 8, 4

@@ -308,7 +308,7 @@ def _knob_child(n, extra, out):
     return np.load(out)
 
 
-@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"},
+@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"}, {"HFMI_EIG_UNB_MAX": "0"}, {"HFMI_EIG_UNB_MAX": "700"}, {"HFMI_XFER_PLAIN": "1"}, {"HFMI_EIG_GEMM": "0"},
                                  {"HFMI_EIG_LARGE": "jacobi"}])
 def test_sym_eig_blocked_ab_knobs_give_the_same_spectrum(ctx, tmp_path, env):
     """The A/B switches of the whole-GPU solver (read once per process, hence a child interpreter each): full-column products only
@@ -319,3 +319,18 @@ def test_sym_eig_blocked_ab_knobs_give_the_same_spectrum(ctx, tmp_path, env):
         _KNOB_DEFAULT[n] = _knob_child(n, {}, tmp_path / "default.npy")
     d = _knob_child(n, env, tmp_path / "knob.npy")
     assert np.abs(d - _KNOB_DEFAULT[n]).max() <= 1e-12 * d[0]
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(1536, 2048, 200), (1111, 1793, 77), (256, 8192, 1030), (2050, 2050, 128), (300, 200, 64)])
+def test_dgemm_of_the_eigensolver_matches_numpy(ctx, ta, tb, M, N, K):
+    """The general fp64 MFMA product behind the trailing updates, the merges and the block reflectors (software-pipelined 128 x 128 /
+    64 x 128 tiles where they fill the chip, the 64 x 64 kernel otherwise; odd sizes take the 8-byte load path and the edge guards)
+    against numpy, to a few ulps of the accumulated magnitude."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K + ta + 2 * tb)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    Cm, ms = ctx.bench_dgemm(A, B, ta=ta, tb=tb, reps=1)
+    ref = (A.T if ta else A) @ (B.T if tb else B)
+    assert np.abs(Cm - ref).max() <= 1e-13 * K * max(1.0, np.abs(ref).max())
+
