@@ -379,10 +379,16 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
             "thread_settings": thread_count, "best_setting": best_label,
             "sample": "blas3 leg at %s = %d BLAS threads (the best of %s): %s" % (best_label, thread_count[best_label], ", ".join(thread_count), notes["blas3"]),
             "seconds_full_estimate": best["seconds_full_estimate"],
-            "reference_style": dict(legs["reference_style"], sample=notes["reference_style"], best_setting=best_ref_label,
-                                    value=max(legs["reference_style"][best_ref_label]["value"], N * r / t_comp / 1e9),
-                                    seconds_full_estimate=min(legs["reference_style"][best_ref_label]["seconds_full_estimate"], t_comp),
-                                    best_per_component_seconds=comp, best_per_component_estimate=t_comp),
+            # the reference-style leg: one entry per thread setting (each a run that a user can reproduce), the best of those, and --
+            # named for what it is -- a COMPOSITE no single run achieves: every component at the thread setting that suits it
+            "reference_style": dict(legs["reference_style"], sample=notes["reference_style"], best_single_setting=best_ref_label,
+                                    best_single_setting_value=legs["reference_style"][best_ref_label]["value"],
+                                    best_single_setting_seconds_full_estimate=legs["reference_style"][best_ref_label]["seconds_full_estimate"],
+                                    composite_of_per_component_best_settings={
+                                        "value": max(legs["reference_style"][best_ref_label]["value"], N * r / t_comp / 1e9),
+                                        "seconds_full_estimate": min(legs["reference_style"][best_ref_label]["seconds_full_estimate"], t_comp),
+                                        "per_component_seconds": comp,
+                                        "note": "MGS / small products at their best thread count, mat-vecs at theirs: not one run"}),
             "blas3": dict(legs["blas3"], sample=notes["blas3"])}
 
 
@@ -615,7 +621,10 @@ def _compact(line):
     if cb:
         out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "kind", "cores", "threads", "physical_cores", "sockets",
                                                        "best_setting", "seconds_full_estimate", "sample")}
-        out["cpu_baseline"]["reference_style_value"] = (cb.get("reference_style") or {}).get("value")
+        rs = cb.get("reference_style") or {}
+        out["cpu_baseline"]["reference_style_best_single_setting_value"] = rs.get("best_single_setting_value")
+        out["cpu_baseline"]["reference_style_composite_of_per_component_best_settings_value"] = (
+            rs.get("composite_of_per_component_best_settings") or {}).get("value")
     comm = line.get("communicator") or {}
     if comm.get("ranks"):
         out["communicator"] = comm

@@ -156,6 +156,11 @@ def load():
         fn.argtypes = argtypes
         fn.restype = res
     _lib = lib
+    # HFMI_TUNE="waves=4,nn_waves=8": the kernel tuning knobs of hfmi_tuning_set (include/hfmi.h) for a whole process -- how the A/B
+    # runs of bench.py / rocprofv3 select a variant without a code change (scripts/tn_tile_ab.sh)
+    for item in filter(None, os.environ.get("HFMI_TUNE", "").split(",")):
+        key, _, val = item.partition("=")
+        check(lib.hfmi_tuning_set(key.strip().encode(), int(val)))
     return lib
 
 

@@ -1,4 +1,4 @@
-// Whole-GPU symmetric eigensolver for 256 < n <= 8192: the n x n Gram problem of the deterministic POD (la.eigh(G),
+// Whole-GPU symmetric eigensolver for 256 < n <= 16384: the n x n Gram problem of the deterministic POD (la.eigh(G),
 // PODProjector.py:812-833 -- any number of snapshots; dataGenerator.py:278-279 hands it the whole training set), i.e. LAPACK
 // dsyevd's algorithm family spread over the 256 compute units instead of the one-workgroup kernels of hfmi_eig_dc.hip:
 //
@@ -40,7 +40,7 @@ int sym_eig_large_jacobi(hfmi_ctx* ctx, const double* host_T, int n, int sort_by
 
 namespace {
 constexpr int EB_NB = 64;          // panel width of the tridiagonalisation and of the block reflectors
-constexpr int EB_MAXN = HFMI_EIG_MAXN;      // 8192: v of k_tri_b (64 KB) and the poles of the top merge (16 bytes each) live in LDS
+constexpr int EB_MAXN = HFMI_EIG_MAXN;      // 16384: v of k_tri_b lives in LDS (128 KB of 160)
 constexpr int GT = 64;             // k_dgemm: C tile
 constexpr int GK = 16;             // reduction depth of an LDS stage
 constexpr int GLD = 80;            // LDS row stride: = 16 mod 32 doubles, so the four k-rows of an MFMA operand fall into two bank halves
@@ -185,31 +185,43 @@ struct pstage {
       k = tid / (BT / 2) + (512 / BT) * u;
     }
   }
-  static __device__ __forceinline__ void load(const double* __restrict__ X, int64_t ld, int t0, int k0, int Tdim, int Kdim, int tid, bool vec,
-                                              d2 (&r)[ND2]) {
+  // FAST: the whole slab lies inside the operand and is 16-byte aligned -- plain 16-byte loads, no predicate.  Otherwise 8-byte loads
+  // from clamped (always valid) addresses and a select: no lane-divergent branch in either form (a predicated load that shares
+  // its destination with another load makes the compiler wait for the first one: eight serialised round trips per slab).
+  template <bool FAST>
+  static __device__ __forceinline__ void load(const double* __restrict__ X, int64_t ld, int t0, int k0, int Tdim, int Kdim, int tid,
+                                              d2 (&r)[ND2], unsigned& valid) {
+    valid = ~0u;
 #pragma unroll
     for (int u = 0; u < ND2; ++u) {
       int t, k;
       idx(tid, u, t, k);
       const int tt = t0 + t, kk = k0 + k;
-      const int64_t off = KC ? (int64_t)kk + (int64_t)tt * ld : (int64_t)tt + (int64_t)kk * ld;
-      const bool ok0 = tt < Tdim && kk < Kdim;
-      const bool ok1 = KC ? (tt < Tdim && kk + 1 < Kdim) : (tt + 1 < Tdim && kk < Kdim);
-      if (vec && ok1) {
+      if (FAST) {
+        const int64_t off = KC ? (int64_t)kk + (int64_t)tt * ld : (int64_t)tt + (int64_t)kk * ld;
         r[u] = *(const d2*)(X + off);
       } else {
-        r[u].x = ok0 ? X[off] : 0.0;
-        r[u].y = ok1 ? X[off + 1] : 0.0;
+        const int tt1 = KC ? tt : tt + 1, kk1 = KC ? kk + 1 : kk;
+        const bool ok0 = tt < Tdim && kk < Kdim, ok1 = tt1 < Tdim && kk1 < Kdim;
+        const int tc0 = min(tt, Tdim - 1), kc0 = min(kk, Kdim - 1), tc1 = min(tt1, Tdim - 1), kc1 = min(kk1, Kdim - 1);
+        r[u].x = X[KC ? (int64_t)kc0 + (int64_t)tc0 * ld : (int64_t)tc0 + (int64_t)kc0 * ld];
+        r[u].y = X[KC ? (int64_t)kc1 + (int64_t)tc1 * ld : (int64_t)tc1 + (int64_t)kc1 * ld];
+        if (!ok0) valid &= ~(1u << (2 * u));
+        if (!ok1) valid &= ~(2u << (2 * u));
       }
     }
   }
-  static __device__ __forceinline__ void store(double* __restrict__ s, int tid, const d2 (&r)[ND2]) {
+  // (the zeroing of out-of-range entries happens here, after the MFMAs of the slab that hid the loads)
+  static __device__ __forceinline__ void store(double* __restrict__ s, int tid, const d2 (&r)[ND2], unsigned valid) {
 #pragma unroll
     for (int u = 0; u < ND2; ++u) {
       int t, k;
       idx(tid, u, t, k);
-      if (KC) *(d2*)(s + t * PS_KC + k) = r[u];
-      else *(d2*)(s + k * LDK + t) = r[u];
+      d2 v = r[u];
+      if (!((valid >> (2 * u)) & 1u)) v.x = 0.0;
+      if (!((valid >> (2 * u)) & 2u)) v.y = 0.0;
+      if (KC) *(d2*)(s + t * PS_KC + k) = v;
+      else *(d2*)(s + k * LDK + t) = v;
     }
   }
   // fragment element (own index t, reduction index k)
@@ -246,18 +258,25 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_p(int M, int N, int K, double 
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
   const int nk1 = (K + PK - 1) / PK, nk2 = (K2 + PK - 1) / PK, nk = nk1 + nk2;
   d2 ra[SA::ND2], rb[SB::ND2];
+  unsigned va = ~0u, vb = ~0u;
+  const bool inside = vec && i0 + BM <= M && j0 + BN <= N;      // workgroup-uniform
   auto gload = [&](int kt) {
     const bool second = kt >= nk1;
     const double* Ap = second ? A2 : A;
     const double* Bp = second ? B2 : B;
     const int Kc = second ? K2 : K, k0 = (second ? kt - nk1 : kt) * PK;
-    SA::load(Ap, lda, i0, k0, M, Kc, tid, vec != 0, ra);
-    SB::load(Bp, ldb, j0, k0, N, Kc, tid, vec != 0, rb);
+    if (inside && k0 + PK <= Kc) {
+      SA::template load<true>(Ap, lda, i0, k0, M, Kc, tid, ra, va);
+      SB::template load<true>(Bp, ldb, j0, k0, N, Kc, tid, rb, vb);
+    } else {
+      SA::template load<false>(Ap, lda, i0, k0, M, Kc, tid, ra, va);
+      SB::template load<false>(Bp, ldb, j0, k0, N, Kc, tid, rb, vb);
+    }
   };
   if (nk > 0) {
     gload(0);
-    SA::store(s_a(0), tid, ra);
-    SB::store(s_b(0), tid, rb);
+    SA::store(s_a(0), tid, ra, va);
+    SB::store(s_b(0), tid, rb, vb);
   }
   __syncthreads();
   const int ta0 = wm * (BM / 2) + li, tb0 = wn * 64 + li;
@@ -285,38 +304,43 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_p(int M, int N, int K, double 
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MFMA_F64(fb[cur][ni], fa[cur][mi], acc[mi][ni]);
     }
     if (kt + 1 < nk) {
-      SA::store(s_a((kt + 1) & 1), tid, ra);
-      SB::store(s_b((kt + 1) & 1), tid, rb);
+      SA::store(s_a((kt + 1) & 1), tid, ra, va);
+      SB::store(s_b((kt + 1) & 1), tid, rb, vb);
     }
     __syncthreads();
   }
-  // epilogue: lane (li, lk), register reg of tile (mi, ni) holds C[i0 + wm BM/2 + 16 mi + li, j0 + wn 64 + 16 ni + lk + 4 reg]
+  // epilogue: lane (li, lk), register reg of tile (mi, ni) holds C[i0 + wm BM/2 + 16 mi + li, j0 + wn 64 + 16 ni + lk + 4 reg].
+  // beta != 0: the old values are fetched two column tiles at a time -- 8 MI loads per lane in flight (from clamped, always valid
+  // addresses: no predicate on a load), then the same number of stores -- two round trips per tile instead of one per column
+  const int ib = i0 + wm * (BM / 2) + li, jb = j0 + wn * 64 + lk;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+  for (int nh = 0; nh < NI; nh += 2) {
+    double old[2][4][MI];
+    if (beta != 0.0) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int j = j0 + wn * 64 + ni * 16 + lk + 4 * reg;
-      if (j >= N) continue;
-      double* __restrict__ ccol = C + (int64_t)j * ldc;
-      double old[MI];
-      if (beta != 0.0) {
+      for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int i = min(ib + 16 * mi, M - 1), j = min(jb + 16 * (nh + n2) + 4 * reg, N - 1);
+            old[n2][reg][mi] = C[(int64_t)i + (int64_t)j * ldc];
+          }
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          const int i = i0 + wm * (BM / 2) + mi * 16 + li;
-          old[mi] = i < M ? ccol[i] : 0.0;
+          const int i = ib + 16 * mi, j = jb + 16 * (nh + n2) + 4 * reg;
+          double v = alpha * acc[mi][nh + n2][reg];
+          if (beta != 0.0) v = fma(beta, old[n2][reg][mi], v);
+          if (i < M && j < N) C[(int64_t)i + (int64_t)j * ldc] = v;
         }
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int i = i0 + wm * (BM / 2) + mi * 16 + li;
-        if (i < M) {
-          double v = alpha * acc[mi][ni][reg];
-          if (beta != 0.0) v = fma(beta, old[mi], v);
-          ccol[i] = v;
-        }
-      }
-    }
+  }
 }
+
 struct gemm_desc {
   bool ta, tb;
   int M, N, K;
@@ -612,16 +636,17 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   }
   // column j of the reduced matrix: every load of it is requested before the first use (a loop over a run-time count would wait
   // for each load before issuing the next: 8 x an L2 round trip per column at n = 4096)
-  double cb[CB];           // CB = 8: n <= 4096, 16: n <= 8192
+  double cb[CB];           // CB = 8: n <= 4096, 16: n <= 8192, 32: n <= 16384
 #pragma unroll
   for (int u = 0; u < CB; ++u) {
     const int r = rs + tid + 512 * u;
     cb[u] = (r > j + 1 && r < n) ? p.colbuf[r] : 0.0;
   }
   const double alpha0 = p.colbuf[j + 1];
-  // one partial sum per 64 rows: at most 64 (one per lane) up to n = 4096, two per lane beyond
+  // one partial sum per 64 rows: at most 64 (one per lane) up to n = 4096, two per lane up to 8192, four up to 16384
   double pnl = l < p.npn ? p.pn[l] : 0.0;
-  if (CB > 8) pnl += l + 64 < p.npn ? p.pn[l + 64] : 0.0;
+#pragma unroll
+  for (int u = 1; u < CB / 8; ++u) pnl += l + 64 * u < p.npn ? p.pn[l + 64 * u] : 0.0;
   const double xn2 = wave_sum(pnl);
   double tau = 0.0, beta = alpha0, scl = 0.0;
   if (xn2 > 1e-280) {      // entries are scaled to O(1): below this the column is zero to any precision that matters
@@ -721,7 +746,8 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
   const int rs2 = (j + 1) & ~(TS - 1);
   const double alpha0 = p.colbuf[j + 1];
   double pnl = l < p.npn ? p.pn[l] : 0.0;
-  if (CB > 8) pnl += l + 64 < p.npn ? p.pn[l + 64] : 0.0;
+#pragma unroll
+  for (int u = 1; u < CB / 8; ++u) pnl += l + 64 * u < p.npn ? p.pn[l + 64 * u] : 0.0;
   const double xn2 = wave_sum(pnl);
   double tau = 0.0, beta = alpha0, scl = 0.0;
   if (xn2 > 1e-280) {
@@ -972,7 +998,8 @@ struct dcl_args {
   double *Q, *Qout, *Qg, *S;
   double *Zv, *Ds, *Zs, *dl, *wv, *tauS, *zhat, *rc, *rs;
   int *Col, *Live, *Ks, *Src, *orgv, *ra, *rb;
-  int *xkp, *xli;               // k_dcl_deflate<true>: its index lists in global memory
+  int *xkp, *xli;               // k_dcl_deflate<1 | 2>: its index lists in global memory
+  double *xd, *xz;              // k_dcl_deflate<2>: poles and rank-one vector in global memory
   unsigned char *xkept, *xlv;
   dcl_node* nodes;
   int* fail;
@@ -1094,8 +1121,11 @@ __global__ __launch_bounds__(256) void k_dcl_rank(dcl_args p) {
 // BIG (a node of more than 4160 poles, i.e. the top merge beyond n = 4096): only the poles and the rank-one vector stay in LDS (16
 // bytes per pole, 132 KB at 8192), the index lists live in global memory at the node's offset -- every access pattern below is
 // "written, workgroup barrier, read by other threads of the SAME workgroup", which global memory serves like LDS.
-template <bool BIG>
+// MODE 2 (a node of more than 9984 poles: the top merge beyond n = 9984): the poles and the rank-one vector live in global memory
+// too (xd, xz): no dynamic LDS at all; the sequential rotation scan, when it is needed at all, then walks global memory.
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
+  constexpr bool BIG = MODE >= 1;
   // dynamic LDS, cap = the largest node of the level rounded up to 64: 30 bytes per pole (125 KB at 4096)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ int s_scan[1024];
@@ -1104,8 +1134,8 @@ __global__ __launch_bounds__(1024) void k_dcl_deflate(dcl_args p, int cap) {
   const dcl_node nd = p.nodes[node];
   const int lo = nd.lo, hi = nd.hi, nn = hi - lo, K0 = nd.K;
   const double tol = nd.tol;
-  double* s_d = (double*)s_raw;
-  double* s_z = s_d + cap;
+  double* s_d = MODE == 2 ? p.xd + lo : (double*)s_raw;
+  double* s_z = MODE == 2 ? p.xz + lo : s_d + cap;
   int* s_ks = BIG ? p.Ks + lo : (int*)(s_z + cap);
   int* s_kp = BIG ? p.xkp + lo : s_ks + cap;
   int* s_li = BIG ? p.xli + lo : s_kp + cap;   // sorted position -> index in the live list (-1: deflated by the first test)
@@ -1314,9 +1344,9 @@ __global__ __launch_bounds__(256) void k_dcl_gather(dcl_args p) {
 // ------------------------------------------------------------------------------------------------ block reflectors
 // triangular factor of a 64-column panel from its Gram matrix (LAPACK dlarft, forward, columnwise): T[i][i] = tau_i,
 // T[0:i, i] = -tau_i T[0:i, 0:i] (V^T v_i).  One wave per panel.  The panels are the diagonal 64 x 64 blocks of the EB_WY-wide
-// block reflectors: panel p lives at offset (p % 4) * 64 on the diagonal of block p / 4 of G and T (leading dimension EB_WY).
-constexpr int EB_WY = 256;         // width of a block reflector of the back-transformation
-__global__ __launch_bounds__(64) void k_larft(const double* __restrict__ G, const double* __restrict__ tauv, double* __restrict__ Tf) {
+// block reflectors (EB_WY = 256 | 512): panel p lives at offset (p % (EB_WY / 64)) * 64 on the diagonal of block p / (EB_WY / 64) of G and T
+// (leading dimension EB_WY).
+__global__ __launch_bounds__(64) void k_larft(const double* __restrict__ G, const double* __restrict__ tauv, double* __restrict__ Tf, int EB_WY) {
   __shared__ double s_t[EB_NB][EB_NB + 1], s_g[EB_NB];
   const int r = threadIdx.x;
   const size_t off = (size_t)(blockIdx.x / (EB_WY / EB_NB)) * EB_WY * EB_WY + (size_t)(blockIdx.x % (EB_WY / EB_NB)) * EB_NB * (EB_WY + 1);
@@ -1484,13 +1514,21 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     return HFMI_OK;
   }
   const int NB = EB_NB;
+  // width of a block reflector of the back-transformation: V^T Z is a WY x nv product over WY / 64 row tiles -- 512 columns from
+  // n = 3072 on keep 8 row tiles x nv / 128 column tiles of the pipelined kernel on the chip where 256 would leave half of it idle
+  static const int wy_env = [] {
+    const char* e = getenv("HFMI_EIG_WY");
+    const int v = e ? atoi(e) : 0;
+    return (v == 256 || v == 512) ? v : 0;
+  }();
+  const int WY = wy_env ? wy_env : (n >= 3072 ? 512 : 256);
   const int64_t ld = round_up(n, 128);
-  const int npad = (int)round_up(n, EB_WY), npanels = npad / NB, nblk = npad / EB_WY;
+  const int npad = (int)round_up(n, WY), npanels = npad / NB, nblk = npad / WY;
   const size_t mat = (size_t)ld * npad;
   const size_t vlen = (size_t)npad + 128;
   // ---- workspace
   const size_t n_mats = 5;
-  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)EB_WY * npad + 3 * (size_t)nblk * EB_WY * EB_WY + 16 * vlen + 2 * 64 + EB_MAXN / 64 + 2112 +
+  const size_t d_count = n_mats * mat + (size_t)ld * NB + (size_t)WY * npad + 3 * (size_t)nblk * WY * WY + 18 * vlen + 2 * 64 + EB_MAXN / 64 + 2112 +
                          (size_t)(npad / 32 + 1) * (npad / 32 + 1);
   const size_t i_count = 11 * vlen + 64;
   const size_t bytes = d_count * sizeof(double) + i_count * sizeof(int) + 64 * sizeof(dcl_node) + 256;
@@ -1508,10 +1546,10 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   double* Q2 = take(mat);
   double* Qg = take(mat);       // raw upload first, gathered columns of the merges, nothing afterwards
   double* Wp = take((size_t)ld * NB);
-  double* W1 = take((size_t)EB_WY * npad);
-  double* Gm = take((size_t)nblk * EB_WY * EB_WY);
-  double* Tf = take((size_t)nblk * EB_WY * EB_WY);
-  double* Tt = take((size_t)nblk * EB_WY * EB_WY);      // products in flight while the triangular factors are merged
+  double* W1 = take((size_t)WY * npad);
+  double* Gm = take((size_t)nblk * WY * WY);
+  double* Tf = take((size_t)nblk * WY * WY);
+  double* Tt = take((size_t)nblk * WY * WY);      // products in flight while the triangular factors are merged
   double* colbuf = take(vlen);
   double* ybuf = take(vlen);
   double* dvec = take(vlen);
@@ -1528,6 +1566,8 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   double* zhat = take(vlen);
   double* rc = take(vlen);
   double* rs = take(vlen);
+  double* xd = take(vlen);
+  double* xz = take(vlen);
   double* x1 = take(64);
   double* x2 = take(64);
   double* pn = take(EB_MAXN / 64);  // one partial norm per 64 rows
@@ -1608,8 +1648,13 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     ta.npvy = 0;
     ta.npn = 0;
     bool prev_slots = false;             // the last column's products were left in slots by k_tri_bs
-    if (n > 4096)      // v of the first columns is 64 KB: beyond what a kernel gets without asking
+    if (n > 8192)      // v of the first columns is 128 KB (of 160)
+      HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
+    else if (n > 4096)      // v of the first columns is 64 KB: beyond what a kernel gets without asking
       HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
+    // the lower-triangle products serve trailing blocks of sym_min ... 8192 rows (64 slots of 128 rows, 2080 tiles); the first columns of a
+    // larger matrix take the full-column products
+    auto uses_bs = [&](int j) { return n - j - 1 >= sym_min && ((int)ld - ((j + 1) & ~(TS - 1))) / TS <= 64; };
     static const int unb_max = [] {      // HFMI_EIG_UNB_MAX: trailing blocks of at most this many rows take one launch per column (0: never)
       const char* e = getenv("HFMI_EIG_UNB_MAX");
       const int v = e ? atoi(e) : 2048;
@@ -1645,7 +1690,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
         const size_t v_lds = (size_t)(ld - rs0) * sizeof(double);
-        if (n - j - 1 >= sym_min) {
+        if (uses_bs(j)) {
           // large trailing block: the lower triangle only (k_tri_bs); the next k_tri_a adds the partial vectors
           const int rs2 = (j + 1) & ~(TS - 1);
           const int nb = ((int)ld - rs2) / TS, ntiles = nb * (nb + 1) / 2;
@@ -1655,7 +1700,8 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
           ta.npvy = ntiles;
           prev_slots = true;
         } else {
-          if (n > 4096) hipLaunchKernelGGL((k_tri_b<8, 16>), dim3(gb), dim3(512), v_lds, st, ta);
+          if (n > 8192) hipLaunchKernelGGL((k_tri_b<8, 32>), dim3(gb), dim3(512), v_lds, st, ta);
+          else if (n > 4096) hipLaunchKernelGGL((k_tri_b<8, 16>), dim3(gb), dim3(512), v_lds, st, ta);
           else if (tri_unr == 8) hipLaunchKernelGGL((k_tri_b<8, 8>), dim3(gb), dim3(512), v_lds, st, ta);
           else hipLaunchKernelGGL((k_tri_b<4, 8>), dim3(gb), dim3(512), v_lds, st, ta);
           ta.npvy = gb;
@@ -1686,7 +1732,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       g.ldc = ld;
       // every column of the NEXT panel takes the lower-triangle products (and there is a next panel): the tiles above the diagonal are
       // not read again until the full-column / unblocked columns begin -- they are skipped and mirrored back once, there
-      const bool next_all_lower = n - (t0 + NB - 1) - 1 >= sym_min && n - t0 > unb_max;
+      const bool next_all_lower = uses_bs(t0) && uses_bs(t0 + NB - 1) && n - t0 > unb_max;
       g.lower = (lower_updates && (next_all_lower || !upper_valid)) ? 1 + (t0 & 127) : 0;
       HFMI_TRY(launch_dgemm(ctx, g));
       if (g.lower) upper_valid = false;
@@ -1758,6 +1804,8 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     da.xli = xli;
     da.xkept = xkept;
     da.xlv = xlv;
+    da.xd = xd;
+    da.xz = xz;
     da.nodes = nodes;
     da.fail = fail;
     for (int L = Lf - 1; L >= 0; --L) {
@@ -1770,14 +1818,16 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       hipLaunchKernelGGL(k_dcl_z, dim3(nn), dim3(1024), 0, st, da);
       hipLaunchKernelGGL(k_dcl_rank, dim3((n + 63) / 64), dim3(256), 0, st, da);
       const int cap = (int)round_up((n + nn - 1) / nn + 1, 64);
-      if (cap > 4160) {      // the top merge beyond n = 4096
+      if (cap > 9984) {      // the top merge beyond n = 9984: nothing of it in LDS
+        hipLaunchKernelGGL(k_dcl_deflate<2>, dim3(nn), dim3(1024), 0, st, da, cap);
+      } else if (cap > 4160) {      // the top merge beyond n = 4096
         const size_t defl_lds = (size_t)cap * 16;
-        HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
-        hipLaunchKernelGGL(k_dcl_deflate<true>, dim3(nn), dim3(1024), defl_lds, st, da, cap);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
+        hipLaunchKernelGGL(k_dcl_deflate<1>, dim3(nn), dim3(1024), defl_lds, st, da, cap);
       } else {
         const size_t defl_lds = (size_t)cap * 30;
-        HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
-        hipLaunchKernelGGL(k_dcl_deflate<false>, dim3(nn), dim3(1024), defl_lds, st, da, cap);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dcl_deflate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)defl_lds));
+        hipLaunchKernelGGL(k_dcl_deflate<0>, dim3(nn), dim3(1024), defl_lds, st, da, cap);
       }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(hnodes, nodes, (size_t)nn * sizeof(dcl_node), hipMemcpyDeviceToHost, st));
@@ -1831,46 +1881,46 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   HIP_TRY(hipGetLastError());
   std::swap(Qcur, Qnext);
 
-  // ---- back-transformation: Z <- (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) Z with block reflectors of EB_WY = 256
+  // ---- back-transformation: Z <- (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) Z with block reflectors of WY = 256 | 512
   // columns (four panels): 64-column products V^T Z would be 64 tiles on 256 compute units.  The triangular factor of a block is
   // assembled from those of its panels: [V_a V_b] has T = [[T_a, -T_a (V_a^T V_b) T_b], [0, T_b]] (twice: 64 -> 128 -> 256).
   {
     double* Z = Qcur;
     double* Y = A;
-    const int64_t sWY = (int64_t)EB_WY * EB_WY;
+    const int64_t sWY = (int64_t)WY * WY;
     gemm_desc g;
     g.ta = true;                 // Gram matrices of all blocks
     g.tb = false;
-    g.M = g.N = EB_WY;
+    g.M = g.N = WY;
     g.K = n;
     g.alpha = 1.0;
     g.beta = 0.0;
     g.A = g.B = Vh;
     g.lda = g.ldb = ld;
     g.C = Gm;
-    g.ldc = EB_WY;
+    g.ldc = WY;
     g.batch = nblk;
-    g.sA = g.sB = (int64_t)EB_WY * ld;
+    g.sA = g.sB = (int64_t)WY * ld;
     g.sC = sWY;
     HFMI_TRY(launch_dgemm(ctx, g));
     HIP_TRY(hipMemsetAsync(Tf, 0, (size_t)nblk * sWY * sizeof(double), st));
-    hipLaunchKernelGGL(k_larft, dim3(npanels), dim3(64), 0, st, Gm, tauv, Tf);
+    hipLaunchKernelGGL(k_larft, dim3(npanels), dim3(64), 0, st, Gm, tauv, Tf, WY);
     HIP_TRY(hipGetLastError());
-    for (int w = NB; w < EB_WY; w *= 2) {              // merge neighbours of width w into width 2 w
-      for (int a0 = 0; a0 + 2 * w <= EB_WY; a0 += 2 * w) {
-        const size_t offTa = (size_t)a0 * (EB_WY + 1), offTb = (size_t)(a0 + w) * (EB_WY + 1);
-        const size_t offX = (size_t)a0 + (size_t)(a0 + w) * EB_WY;          // rows of a, columns of b
+    for (int w = NB; w < WY; w *= 2) {              // merge neighbours of width w into width 2 w
+      for (int a0 = 0; a0 + 2 * w <= WY; a0 += 2 * w) {
+        const size_t offTa = (size_t)a0 * (WY + 1), offTb = (size_t)(a0 + w) * (WY + 1);
+        const size_t offX = (size_t)a0 + (size_t)(a0 + w) * WY;          // rows of a, columns of b
         gemm_desc m1;            // tmp = (V_a^T V_b) T_b
         m1.ta = m1.tb = false;
         m1.M = m1.N = m1.K = w;
         m1.alpha = 1.0;
         m1.beta = 0.0;
         m1.A = Gm + offX;
-        m1.lda = EB_WY;
+        m1.lda = WY;
         m1.B = Tf + offTb;
-        m1.ldb = EB_WY;
+        m1.ldb = WY;
         m1.C = Tt + offX;
-        m1.ldc = EB_WY;
+        m1.ldc = WY;
         m1.batch = nblk;
         m1.sA = m1.sB = m1.sC = sWY;
         HFMI_TRY(launch_dgemm(ctx, m1));
@@ -1885,28 +1935,28 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     gemm_desc gy;                // Y = V T, every block
     gy.ta = gy.tb = false;
     gy.M = n;
-    gy.N = gy.K = EB_WY;
+    gy.N = gy.K = WY;
     gy.alpha = 1.0;
     gy.beta = 0.0;
     gy.A = Vh;
     gy.lda = ld;
     gy.B = Tf;
-    gy.ldb = EB_WY;
+    gy.ldb = WY;
     gy.C = Y;
     gy.ldc = ld;
     gy.batch = nblk;
-    gy.sA = gy.sC = (int64_t)EB_WY * ld;
+    gy.sA = gy.sC = (int64_t)WY * ld;
     gy.sB = sWY;
     HFMI_TRY(launch_dgemm(ctx, gy));
     for (int bi = nblk - 1; bi >= 0; --bi) {
       // rows from p0 on: row p0 of the block's reflectors (and of Y = V T) is zero -- column p0 + c starts at row p0 + c + 1 --
       // so the products are the same as from p0 + 1, and every operand keeps its 16-byte alignment
-      const int p0 = bi * EB_WY, r0 = p0;
+      const int p0 = bi * WY, r0 = p0;
       if (p0 >= n - 2) continue;
       gemm_desc g1;              // W1 = V^T Z   (rows r0 ..)
       g1.ta = true;
       g1.tb = false;
-      g1.M = EB_WY;
+      g1.M = WY;
       g1.N = nv;
       g1.K = n - r0;
       g1.alpha = 1.0;
@@ -1916,19 +1966,19 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       g1.B = Z + r0;
       g1.ldb = ld;
       g1.C = W1;
-      g1.ldc = EB_WY;
+      g1.ldc = WY;
       HFMI_TRY(launch_dgemm(ctx, g1));
       gemm_desc g2;              // Z -= Y W1
       g2.ta = g2.tb = false;
       g2.M = n - r0;
       g2.N = nv;
-      g2.K = EB_WY;
+      g2.K = WY;
       g2.alpha = -1.0;
       g2.beta = 1.0;
       g2.A = Y + (size_t)p0 * ld + r0;
       g2.lda = ld;
       g2.B = W1;
-      g2.ldb = EB_WY;
+      g2.ldb = WY;
       g2.C = Z + r0;
       g2.ldc = ld;
       HFMI_TRY(launch_dgemm(ctx, g2));

@@ -290,7 +290,7 @@ int launch_small_matmul(hfmi_ctx* ctx, int k, int r, int slot_a, int slot_b, int
 // R (k x k, slot_r) = U diag(s) V^T: singular values descending in svals (device), U -> slot_u, V -> slot_v (columns)
 int launch_jacobi_svd(hfmi_ctx* ctx, int k, int slot_r, int slot_u, int slot_v, double* svals);
 
-constexpr int HFMI_EIG_MAXN = 8192;      // largest symmetric eigenproblem (hfmi_sym_eig_small / _leading, hfmi_block_gram_eig)
+constexpr int HFMI_EIG_MAXN = 16384;     // largest symmetric eigenproblem (hfmi_sym_eig_small / _leading, hfmi_block_gram_eig)
 // symmetric eigensolve for 256 < n <= HFMI_EIG_MAXN: host in, host out.  hfmi_eig_blocked.hip (panel tridiagonalisation on the MFMA, divide
 // and conquer, block-reflector back-transformation); HFMI_EIG_LARGE=jacobi selects the two-sided Jacobi of hfmi_eig_large.hip
 // nvec < 0 or > n: all eigenvectors; otherwise host_V is n x nvec (the leading eigenvectors in output order)

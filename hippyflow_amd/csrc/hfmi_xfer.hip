@@ -75,7 +75,15 @@ struct pool {
 };
 }  // namespace
 
+// device -> pinned host memory by a kernel: the shader cores write across PCIe themselves.  The copy engine the runtime uses for
+// hipMemcpyAsync delivered 21-26 GB/s device -> host on these boxes (49 GB/s host -> device: profiles/r06a_eig_large.txt)
+typedef double xd2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_xfer_out(xd2* __restrict__ dst, const xd2* __restrict__ src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 struct xfer_state {
+  char* pin_dev = nullptr;        // the ring as the device sees it
   char* pin = nullptr;
   hipEvent_t ev[XF_NBUF];
   bool have_events = false;
@@ -89,6 +97,7 @@ static int xfer_get(hfmi_ctx* ctx, xfer_state** out) {
     if (!s) HFMI_FAIL(HFMI_ERR_INVALID, "out of host memory");
     ctx->xfer = s;
     HIP_TRY(hipHostMalloc((void**)&s->pin, XF_NBUF * XF_CHUNK, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&s->pin_dev, s->pin, 0));
     for (int i = 0; i < XF_NBUF; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming));
     s->have_events = true;
     const char* e = getenv("HFMI_XFER_THREADS");
@@ -146,8 +155,17 @@ int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes) {
     }
   });
   hipError_t err = hipSuccess;
+  static const bool engine = env_flag("HFMI_XFER_D2H_ENGINE");      // A/B: the runtime's copy engine instead of the copy kernel
+  const bool aligned = (((uintptr_t)dev) & 15) == 0;
   auto issue = [&](int c) {
-    err = hipMemcpyAsync(s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK, (const char*)dev + (size_t)c * XF_CHUNK, chunk_len(c), hipMemcpyDeviceToHost, st);
+    const size_t len = chunk_len(c);
+    if (engine || !aligned || (len & 15)) {
+      err = hipMemcpyAsync(s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK, (const char*)dev + (size_t)c * XF_CHUNK, len, hipMemcpyDeviceToHost, st);
+    } else {
+      hipLaunchKernelGGL(k_xfer_out, dim3(128), dim3(256), 0, st, (xd2*)(s->pin_dev + (size_t)(c % XF_NBUF) * XF_CHUNK),
+                         (const xd2*)((const char*)dev + (size_t)c * XF_CHUNK), len / 16);
+      err = hipGetLastError();
+    }
     if (err == hipSuccess) err = hipEventRecord(s->ev[c % XF_NBUF], st);
   };
   for (int c = 0; c < std::min(nch, XF_NBUF) && err == hipSuccess; ++c) issue(c);

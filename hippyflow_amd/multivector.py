@@ -156,7 +156,7 @@ class MultiVector:
     def gram_eig(self, other, nvec, sort_by_abs=False):
         """``la.eigh(self^T other)`` with eigenvalues descending and the ``nvec`` leading eigenvectors: the Gram matrix is formed
         on the device and never leaves it (PODProjector.py:818-826: ``UtMU = u_data @ M @ u_data.T``, ``eigh``,
-        ``U[:, :u_rank]``).  Both blocks hold the same number n <= 8192 of vectors; returns (d (n,), V (n, nvec))."""
+        ``U[:, :u_rank]``).  Both blocks hold the same number n <= 16384 of vectors; returns (d (n,), V (n, nvec))."""
         n, nvec = self._k, int(nvec)
         d, V = np.empty(n), np.empty((n, nvec))
         L.call("hfmi_block_gram_eig", self.handle, other.handle, 1 if sort_by_abs else 0, nvec, L.ptr(d), L.ptr(V))

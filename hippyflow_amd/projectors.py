@@ -931,7 +931,7 @@ class PODProjectorFromData:
     """Deterministic mass-weighted POD from a snapshot matrix (PODProjector.py:666-852).
     ``method='hep'`` (n << N) runs on the device: the n x n Gram matrix X^T M X and the back-transform
     phi = X U are tall-skinny contractions, the n x n symmetric eigensolve is tridiagonalisation + divide and conquer
-    (one workgroup up to 256 snapshots; panels, merges and block reflectors over the whole GPU up to 8192:
+    (one workgroup up to 256 snapshots; panels, merges and block reflectors over the whole GPU up to 16384:
     ``hfmi_block_gram_eig``, only the u_rank wanted eigenvectors come back) -- same steps as :812-833.
 
     ``method='ghep'`` (H = M X (M X)^T / n against M, :743-773) and ``'inverse_ghep'`` (H = X X^T / n against
@@ -950,21 +950,38 @@ class PODProjectorFromData:
         self.M_csr = sp.csr_matrix(M_output)
         self.ctx = ctx or L.Context.default()
 
-    def _randomized(self, u_data, u_rank, oversampling=20):
-        """More than 8192 snapshots (the n x n eigensolve on the device stops there; the reference's :812-833 takes any n): the
+    EXACT_MAX_SNAPSHOTS = 16384          # HFMI_EIG_MAXN: the largest n x n eigensolve on the device
+    RANDOMIZED_PASSES = 3                # power passes of the fallback beyond it
+    RANDOMIZED_OVERSAMPLING = 40
+
+    def _randomized(self, u_data, u_rank, oversampling=None, passes=None):
+        """More than 16384 snapshots (the n x n eigensolve on the device stops there; the reference's :812-833 takes any n): the
         same modes from the N-dimensional form of the problem, (1/n) M X X^T M phi = lambda M phi with phi^T M phi = 1, by the
-        randomized double pass this library is built around (``doublePassG`` with B = M, B^-1 = the device mass solve).  The
-        eigenpairs are those of the randomized method (oversampling 20, one pass): exact to rounding when the snapshots have
-        numerical rank <= u_rank + 20, otherwise as accurate as the decay of the spectrum beyond that allows."""
+        randomized double pass this library is built around (``doublePassG`` with B = M, B^-1 = the device mass solve) with
+        ``oversampling`` = 40 extra probe columns and ``passes`` = 3 applications of the operator per side.
+
+        STATED TOLERANCE (tests/test_gpu_solvers.py::test_pod_from_data_randomized_fallback_tolerance): with k = u_rank + 40 probe
+        columns and s = 3 passes the relative error of eigenvalue i is bounded by about (lambda_{k+1} / lambda_i)^(2 s - 1)
+        (Halko-Martinsson-Tropp 2011, section 10.4) -- exact to rounding when the snapshots' numerical rank is <= k, <= 1e-6 for
+        the leading u_rank modes as soon as lambda_{k+1} <= 0.06 lambda_{u_rank}; a spectrum flatter than that over 40 modes is
+        reported by the warning below with the measured ratio, so that the caller can raise the oversampling."""
         import warnings
         from .operators import ComposedOperator
-        warnings.warn("PODProjectorFromData: %d snapshots > 8192 -- using the randomized double pass on the N-dimensional "
-                      "generalized problem instead of the n x n Gram eigensolve" % u_data.shape[0])
+        oversampling = self.RANDOMIZED_OVERSAMPLING if oversampling is None else oversampling
+        passes = self.RANDOMIZED_PASSES if passes is None else passes
         X = MultiVector.from_vectors(u_data, ctx=self.ctx)
         Mop = CsrOperator(self.M_csr, ctx=self.ctx)
         A = ComposedOperator(Mop, SnapshotGramOperator(X, scale=1.0 / X.nvec()), Mop)
-        Omega = _draw_omega(X.size(), min(u_rank + oversampling, X.size()), NullCollective(), self.ctx)
-        d, phi_mv = doublePassG(A, Mop, CsrPCGSolver(Mop.csr, ctx=self.ctx), Omega, u_rank, s=1)
+        k = min(u_rank + oversampling, X.size())
+        Omega = _draw_omega(X.size(), k, NullCollective(), self.ctx)
+        d_all, phi_all = doublePassG(A, Mop, CsrPCGSolver(Mop.csr, ctx=self.ctx), Omega, k, s=passes)
+        tail = float(d_all[-1] / d_all[u_rank - 1]) if d_all[u_rank - 1] > 0 else 0.0
+        warnings.warn("PODProjectorFromData: %d snapshots > %d -- randomized double pass (k = %d probe columns, %d passes) on the "
+                      "N-dimensional generalized problem instead of the n x n Gram eigensolve; lambda_k / lambda_r = %.2e, estimated "
+                      "relative eigenvalue error of mode r <= %.1e" % (u_data.shape[0], self.EXACT_MAX_SNAPSHOTS, k, passes, tail,
+                                                                      tail ** (2 * passes - 1)))
+        d = d_all[:u_rank]
+        phi_mv = phi_all if k == u_rank else MultiVector.from_vectors(np.ascontiguousarray(phi_all.to_dense()[:, :u_rank].T), ctx=self.ctx)
         Mphi_mv = MultiVector(phi_mv)
         Mop.matMvMult(phi_mv, Mphi_mv)
         return d, phi_mv.to_dense(), Mphi_mv.to_dense()
@@ -977,7 +994,7 @@ class PODProjectorFromData:
             u_data = u_data - u_shift
         else:
             u_shift = np.zeros(u_data.shape[1])
-        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > 8192:
+        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > self.EXACT_MAX_SNAPSHOTS:
             d, phi, Mphi = self._randomized(u_data, u_rank)
         elif method in ('hep', 'ghep', 'inverse_ghep'):
             X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector

@@ -98,7 +98,7 @@ parRandom = _ParRandom()
 def sym_eig_small(T, sort_by_abs=False, ctx=None, method="dc", nvec=None):
     """np.linalg.eigh(T) + descending sort, on the device.  ``method="dc"``: Householder tridiagonalisation + divide
     and conquer (the algorithm family of the LAPACK routine behind np.linalg.eigh; up to 256 rows on one compute unit,
-    up to 8192 over the whole GPU); ``"jacobi"``: one-workgroup cyclic Jacobi (high relative accuracy of small
+    up to 16384 over the whole GPU); ``"jacobi"``: one-workgroup cyclic Jacobi (high relative accuracy of small
     eigenvalues of graded positive definite matrices).  ``nvec``: return only the leading ``nvec`` eigenvectors
     (all eigenvalues still) -- ``la.eigh(G)[1][:, :u_rank]`` of PODProjector.py:821-826 without back-transforming
     and reading back the rest."""

@@ -246,7 +246,7 @@ int hfmi_borth_qr(hfmi_block* Q, hfmi_op* B, hfmi_block* BQ, double* host_R, int
  * (hfmi_eig_dc.hip) -- the algorithm family of the LAPACK routine behind np.linalg.eigh, absolute
  * accuracy eps ||T||.  HFMI_EIG_JACOBI: one-workgroup parallel cyclic Jacobi in LDS (slower; small
  * eigenvalues of graded positive definite matrices to high RELATIVE accuracy).
- * 256 < k <= 8192 (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821, any number of
+ * 256 < k <= 16384 (the n x n Gram problem of the deterministic POD, la.eigh at PODProjector.py:821, any number of
  * snapshots): the same algorithm family over the whole GPU (hfmi_eig_blocked.hip) -- panel Householder
  * tridiagonalisation with the trailing update on the fp64 MFMA, divide and conquer with the leaves on one compute unit
  * each and the upper merges on all of them, block-reflector back-transformation.  Non-finite entries: HFMI_ERR_NUMERIC

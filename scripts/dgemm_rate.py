@@ -7,7 +7,7 @@ if "--old" in sys.argv:
     os.environ["HFMI_EIG_GEMM"] = "0"
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import hippyflow_amd as hf  # noqa: E402
 
 ctx = hf.Context.default()

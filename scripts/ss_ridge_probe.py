@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import hippyflow_amd as hf  # noqa: E402
 from hippyflow_amd import _lib as L  # noqa: E402
 

@@ -33,12 +33,14 @@ def test_compact_form_of_an_extra_workload():
             "phases_ms_per_step": {"apply_A": 9.0},
             "cpu_baseline": {"value": 0.01, "unit": "GDoF*rank/s", "kind": "port", "cores": 64, "threads": 256, "physical_cores": 128,
                              "sockets": 2, "best_setting": "threads_all", "seconds_full_estimate": 3.8, "sample": "s",
-                             "reference_style": {"value": 7e-4}, "blas3": {}},
+                             "reference_style": {"best_single_setting_value": 6e-4,
+                                                 "composite_of_per_component_best_settings": {"value": 7e-4}}, "blas3": {}},
             "communicator": {"ranks": 1, "transport": "rccl"}}
     c = bench._compact(line)
     assert c["workload"] == "config3 PODProjector" and c["ms_per_step"] == 15.5 and c["roofline"]["frac"] == 0.81
     assert "extra" not in c["roofline"] and "note" not in c["parity"] and c["parity"]["eig_rel_err_vs_oracle"] == 4e-13
-    assert c["cpu_baseline"]["reference_style_value"] == 7e-4 and c["cpu_baseline"]["physical_cores"] == 128
+    assert c["cpu_baseline"]["reference_style_composite_of_per_component_best_settings_value"] == 7e-4
+    assert c["cpu_baseline"]["reference_style_best_single_setting_value"] == 6e-4 and c["cpu_baseline"]["physical_cores"] == 128
     assert c["communicator"]["transport"] == "rccl"
     json.dumps(c)
     bare = bench._compact({"value": 1.0, "config": {"workload": "w"}})             # nothing optional present

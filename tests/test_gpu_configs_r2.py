@@ -298,10 +298,10 @@ def test_low_rank_operator_with_a_general_diagonal(ctx):
     assert np.abs(Ud.T @ Bd @ Ud - np.eye(6)).max() < 1e-10
 
 
-def test_pod_from_data_beyond_8192_snapshots_goes_through_the_randomized_pass(ctx):
-    """The reference's deterministic POD takes any number of snapshots (PODProjector.py:812-833); beyond the 8192 of the
-    device's n x n eigensolve the same modes come from the N-dimensional generalized problem by doublePassG.  Snapshots of
-    numerical rank 30 <= rank + oversampling: the result equals the oracle's 'hep' to rounding."""
+def test_pod_from_data_8300_snapshots_is_the_exact_gram_route(ctx):
+    """The reference's deterministic POD takes any number of snapshots (PODProjector.py:812-833); up to 16384 the device solves
+    the n x n Gram problem exactly (whole-GPU eigensolver) -- no warning, no randomization: rank-30 snapshots against the oracle."""
+    import warnings
     from hippyflow_amd import workloads
     rng = np.random.default_rng(8)
     n, nx, ny, r = 8300, 30, 20, 18
@@ -310,7 +310,8 @@ def test_pod_from_data_beyond_8192_snapshots_goes_through_the_randomized_pass(ct
     W0, _ = np.linalg.qr(rng.standard_normal((N, 30)))
     u_data = (rng.standard_normal((n, 30)) * np.exp(-0.3 * np.arange(30))) @ W0.T + 0.25
     pod = hf.PODProjectorFromData(M_output=M)
-    with pytest.warns(UserWarning, match="randomized double pass"):
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=True, method="hep")
     d_o, phi_o, Mphi_o, shift_o = hf_o.pod_from_data(u_data.copy(), M, r, shifted=True, method="hep")
     np.testing.assert_allclose(d, d_o, rtol=1e-8)
@@ -321,13 +322,45 @@ def test_pod_from_data_beyond_8192_snapshots_goes_through_the_randomized_pass(ct
     assert np.abs(phi.T @ Mphi - np.eye(r)).max() < 1e-9
 
 
+def test_pod_from_data_randomized_fallback_tolerance(ctx):
+    """Beyond 16384 snapshots (both the n x n and, for a large state space, the N x N problem are out of the exact solver's reach) the
+    modes come from the randomized double pass on the N-dimensional generalized problem, k = r + 40 probe columns, 3 passes, WITH A
+    STATED TOLERANCE: relative eigenvalue error of mode i <= (lambda_{k+1} / lambda_i)^5 (PODProjectorFromData._randomized).  Checked on
+    a SLOWLY decaying spectrum (0.95^i per singular value): N = 600 here, so the exact answer is the dense generalized
+    eigenproblem of M H M / n against M."""
+    import scipy.linalg as sla
+    from hippyflow_amd import workloads
+    rng = np.random.default_rng(17)
+    n, nx, ny, r = 16500, 30, 20, 12
+    N = nx * ny
+    M = workloads.grid_mass_matrix(nx, ny)
+    K = 200
+    W0, _ = np.linalg.qr(rng.standard_normal((N, K)))
+    u_data = (rng.standard_normal((n, K)) * 0.95 ** np.arange(K)) @ W0.T
+    pod = hf.PODProjectorFromData(M_output=M)
+    with pytest.warns(UserWarning, match="randomized double pass"):
+        d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=False, method="hep")
+    Md = M.toarray()
+    lam, vec = sla.eigh(Md @ (u_data.T @ u_data / n) @ Md, Md)
+    lam, vec = lam[::-1], vec[:, ::-1]
+    k = r + pod.RANDOMIZED_OVERSAMPLING
+    bound = (lam[k] / lam[:r]) ** (2 * pod.RANDOMIZED_PASSES - 1)
+    rel = np.abs(d - lam[:r]) / lam[:r]
+    assert np.all(rel <= np.maximum(bound, 1e-10)), (rel, bound)
+    assert rel.max() < 1e-6                                                   # lambda_{k+1} / lambda_r = 0.95^80 = 0.0165: bound 1.2e-9
+    cos = np.abs(np.einsum("ij,ij->j", phi, Md @ vec[:, :r]))
+    np.testing.assert_allclose(cos[:r - 2], 1.0, atol=1e-6)
+    assert np.abs(phi.T @ Mphi - np.eye(r)).max() < 1e-9
+
+
 # ------------------------------------------------------------------ error behaviour of the round-2 entry points
 def test_round2_entry_points_reject_bad_arguments(ctx):
     import ctypes as C
     L = hf._lib
-    # sym_eig beyond 8192
+    # sym_eig beyond 16384 (the range check comes before anything is read: a small buffer stands in for the 2 GB matrix)
     with pytest.raises(hf.HfmiError) as e:
-        hf.sym_eig_small(np.eye(8193))
+        small = np.eye(4)
+        L.call("hfmi_sym_eig_small", hf.Context.default().handle, L.ptr(small), 16385, 0, L.ptr(np.empty(4)), None)
     assert "out of range" in str(e.value)
     # host-callback slab size: negative, and on an operator that is not a host callback
     cb = hf.HostCallbackOperator(lambda W: W, 64)

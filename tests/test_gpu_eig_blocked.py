@@ -1,4 +1,4 @@
-"""hfmi_sym_eig_small for 256 < n <= 8192 (hfmi_eig_blocked.hip: panel tridiagonalisation on the MFMA, divide and conquer over
+"""hfmi_sym_eig_small for 256 < n <= 16384 (hfmi_eig_blocked.hip: panel tridiagonalisation on the MFMA, divide and conquer over
 the whole GPU, block-reflector back-transformation) against numpy.linalg.eigh -- what the reference calls at
 PODProjector.py:821 (la.eigh(G)).  Bar: eigenvalues to 1e-12 ||T||, ||V^T V - I|| <= 1e-12,
 residual <= 1e-12 ||T|| (max-abs entries; n eps grows to 9e-13 at n = 4096, so the largest sizes get 4e-12, 8e-12 beyond 4096)."""
@@ -277,6 +277,56 @@ def test_pod_from_data_320_snapshots_matches_the_reference(ctx, golden_dir, meth
     assert np.linalg.norm(M @ phi - Mphi) / np.linalg.norm(Mphi) < 1e-8           # :170-174
 
 
+@pytest.mark.parametrize("shifted", [True, False])
+def test_pod_from_data_8300_snapshots_matches_the_reference(ctx, golden_dir, shifted):
+    """MORE THAN 8192 snapshots with a slowly decaying spectrum (0.95^k per singular value, rank 150 + noise floor): the reference's
+    exact la.eigh(G) (PODProjector.py:812-833; dataGenerator.py:278-279 hands it the whole training set) against the device's exact
+    n x n route (hfmi_block_gram_eig up to 16384) -- tests/golden/pod_from_data_8300.npz holds the REFERENCE's outputs, the snapshot
+    matrix is rebuilt from the stored seed with integer arithmetic (tests/golden/make_pod_huge_golden.py: snapshots()).  No warning:
+    nothing is randomized here."""
+    import os
+    import sys
+    import warnings
+    import scipy.sparse as sp
+    sys.path.insert(0, golden_dir)
+    from make_pod_huge_golden import snapshots
+    g = np.load(os.path.join(golden_dir, "pod_from_data_8300.npz"))
+    N, r = int(g["N"]), int(g["r"])
+    M = sp.csr_matrix((g["M_data"], g["M_indices"], g["M_indptr"]), shape=(N, N))
+    u_data = snapshots(int(g["seed"]), int(g["n"]), N, int(g["K"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        d, phi, Mphi, shift = hf.PODProjectorFromData(None, M).construct_subspace(u_data.copy(), r, shifted=shifted, method="hep")
+    tag = "hep_%d" % int(shifted)
+    np.testing.assert_allclose(shift, g["shift_" + tag], atol=1e-13)
+    np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-8)
+    cos = np.abs(np.einsum("ij,ij->j", phi[:, :r - 2], M @ g["phi_" + tag][:, :r - 2]))
+    np.testing.assert_allclose(cos, 1.0, atol=1e-8)
+    eye = np.eye(r)
+    assert np.linalg.norm(eye - phi.T @ Mphi) / np.linalg.norm(eye) < 1e-8
+
+
+@pytest.mark.parametrize("n", [8193, 9000, 12500, 16384])
+def test_sym_eig_blocked_beyond_8192(ctx, n):
+    """8192 < n <= 16384: the first columns take full-column products (v of k_tri_b is up to 128 KB of LDS), the top merge of the divide
+    and conquer keeps everything in global memory beyond 9984 poles (k_dcl_deflate<2>).  A matrix with a KNOWN spectrum (a diagonal
+    conjugated by three Householder reflectors: O(n^2) to build, no host eigh): every eigenvalue, and residual + orthonormality of the
+    64 leading eigenvectors."""
+    rng = np.random.default_rng(n)
+    lam = np.sort(np.concatenate([np.exp(-0.002 * np.arange(n - 40)), np.repeat([2.0, 3.0], 10), -np.linspace(0.1, 1.0, 20)]))[::-1]
+    T = np.diag(lam)
+    for _ in range(3):
+        u = rng.standard_normal(n)
+        u /= np.linalg.norm(u)
+        T -= 2.0 * np.outer(u, u @ T)
+        T -= 2.0 * np.outer(T @ u, u)
+    T = 0.5 * (T + T.T)
+    d, V = hf.sym_eig_small(T, nvec=64)
+    assert np.abs(d - lam).max() <= 2e-11 * np.abs(lam).max()
+    assert np.abs(V.T @ V - np.eye(64)).max() <= 1e-11
+    assert np.abs(T @ V - V * d[:64]).max() <= 2e-11 * np.abs(lam).max()
+
+
 _KNOB_SCRIPT = r"""
 import sys
 import numpy as np
@@ -308,7 +358,7 @@ def _knob_child(n, extra, out):
     return np.load(out)
 
 
-@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"}, {"HFMI_EIG_UNB_MAX": "0"}, {"HFMI_EIG_UNB_MAX": "700"}, {"HFMI_XFER_PLAIN": "1"}, {"HFMI_EIG_GEMM": "0"},
+@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"}, {"HFMI_EIG_UNB_MAX": "0"}, {"HFMI_EIG_UNB_MAX": "700"}, {"HFMI_XFER_PLAIN": "1"}, {"HFMI_EIG_GEMM": "0"}, {"HFMI_EIG_WY": "256"}, {"HFMI_XFER_D2H_ENGINE": "1"}, {"HFMI_EIG_FULL_UPDATE": "1"},
                                  {"HFMI_EIG_LARGE": "jacobi"}])
 def test_sym_eig_blocked_ab_knobs_give_the_same_spectrum(ctx, tmp_path, env):
     """The A/B switches of the whole-GPU solver (read once per process, hence a child interpreter each): full-column products only

@@ -114,3 +114,30 @@ def test_first_qr_pass_on_trust_equals_the_checked_path(ctx, rate, s):
         L.call("hfmi_tuning_set", b"qr_trust_first", 1)
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_fuzz_whole_gpu_eigensolver_sizes(ctx):
+    """20 random sizes n in [257, 3000] of the whole-GPU eigensolver (hfmi_eig_blocked.hip: panels above 2048 rows, one launch per column
+    below, divide and conquer, block reflectors), primes and n = 1 mod 64 included, three kinds of spectra, against numpy.linalg.eigh:
+    eigenvalues, orthonormality, residual."""
+    rng = np.random.default_rng(6006)
+    sizes = [257, 263, 449, 513, 577, 641, 1009, 1025, 1153, 1601, 2049, 2111, 2113, 2999] + [int(v) for v in rng.integers(257, 3001, 6)]
+    for it, n in enumerate(sizes):
+        kind = it % 3
+        if kind == 0:                              # Gram matrix of decaying snapshots (the POD's matrix)
+            X = rng.standard_normal((n, n // 3 + 5)) * np.exp(-0.02 * np.arange(n // 3 + 5))[None, :]
+            T = X @ X.T
+        elif kind == 1:                            # indefinite
+            S = rng.standard_normal((n, n))
+            T = S + S.T
+        else:                                      # clustered: eight-fold eigenvalues
+            Qm = np.linalg.qr(rng.standard_normal((n, n)))[0]
+            T = (Qm * np.repeat(np.arange(1.0, 2.0 + n // 8), 8)[:n]) @ Qm.T
+        T = 0.5 * (T + T.T)
+        nv = int(rng.choice([n, 17, 130]))
+        d, V = hf.sym_eig_small(T, nvec=nv)
+        w = np.linalg.eigvalsh(T)[::-1]
+        sc = np.abs(w).max()
+        assert np.abs(d - w).max() <= 4e-12 * sc, (n, kind, np.abs(d - w).max() / sc)
+        assert np.abs(V.T @ V - np.eye(nv)).max() <= 5e-12, (n, kind)
+        assert np.abs(T @ V - V * d[:nv]).max() <= 4e-12 * sc, (n, kind)

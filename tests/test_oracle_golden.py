@@ -139,3 +139,21 @@ def test_pod_from_data_with_320_snapshots_matches_reference(golden_dir, method, 
     np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-8)
     cosines = np.abs(np.einsum("ij,ij->j", phi[:, :6], M @ g["phi_" + tag][:, :6]))
     np.testing.assert_allclose(cosines, 1.0, atol=1e-8)
+
+
+def test_pod_from_data_with_8300_snapshots_matches_reference(golden_dir):
+    """More than 8192 snapshots, slowly decaying spectrum (tests/golden/make_pod_huge_golden.py: the reference's construct_subspace,
+    'hep', shifted, on 8300 x 600 integer-valued snapshots rebuilt from the stored seed): the oracle here (one la.eigh of 8300 x 8300,
+    about a minute), the device's exact n x n route in tests/test_gpu_eig_blocked.py."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_pod_huge_golden import snapshots
+    g = _load(golden_dir, "pod_from_data_8300.npz")
+    N, r = int(g["N"]), int(g["r"])
+    M = _csr(g, N)
+    u_data = snapshots(int(g["seed"]), int(g["n"]), N, int(g["K"]))
+    d, phi, Mphi, shift = hf_o.pod_from_data(u_data.copy(), M, r, shifted=True, method="hep")
+    np.testing.assert_allclose(shift, g["shift_hep_1"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(d, g["d_hep_1"], rtol=1e-8)
+    cosines = np.abs(np.einsum("ij,ij->j", phi[:, :r - 2], M @ g["phi_hep_1"][:, :r - 2]))
+    np.testing.assert_allclose(cosines, 1.0, atol=1e-8)
