@@ -245,6 +245,46 @@ def _cpu_topology():
     return {"threads": threads, "physical_cores": len(cores) or threads, "sockets": len(sockets) or 1}
 
 
+def _cpu_quota():
+    """CPUs' worth of run time the container's cgroup grants this process (cpu.max: quota / period), or None without a limit.
+    The GPU boxes of this pool report 256 hardware threads and an affinity mask of 256 with cpu.max = 1600000 100000: SIXTEEN CPUs.
+    A process that makes more threads runnable than that (numpy's default BLAS pool after any host matmul, busy-waiting helpers)
+    is throttled by the scheduler for the rest of the 100 ms period -- every thread of it, the one that feeds the GPU included:
+    the 15-80 ms stalls of rounds 4-5 (profiles/r06_eig_stall_diagnosis.txt)."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                return max(1, int(round(float(quota) / float(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            return max(1, int(round(q / per)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+_BLAS_LIMIT = None
+
+
+def limit_host_blas_to_cpu_quota():
+    """Keep numpy's BLAS pool within what the cgroup lets the process run (see _cpu_quota): process-wide, for the life of it."""
+    global _BLAS_LIMIT
+    quota = _cpu_quota()
+    if quota is None or _BLAS_LIMIT is not None:
+        return quota
+    try:
+        from threadpoolctl import threadpool_limits
+        _BLAS_LIMIT = threadpool_limits(limits=max(1, min(os.cpu_count() or 1, quota)))
+    except Exception:
+        pass
+    return quota
+
+
 def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
     """The reference's CPU path on the GPU box's host cores, on bounded samples scaled to the full workload (every
     scaling factor is stated).  Two legs, each at all threads and at one thread:
@@ -255,12 +295,17 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
       blas3           -- the best-effort CPU form: block applies as threaded GEMMs, Householder QR."""
     from threadpoolctl import threadpool_limits
     topo = _cpu_topology()
-    cores = topo["threads"]
+    quota = _cpu_quota()
+    # what the process can actually run at once: the hardware threads, or the cgroup's CPU quota where that is smaller (a BLAS pool
+    # beyond the quota is throttled by the scheduler, not faster)
+    cores = topo["threads"] if quota is None else max(1, min(topo["threads"], quota))
     # BLAS thread counts: every hardware thread (what a default numpy does), the physical cores of ONE socket (level-1/2
     # style loops like the reference's column-by-column MGS lose to their own fork/join and cross-socket traffic beyond that:
     # 0.81 s at 256 threads against 0.027 s at one, BENCH_r04), and one thread.  The best of each leg is reported.
     per_socket = max(1, min(cores, topo["physical_cores"] // max(1, topo["sockets"])))
     settings = [("threads_all", cores), ("threads_one_socket_cores", per_socket), ("threads_1", 1)]
+    if per_socket == cores:          # (a CPU quota below one socket's cores: the two settings coincide)
+        settings = [st for st in settings if st[0] != "threads_one_socket_cores"]
     quick = args.cpu_baseline == "quick"
     # quick (the extra workloads of a default run): the reference-style leg at one thread only (its level-1 loops are fastest
     # there on every box seen), the BLAS-3 leg at all threads and at one socket's cores
@@ -376,7 +421,7 @@ def cpu_baseline(args, wl, prior, Omega_host, r, N, hp_o, hf_o):
     t_comp = 2.0 * comp["apply"] * ref_scale["apply"] + (comp["mgs_reortho"] + comp["MvDSmatMult"]) * ref_scale["N"] + comp["eigh"]
     return {"value": best["value"], "unit": "GDoF*rank/s", "cores": thread_count[best_label], "kind": "port", "cpu_model": _cpu_model(),
             "threads": topo["threads"], "physical_cores": topo["physical_cores"], "sockets": topo["sockets"],
-            "thread_settings": thread_count, "best_setting": best_label,
+            "cgroup_cpu_quota": quota, "thread_settings": thread_count, "best_setting": best_label,
             "sample": "blas3 leg at %s = %d BLAS threads (the best of %s): %s" % (best_label, thread_count[best_label], ", ".join(thread_count), notes["blas3"]),
             "seconds_full_estimate": best["seconds_full_estimate"],
             # the reference-style leg: one entry per thread setting (each a run that a user can reproduce), the best of those, and --
@@ -560,8 +605,23 @@ def kernel_point_line(args):
                      "mfma_frac": fl / ts / (FP64_MFMA_PEAK_TFLOPS * 1e12), "bound": bound,
                      "frac": (fl / ts / (FP64_MFMA_PEAK_TFLOPS * 1e12)) if bound == "mfma" else by / ts / (HBM_PEAK_GBS * 1e9)})
         del X
+    # the same shapes against what THIS box delivers in THIS job: a read-only 16-byte stream and the MFMA loop on Gaussian operands.
+    # At the ridge (n = 48 ... 138) both are loaded at once: frac_of_measured = max(bytes / read rate, flops / MFMA rate) / time
+    measured = {}
+    try:
+        ctx = hf.Context.default()
+        measured.update(ctx.bench_hbm_read())
+        measured.update(ctx.bench_random_peaks())
+        for row in rows:
+            by, fl = 8.0 * (N * row["n"] + N * k + row["n"] * k), 2.0 * N * row["n"] * k
+            t_roof = max(by / (measured["hbm_read_gbs"] * 1e9), fl / (measured["mfma_f64_tflops_random_operands"] * 1e12))
+            row["frac_of_measured"] = t_roof / (row["ms"] * 1e-3)
+            row["bound_measured"] = "hbm" if by / (measured["hbm_read_gbs"] * 1e9) >= fl / (measured["mfma_f64_tflops_random_operands"] * 1e12) else "mfma"
+    except Exception as exc:
+        measured["error"] = str(exc)
     print(json.dumps({"kernel_point": {"N": N, "k": k, "rows": rows, "build_tag": hf.build_tag(),
-                                       "peaks": {"hbm_gbs": HBM_PEAK_GBS, "fp64_mfma_tflops": FP64_MFMA_PEAK_TFLOPS}}}), flush=True)
+                                       "peaks": {"hbm_gbs": HBM_PEAK_GBS, "fp64_mfma_tflops": FP64_MFMA_PEAK_TFLOPS},
+                                       "peaks_measured_in_job": measured}}), flush=True)
 
 
 def eig_large_line(args):
@@ -619,7 +679,7 @@ def _compact(line):
     out["phases_ms_per_step"] = line.get("phases_ms_per_step")
     cb = line.get("cpu_baseline")
     if cb:
-        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "kind", "cores", "threads", "physical_cores", "sockets",
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "kind", "cores", "threads", "physical_cores", "sockets", "cgroup_cpu_quota",
                                                        "best_setting", "seconds_full_estimate", "sample")}
         rs = cb.get("reference_style") or {}
         out["cpu_baseline"]["reference_style_best_single_setting_value"] = rs.get("best_single_setting_value")
@@ -649,9 +709,9 @@ def run_extras(args):
             ("shard64_rccl_1rank", ["--samples-total", "64", "--dist-single", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + q, 90),
             # the reference's DEFAULT active-subspace path (construct_input_subspace(prior_preconditioned=True), activeSubspaceProjector.py:400,
             # :447-450: doublePassG(A, prior.R, prior.Rsolver)): the 64-sample shard with B = R as CSR on the device and B^-1 = the host
-            # sparse-LU pool (one worker process per pair of probe vectors, at most the box's physical cores), pinned-slab overlap on
+            # sparse-LU pool (one worker process per probe vector, at most the box's physical cores and the cgroup's CPU quota), pinned-slab overlap on
             ("as_prior_shard64", ["--prior", "--samples-total", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--host-workers",
-                                  str(max(1, min(37, _cpu_topology()["physical_cores"])))] + q, 150)]
+                                  str(max(1, min(74, _cpu_topology()["physical_cores"], _cpu_quota() or 74)))] + q, 150)]
     extras, seconds = {}, {}
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
@@ -720,6 +780,7 @@ def spawn_and_report(args):
 
 def main():
     args = parse_args()
+    limit_host_blas_to_cpu_quota()
     if args.workload == "dipnet":
         return dipnet_line(args)
     if args.kernel_point:
@@ -951,6 +1012,7 @@ def solve_line(args, world, rank):
                                                              out["device_peaks_measured"]["mfma_f64_tflops_while_streaming"])
         # ... and against the same loop on Gaussian operands (the constant-operand loops above toggle almost no bits: their clock
         # is one the solve's data never sees under the power limit)
+        out["device_peaks_measured"].update(ctx.bench_hbm_read())
         out["device_peaks_measured"].update(ctx.bench_random_peaks())
         if "roofline" in out and out["roofline"]["bound"] == "mfma":
             pm = out["device_peaks_measured"]

@@ -105,6 +105,7 @@ SIGNATURES = {
     "hfmi_bench_peaks": [_P, _D, _D, _D],
     "hfmi_bench_loaded_peak": [_P, _D, _D],
     "hfmi_bench_random_peaks": [_P, _D, _D, _D],
+    "hfmi_bench_hbm_read": [_P, _D],
     "hfmi_bench_dgemm": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D, _D, _D, _D],
     "hfmi_profile_begin": [_P],
     "hfmi_profile_phases": [_P, _D],
@@ -327,6 +328,11 @@ class Context:
         call("hfmi_bench_dgemm", self.handle, M, N, K, int(ta), int(tb), int(reps), A.ctypes.data_as(_D), B.ctypes.data_as(_D),
              Cm.ctypes.data_as(_D) if want_c else None, C.byref(ms))
         return Cm, ms.value
+
+    def bench_hbm_read(self):
+        a = C.c_double(0)
+        call("hfmi_bench_hbm_read", self.handle, C.byref(a))
+        return {"hbm_read_gbs": a.value}
 
     def bench_random_peaks(self):
         """fp64 MFMA rate on Gaussian (full-mantissa) operands rotated through the registers, alone and beside the streaming copy."""

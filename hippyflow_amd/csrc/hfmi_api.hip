@@ -2110,6 +2110,11 @@ extern "C" int hfmi_bench_dgemm(hfmi_ctx* ctx, int M, int N, int K, int ta, int 
   HIP_TRY(hipSetDevice(ctx->device));
   return eig_dgemm_bench(ctx, M, N, K, ta, tb, reps, host_A, host_B, host_C, avg_ms);
 }
+extern "C" int hfmi_bench_hbm_read(hfmi_ctx* ctx, double* hbm_read_gbs) {
+  if (!ctx || !hbm_read_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_bench_read(ctx, hbm_read_gbs);
+}
 extern "C" int hfmi_bench_random_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* mfma_f64_tflops_while_streaming, double* hbm_copy_gbs) {
   if (!ctx || !mfma_f64_tflops || !mfma_f64_tflops_while_streaming || !hbm_copy_gbs) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));

@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256) void k_scale_apply(double* __restrict__ A, int
 // ------------------------------------------------------------------------------------------------ tridiagonalisation
 struct tri_args {
   int n, j, jj, p0, mode;       // mode bit 0: finalise W[:, jj - 1] (products of step j - 1); bit 1: form column j
-  int64_t ld;
+  int nr;                       // rows of a column that exist and are zero beyond n: n rounded up to 128
+  int64_t ld;                   // leading dimension: nr, or nr + 144 where nr is a power of two (see sym_eig_large)
   double* A;
   double* Vh;                   // reflectors, n x n (column j = v_j with explicit zeros and the unit entry)
   double* W;                    // panel W, n x EB_NB
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
   const int64_t ld = p.ld;
   const int rs = (j + 1) & ~63;
   const int nA = n - j - 1, nc = nA + 2 * jj;
-  const int npair = ((int)ld - rs) >> 1;
+  const int npair = (p.nr - rs) >> 1;
   auto column = [&](int q) -> const d2* {
     const double* colp;
     if (q < nA) colp = p.A + (size_t)(j + 1 + q) * ld;
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(512) void k_tri_b(tri_args p) {
 #pragma unroll
   for (int u = 0; u < CB; ++u) {
     const int r = rs + tid + 512 * u;
-    if (r < (int)ld) s_v[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : cb[u] * scl);
+    if (r < p.nr) s_v[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : cb[u] * scl);
   }
   if (blockIdx.x == 0 && tid == 0) {
     p.evec[j] = beta;
@@ -744,10 +745,51 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
   const int64_t ld = p.ld;
   const int rs2 = (j + 1) & ~(TS - 1);
+  const bool is_tile = (int)blockIdx.x < ntiles;
+  // ---- every load of this workgroup is requested before anything waits (round 6: the tile loads used to sit behind the wait
+  // for the partial norms -- two dependent memory round trips per workgroup, 4.85 TB/s where the bare tile pattern reads 6.25).
+  // The small loads go first: vmcnt retires in order, so waiting for them leaves the tile in flight.
   const double alpha0 = p.colbuf[j + 1];
-  double pnl = l < p.npn ? p.pn[l] : 0.0;
+  double pnv[CB / 8];
 #pragma unroll
-  for (int u = 1; u < CB / 8; ++u) pnl += l + 64 * u < p.npn ? p.pn[l + 64 * u] : 0.0;
+  for (int u = 0; u < CB / 8; ++u) pnv[u] = l + 64 * u < p.npn ? p.pn[l + 64 * u] : 0.0;
+  // tile (I, J), I >= J: blockIdx = I (I + 1) / 2 + J
+  int I = 0, J = 0;
+  if (is_tile) {
+    I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) ++I;
+    while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
+    J = blockIdx.x - I * (I + 1) / 2;
+  }
+  const int r0 = rs2 + TS * I, c0 = rs2 + TS * J;
+  // a panel column: x1[q] = V[:, q] . v  or  x2[q] = W[:, q] . v
+  const int q = is_tile ? 0 : (int)blockIdx.x - ntiles;
+  const int npair = (p.nr - rs2) >> 1;               // pairs of rows from rs2
+  const int per = (npair + 7) >> 3;                  // per wave (<= 512: at most 8 per lane)
+  // ONE straight-line load sequence for both kinds of workgroup (addresses selected, never a branch around a load: the waitcnt
+  // pass treats a join behind divergent loads as "everything may be in flight" and waited for the small loads before the big ones)
+  const double* colp = q < jj ? p.Vh + (size_t)(p.p0 + q) * ld : p.W + (size_t)(q - jj) * ld;
+  const d2* __restrict__ c2 = (const d2*)(colp + rs2);
+  const d2* __restrict__ b2 = (const d2*)(p.colbuf + rs2);
+  const double* __restrict__ Ab = p.A + (size_t)r0 + (size_t)c0 * ld;
+  // this thread's entry of column j for the tile's two row ranges (any valid address for the threads / workgroups without one)
+  const double cvec = p.colbuf[is_tile ? (tid < TS ? r0 + tid : c0 + (tid & (TS - 1))) : rs2];
+  d2 x[16];
+  unsigned okmask = 0xffffu;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int u8 = u & 7;
+    const int i = w * per + l + 64 * u8;
+    const bool ok = l + 64 * u8 < per && i < npair;
+    const int ic = min(i, npair - 1);
+    const d2* src = is_tile ? (const d2*)(Ab + (size_t)(w + 8 * u) * ld) + l : (u < 8 ? c2 + ic : b2 + ic);
+    x[u] = *src;
+    if (!is_tile && !ok) okmask &= ~(1u << u);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double pnl = pnv[0];
+#pragma unroll
+  for (int u = 1; u < CB / 8; ++u) pnl += pnv[u];
   const double xn2 = wave_sum(pnl);
   double tau = 0.0, beta = alpha0, scl = 0.0;
   if (xn2 > 1e-280) {
@@ -761,28 +803,15 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
     p.evec[j] = beta;
     p.tauv[j] = tau;
   }
-  if ((int)blockIdx.x >= ntiles) {
-    // ---- a panel column: x1[q] = V[:, q] . v  or  x2[q] = W[:, q] . v
-    const int q = blockIdx.x - ntiles;
-    const double* colp = q < jj ? p.Vh + (size_t)(p.p0 + q) * ld : p.W + (size_t)(q - jj) * ld;
-    const int npair = ((int)ld - rs2) >> 1;            // pairs of rows from rs2
-    const int per = (npair + 7) >> 3;                  // per wave (<= 512: at most 8 per lane)
-    const d2* __restrict__ c2 = (const d2*)(colp + rs2);
-    const d2* __restrict__ b2 = (const d2*)(p.colbuf + rs2);
-    d2 x[8], c[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = w * per + l + 64 * u;
-      const bool ok = l + 64 * u < per && i < npair;
-      x[u] = ok ? c2[i] : d2{0.0, 0.0};
-      c[u] = ok ? b2[i] : d2{0.0, 0.0};
-    }
+  if (!is_tile) {
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int r = rs2 + 2 * (w * per + l + 64 * u);
-      acc = fma(x[u].x, vrow(r, c[u].x), acc);
-      acc = fma(x[u].y, vrow(r + 1, c[u].y), acc);
+      if ((okmask >> u) & 1u) {
+        acc = fma(x[u].x, vrow(r, x[8 + u].x), acc);
+        acc = fma(x[u].y, vrow(r + 1, x[8 + u].y), acc);
+      }
     }
     acc = wave_sum(acc);
     if (l == 0) s_dot[w] = acc;
@@ -794,19 +823,8 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
     }
     return;
   }
-  // ---- tile (I, J), I >= J: blockIdx = I (I + 1) / 2 + J
-  int I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-  while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) ++I;
-  while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
-  const int J = blockIdx.x - I * (I + 1) / 2;
-  const int r0 = rs2 + TS * I, c0 = rs2 + TS * J;
-  // the wave's 16 columns first: nothing below waits for them until they are used
-  const double* __restrict__ Ab = p.A + (size_t)r0 + (size_t)c0 * ld;
-  d2 x[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) x[u] = ((const d2*)(Ab + (size_t)(w + 8 * u) * ld))[l];
-  if (tid < TS) s_vi[tid] = vrow(r0 + tid, p.colbuf[r0 + tid]);
-  else if (tid < 2 * TS) s_vj[tid - TS] = vrow(c0 + tid - TS, p.colbuf[c0 + tid - TS]);
+  if (tid < TS) s_vi[tid] = vrow(r0 + tid, cvec);
+  else if (tid < 2 * TS) s_vj[tid - TS] = vrow(c0 + tid - TS, cvec);
   __syncthreads();
   if (I == J && tid < TS) p.Vh[(size_t)(r0 + tid) + (size_t)j * ld] = s_vi[tid];      // column j of the reflector matrix (rows above rs2 are zero already)
   const double vi0 = s_vi[2 * l], vi1 = s_vi[2 * l + 1];
@@ -858,7 +876,7 @@ __global__ __launch_bounds__(512) void k_tri_u(tri_args p, const double* __restr
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j;
   const int64_t ld = p.ld;
   const int rs = j & ~63;
-  const int L = (int)ld - rs, npair = L >> 1;
+  const int L = p.nr - rs, npair = L >> 1;
   double* s_vp = s_dyn;
   double* s_w = s_dyn + L;
   double* s_vn = s_dyn + 2 * L;
@@ -903,7 +921,7 @@ __global__ __launch_bounds__(512) void k_tri_u(tri_args p, const double* __restr
   for (int u = 0; u < CB; ++u) {
     const int r = rs + tid + 512 * u;
     wv[u] = fma(tp, yv[u], alpha * vp[u]);
-    if (r < (int)ld) {
+    if (r < p.nr) {
       s_vp[r - rs] = vp[u];
       s_w[r - rs] = wv[u];
     }
@@ -932,7 +950,7 @@ __global__ __launch_bounds__(512) void k_tri_u(tri_args p, const double* __restr
 #pragma unroll
   for (int u = 0; u < CB; ++u) {
     const int r = rs + tid + 512 * u;
-    if (r < (int)ld) s_vn[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : c[u] * scl);
+    if (r < p.nr) s_vn[r - rs] = (r <= j || r >= n) ? 0.0 : (r == j + 1 ? 1.0 : c[u] * scl);
   }
   if (blockIdx.x == 0 && tid == 0) {
     p.dvec[j] = dj;
@@ -1522,7 +1540,13 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     return (v == 256 || v == 512) ? v : 0;
   }();
   const int WY = wy_env ? wy_env : (n >= 3072 ? 512 : 256);
-  const int64_t ld = round_up(n, 128);
+  // rows of a column: n rounded up to 128.  Leading dimension: the same, except where that is a power of two (n = 4096, 8192,
+  // 16384): consecutive columns of a 128 x 128 tile or of a wave's column set then sit a power of two apart and crowd the same
+  // HBM channels -- the tile pattern of the lower-triangle products read 6.25 TB/s at ld = 8192 and 6.9-7.0 at 8336 / 8720, 5.5
+  // against 6.0-6.2 at n = 4096 (scripts/tile_stride_probe.hip, profiles/r06_tile_stride_probe.txt); 144 = 9 cache lines
+  static const bool ld_pad = !env_flag("HFMI_EIG_NO_LD_PAD");
+  const int nr = (int)round_up(n, 128);
+  const int64_t ld = nr + ((ld_pad && nr >= 4096 && (nr & (nr - 1)) == 0) ? 144 : 0);
   const int npad = (int)round_up(n, WY), npanels = npad / NB, nblk = npad / WY;
   const size_t mat = (size_t)ld * npad;
   const size_t vlen = (size_t)npad + 128;
@@ -1632,6 +1656,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     ta.part = Qg;                        // free between the load and the merges: nb <= 64 partial vectors of ld doubles
     ta.nb = 0;
     ta.n = n;
+    ta.nr = nr;
     ta.ld = ld;
     ta.A = A;
     ta.Vh = Vh;
@@ -1649,12 +1674,12 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
     ta.npn = 0;
     bool prev_slots = false;             // the last column's products were left in slots by k_tri_bs
     if (n > 8192)      // v of the first columns is 128 KB (of 160)
-      HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nr * sizeof(double))));
     else if (n > 4096)      // v of the first columns is 64 KB: beyond what a kernel gets without asking
-      HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * sizeof(double))));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_tri_b<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nr * sizeof(double))));
     // the lower-triangle products serve trailing blocks of sym_min ... 8192 rows (64 slots of 128 rows, 2080 tiles); the first columns of a
     // larger matrix take the full-column products
-    auto uses_bs = [&](int j) { return n - j - 1 >= sym_min && ((int)ld - ((j + 1) & ~(TS - 1))) / TS <= 64; };
+    auto uses_bs = [&](int j) { return n - j - 1 >= sym_min && (nr - ((j + 1) & ~(TS - 1))) / TS <= 64; };
     static const int unb_max = [] {      // HFMI_EIG_UNB_MAX: trailing blocks of at most this many rows take one launch per column (0: never)
       const char* e = getenv("HFMI_EIG_UNB_MAX");
       const int v = e ? atoi(e) : 2048;
@@ -1689,11 +1714,11 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
         const int nc = (n - j - 1) + 2 * jj;
         const int gb = std::max(1, std::min(512, (nc + 7) / 8));
         const int rs0 = (j + 1) & ~63;
-        const size_t v_lds = (size_t)(ld - rs0) * sizeof(double);
+        const size_t v_lds = (size_t)(nr - rs0) * sizeof(double);
         if (uses_bs(j)) {
           // large trailing block: the lower triangle only (k_tri_bs); the next k_tri_a adds the partial vectors
           const int rs2 = (j + 1) & ~(TS - 1);
-          const int nb = ((int)ld - rs2) / TS, ntiles = nb * (nb + 1) / 2;
+          const int nb = (nr - rs2) / TS, ntiles = nb * (nb + 1) / 2;
           ta.nb = nb;
           if (n > 4096) hipLaunchKernelGGL(k_tri_bs<16>, dim3(ntiles + 2 * jj), dim3(512), 0, st, ta, ntiles);
           else hipLaunchKernelGGL(k_tri_bs<8>, dim3(ntiles + 2 * jj), dim3(512), 0, st, ta, ntiles);
@@ -1747,7 +1772,7 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
       double* yb[2] = {ybuf, colbuf};      // y of the last step / of this step (the panel kernels' colbuf is free here)
       for (int j = j_unb; j < n; ++j) {
         ta.j = j;
-        const int rs0 = j & ~63, L = (int)ld - rs0, nA = n - j - 1;
+        const int rs0 = j & ~63, L = nr - rs0, nA = n - j - 1;
         const int g = std::max(1, std::min(512, (nA + 7) / 8));
         const size_t lds = (size_t)3 * L * sizeof(double);
         const int has_prev = j > j_unb ? 1 : 0;

@@ -303,4 +303,5 @@ int eig_dgemm_bench(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, int reps
 // micro-benchmarks
 int launch_bench_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* fma_tflops, double* copy_gbs);
 int launch_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_tflops, double* copy_gbs);
+int launch_bench_read(hfmi_ctx* ctx, double* read_gbs);
 int launch_bench_random_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* mfma_tflops_streaming, double* copy_gbs);

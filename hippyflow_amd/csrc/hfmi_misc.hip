@@ -794,6 +794,37 @@ int launch_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_tflops, double* copy_gb
   return HFMI_OK;
 }
 
+// read-only stream: what a contraction that only READS its big operand can get from HBM (the copy above also writes)
+__global__ __launch_bounds__(256) void k_bench_read(const d2* __restrict__ src, double* out, int64_t n) {
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 * 8 + threadIdx.x; i + 7 * 256 < n; i += stride) {
+    d2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u].x + v[u].y;
+  }
+  if (s == 123.456) out[0] = s;
+}
+int launch_bench_read(hfmi_ctx* ctx, double* read_gbs) {
+  void* buf = nullptr;
+  const size_t bytes = (size_t)2 << 30;
+  HFMI_TRY(ctx_ws(ctx, WS_STAGE, bytes + 4096, &buf));
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int64_t n = (int64_t)(bytes / sizeof(d2));
+  double* out = (double*)((char*)buf + bytes);
+  float ms = 0.f;
+  hipLaunchKernelGGL(k_bench_read, dim3(cus * 8), dim3(256), 0, ctx->stream, (const d2*)buf, out, n);
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL(k_bench_read, dim3(cus * 8), dim3(256), 0, ctx->stream, (const d2*)buf, out, n);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *read_gbs = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
+  return HFMI_OK;
+}
+
 // fp64 MFMA rate on Gaussian operands: alone, and with the copy kernel streaming HBM beside it (the regime of the solve's big
 // contractions) -- the denominators bench.py reports as roofline.frac_of_in_job_random_operand_peak[_while_streaming]
 int launch_bench_random_peaks(hfmi_ctx* ctx, double* mfma_tflops, double* mfma_tflops_streaming, double* copy_gbs) {

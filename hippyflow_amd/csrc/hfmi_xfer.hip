@@ -20,9 +20,10 @@
 #include "hfmi_internal.h"
 
 namespace {
-constexpr size_t XF_CHUNK = (size_t)4 << 20;
-constexpr int XF_NBUF = 4;
-constexpr size_t XF_DIRECT = 2 * XF_CHUNK;      // below this the plain copy is as good
+constexpr size_t XF_CHUNK_MAX = (size_t)16 << 20;   // a ring slot: eight 2 MB pages, one per worker (see for_slices)
+constexpr size_t XF_CHUNK = XF_CHUNK_MAX;
+constexpr int XF_NBUF = 3;
+constexpr size_t XF_DIRECT = (size_t)8 << 20;   // below this the plain copy is as good
 
 struct pool {
   std::vector<std::thread> threads;
@@ -102,7 +103,7 @@ static int xfer_get(hfmi_ctx* ctx, xfer_state** out) {
     s->have_events = true;
     const char* e = getenv("HFMI_XFER_THREADS");
     int nt = e ? atoi(e) : 0;
-    if (nt <= 0) nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));     // (first-touch page faults of a fresh output array scale with the threads)
+    if (nt <= 0) nt = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4));
     s->nthreads = std::min(nt, 32);
     s->workers.start(s->nthreads);
   }
@@ -119,8 +120,23 @@ void xfer_destroy(hfmi_ctx* ctx) {
   ctx->xfer = nullptr;
 }
 
-// this thread's share [lo, hi) of a chunk of `len` bytes, in whole 4 KB pages except at the end
-static inline void slice_of(size_t len, int t, int T, size_t& lo, size_t& hi) {
+// Thread t's share of a chunk of `len` bytes that lands at host address `dst`: the pieces between consecutive 2 MB boundaries OF THE
+// DESTINATION, dealt round-robin.  A fresh numpy array is backed by transparent huge pages that are zero-filled on first touch,
+// one page per fault, by ONE thread while every other thread touching the same page waits: with 4 KB slices of a 4 MB chunk eight
+// threads queued on two page faults per chunk and the 512 MB output of n = 8192 took 24-27 ms (19 GB/s); with one huge page
+// per thread the faults run side by side.  Calls fn(offset, bytes) for every piece of thread t.
+template <class F>
+static inline void for_slices(const void* dst, size_t len, int t, int T, F fn) {
+  constexpr uintptr_t HP = (uintptr_t)2 << 20;
+  const uintptr_t a0 = (uintptr_t)dst, a1 = a0 + len;
+  uintptr_t piece = a0 & ~(HP - 1);
+  for (int k = 0; piece < a1; piece += HP, ++k) {
+    if (k % T != t) continue;
+    const uintptr_t lo = std::max(piece, a0), hi = std::min(piece + HP, a1);
+    if (hi > lo) fn((size_t)(lo - a0), (size_t)(hi - lo));
+  }
+}
+static inline void slice_of(size_t len, int t, int T, size_t& lo, size_t& hi) {      // (the upload ring: 4 KB pages, contiguous shares)
   const size_t pages = (len + 4095) / 4096, per = (pages + T - 1) / T;
   lo = std::min(len, (size_t)t * per * 4096);
   hi = std::min(len, (size_t)(t + 1) * per * 4096);
@@ -136,22 +152,31 @@ int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes) {
   }
   xfer_state* s = nullptr;
   HFMI_TRY(xfer_get(ctx, &s));
+  // chunk: an eighth of the transfer in whole 2 MB pages, 4 ... 16 MB (a 32 MB output still pipelines over 8 chunks)
+  const size_t XF_CHUNK = std::min(XF_CHUNK_MAX, std::max((size_t)4 << 20, ((bytes / 8) >> 21) << 21));
   const int nch = (int)((bytes + XF_CHUNK - 1) / XF_CHUNK), T = s->nthreads;
-  std::atomic<int> ready{0};
-  std::atomic<bool> abort_flag{false};
-  std::vector<std::atomic<int>> done(nch);
-  for (auto& d : done) d.store(0, std::memory_order_relaxed);
+  // hand-over between this thread and the workers through ONE mutex + condition variable: nobody spins (a spinning helper thread
+  // competes with the thread that feeds the GPU for the cores the process may use -- see DESIGN section 8 item 3)
+  std::mutex mu;
+  std::condition_variable cv;
+  int ready = 0;                    // chunks whose data is in the ring
+  bool abort_flag = false;
+  std::vector<int> done(nch, 0);    // workers that have moved chunk c out
   auto chunk_len = [&](int c) { return std::min(XF_CHUNK, bytes - (size_t)c * XF_CHUNK); };
   s->workers.launch([&, T](int t) {
     for (int c = 0; c < nch; ++c) {
-      while (ready.load(std::memory_order_acquire) <= c) {
-        if (abort_flag.load(std::memory_order_relaxed)) return;
-        std::this_thread::yield();
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ready > c || abort_flag; });
+        if (abort_flag) return;
       }
-      size_t lo, hi;
-      slice_of(chunk_len(c), t, T, lo, hi);
-      if (hi > lo) memcpy((char*)host + (size_t)c * XF_CHUNK + lo, s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK + lo, hi - lo);
-      done[c].fetch_add(1, std::memory_order_release);
+      char* dst = (char*)host + (size_t)c * XF_CHUNK;
+      const char* src = s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK_MAX;
+      for_slices(dst, chunk_len(c), t, T, [&](size_t off, size_t nb) { memcpy(dst + off, src + off, nb); });
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (++done[c] == T) cv.notify_all();
+      }
     }
   });
   hipError_t err = hipSuccess;
@@ -160,9 +185,9 @@ int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes) {
   auto issue = [&](int c) {
     const size_t len = chunk_len(c);
     if (engine || !aligned || (len & 15)) {
-      err = hipMemcpyAsync(s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK, (const char*)dev + (size_t)c * XF_CHUNK, len, hipMemcpyDeviceToHost, st);
+      err = hipMemcpyAsync(s->pin + (size_t)(c % XF_NBUF) * XF_CHUNK_MAX, (const char*)dev + (size_t)c * XF_CHUNK, len, hipMemcpyDeviceToHost, st);
     } else {
-      hipLaunchKernelGGL(k_xfer_out, dim3(128), dim3(256), 0, st, (xd2*)(s->pin_dev + (size_t)(c % XF_NBUF) * XF_CHUNK),
+      hipLaunchKernelGGL(k_xfer_out, dim3(128), dim3(256), 0, st, (xd2*)(s->pin_dev + (size_t)(c % XF_NBUF) * XF_CHUNK_MAX),
                          (const xd2*)((const char*)dev + (size_t)c * XF_CHUNK), len / 16);
       err = hipGetLastError();
     }
@@ -172,13 +197,19 @@ int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes) {
   for (int c = 0; c < nch && err == hipSuccess; ++c) {
     err = hipEventSynchronize(s->ev[c % XF_NBUF]);
     if (err != hipSuccess) break;
-    ready.store(c + 1, std::memory_order_release);
-    if (c + XF_NBUF < nch) {
-      while (done[c].load(std::memory_order_acquire) < T) std::this_thread::yield();       // the ring slot is free again
-      issue(c + XF_NBUF);
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      ready = c + 1;
+      cv.notify_all();
+      if (c + XF_NBUF < nch) cv.wait(lk, [&] { return done[c] == T; });       // the ring slot is free again
     }
+    if (c + XF_NBUF < nch) issue(c + XF_NBUF);
   }
-  if (err != hipSuccess) abort_flag.store(true);
+  if (err != hipSuccess) {
+    std::lock_guard<std::mutex> lk(mu);
+    abort_flag = true;
+    cv.notify_all();
+  }
   s->workers.wait();
   if (err != hipSuccess) {
     (void)hipStreamSynchronize(st);

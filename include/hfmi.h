@@ -306,6 +306,9 @@ int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, double* hbm_c
 /* the MFMA loop on full-mantissa Gaussian operands rotated through the registers every iteration -- alone, and beside the streaming
  * copy: the ceiling the contractions can reach on the solve's data under the power limit (SURVEY section 8d "fp64 MFMA
  * micro-benchmark run in the same job"; bench.py: roofline.frac_of_in_job_random_operand_peak[_while_streaming]) */
+/* read-only 16-byte stream over 2 GiB: the HBM rate a contraction that only reads its big operand can reach (the copy of
+ * hfmi_bench_peaks also writes); bench.py: roofline.frac_of_in_job_read_peak for the HBM-bound kernel-point shapes */
+int hfmi_bench_hbm_read(hfmi_ctx* ctx, double* hbm_read_gbs);
 int hfmi_bench_random_peaks(hfmi_ctx* ctx, double* mfma_f64_tflops, double* mfma_f64_tflops_while_streaming, double* hbm_copy_gbs);
 /* per-launch HIP-event timing over a region of ordinary calls (bench.py's roofline numbers come from the
  * timed region itself): between begin and end every tsgemm_tn / tsgemm_nn launch is bracketed by events on

@@ -19,6 +19,23 @@ def _steal():
         return 0
 
 
+def _cpu_budget():
+    """what the process may use, next to what the machine reports: affinity mask, cgroup quota"""
+    out = {"os.cpu_count": __import__("os").cpu_count(), "affinity": len(__import__("os").sched_getaffinity(0))}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            out[path] = open(path).read().strip()
+        except OSError:
+            pass
+    return out
+
+
+blas_threads = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--blas-threads=")]
+if blas_threads:      # the host BLAS pool (numpy's matmul that builds the test matrix) limited for the WHOLE script: its workers keep
+    from threadpoolctl import threadpool_limits      # spinning for a while after a product and compete with the thread that feeds the GPU
+    threadpool_limits(limits=blas_threads[0])
+if "--diag" in sys.argv:
+    print("cpu budget:", _cpu_budget(), "blas threads:", blas_threads or "default", flush=True)
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 1024, 2048, 4096]
 host = "--no-host" not in sys.argv
 rng = np.random.default_rng(0)
