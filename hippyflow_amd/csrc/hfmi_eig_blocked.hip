@@ -742,7 +742,9 @@ __global__ __launch_bounds__(512) void k_tri_bs(tri_args p, int ntiles) {
   __shared__ double s_vi[TS], s_vj[TS];
   __shared__ double s_pr[8][TS];
   __shared__ double s_dot[8];
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = p.n, j = p.j, jj = p.jj;
+  // (the wave index as a SCALAR: the 16 column addresses of a lane are then one lane offset + scalar strides instead of 16 address pairs
+  // in registers -- 108 -> fewer VGPRs, i.e. three resident workgroups per CU instead of two)
+  const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = p.n, j = p.j, jj = p.jj;
   const int64_t ld = p.ld;
   const int rs2 = (j + 1) & ~(TS - 1);
   const bool is_tile = (int)blockIdx.x < ntiles;
@@ -1533,13 +1535,14 @@ int sym_eig_large(hfmi_ctx* ctx, const double* host_T, int n, int sort_by_abs, d
   }
   const int NB = EB_NB;
   // width of a block reflector of the back-transformation: V^T Z is a WY x nv product over WY / 64 row tiles -- 512 columns from
-  // n = 3072 on keep 8 row tiles x nv / 128 column tiles of the pipelined kernel on the chip where 256 would leave half of it idle
+  // n = 2048 on keep 8 row tiles x nv / 128 column tiles of the pipelined kernel on the chip where 256 would leave half of it idle
+  // (back-transformation at n = 2048 / 4096: 1.9 -> 1.6 / 6.5 -> 4.7 ms; profiles/r06_eig_large.txt)
   static const int wy_env = [] {
     const char* e = getenv("HFMI_EIG_WY");
     const int v = e ? atoi(e) : 0;
     return (v == 256 || v == 512) ? v : 0;
   }();
-  const int WY = wy_env ? wy_env : (n >= 3072 ? 512 : 256);
+  const int WY = wy_env ? wy_env : (n >= 2048 ? 512 : 256);
   // rows of a column: n rounded up to 128.  Leading dimension: the same, except where that is a power of two (n = 4096, 8192,
   // 16384): consecutive columns of a 128 x 128 tile or of a wave's column set then sit a power of two apart and crowd the same
   // HBM channels -- the tile pattern of the lower-triangle products read 6.25 TB/s at ld = 8192 and 6.9-7.0 at 8336 / 8720, 5.5

@@ -152,8 +152,8 @@ int xfer_d2h(hfmi_ctx* ctx, void* host, const void* dev, size_t bytes) {
   }
   xfer_state* s = nullptr;
   HFMI_TRY(xfer_get(ctx, &s));
-  // chunk: an eighth of the transfer in whole 2 MB pages, 4 ... 16 MB (a 32 MB output still pipelines over 8 chunks)
-  const size_t XF_CHUNK = std::min(XF_CHUNK_MAX, std::max((size_t)4 << 20, ((bytes / 8) >> 21) << 21));
+  // chunk: an eighth of the transfer in whole 2 MB pages, 8 ... 16 MB (a 32 MB output: four chunks of four huge pages)
+  const size_t XF_CHUNK = std::min(XF_CHUNK_MAX, std::max((size_t)8 << 20, ((bytes / 8) >> 21) << 21));
   const int nch = (int)((bytes + XF_CHUNK - 1) / XF_CHUNK), T = s->nthreads;
   // hand-over between this thread and the workers through ONE mutex + condition variable: nobody spins (a spinning helper thread
   // competes with the thread that feeds the GPU for the cores the process may use -- see DESIGN section 8 item 3)

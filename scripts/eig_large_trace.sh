@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out; mkdir -p $out
 for n in $ns; do
   rm -rf /tmp/prof_el
-  ( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_el -- python3 scripts/eig_large_time.py $n --no-host > $out/${tag}_eig_large_n$n.txt 2> $out/${tag}_eig_large_n$n.err )
+  ( cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_el -- python3 scripts/eig_large_time.py $n --no-host --blas-threads=8 > $out/${tag}_eig_large_n$n.txt 2> $out/${tag}_eig_large_n$n.err )
   db=$(find /tmp/prof_el -name "*.db" | head -1)
   [ -n "$db" ] && python3 $R/profiles/summarize_rocpd.py $db > $out/${tag}_eig_large_n${n}_kernel_stats.csv
   echo "== n=$n"; cat $out/${tag}_eig_large_n$n.txt

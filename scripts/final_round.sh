@@ -33,9 +33,16 @@ timeout 600 python scripts/kernel_point.py > $out/${tag}_kernel_point.log 2>&1 &
 bash scripts/shard_profile.sh ${tag}_shard64 > $out/${tag}_shard64_timeline.txt 2>&1
 bash scripts/shard_profile.sh ${tag}_shard64_dist1 --samples-total 64 --dist-single > $out/${tag}_shard64_dist1_timeline.txt 2>&1
 bash scripts/eig_corner_trace.sh $tag 138 160 192 224 256 > $out/${tag}_eig_corner.txt 2>&1
-# the whole-GPU eigensolver beyond 256 (hfmi_eig_blocked.hip): wall times next to numpy.linalg.eigh with the phase split, then traces
-HFMI_EIG_LARGE_TIMING=1 timeout 900 python scripts/eig_large_time.py 300 512 1024 2048 4096 8192 > $out/${tag}_eig_large.txt 2>&1
+# the whole-GPU eigensolver beyond 256 (hfmi_eig_blocked.hip): wall times next to numpy.linalg.eigh with the phase split (host BLAS kept
+# inside the container's CPU quota: scripts/eig_stall_diagnosis.py says why), 20 back-to-back calls per size, traces, counters
+HFMI_EIG_LARGE_TIMING=1 timeout 900 python scripts/eig_large_time.py 300 512 1024 2048 4096 8192 --blas-threads=8 > $out/${tag}_eig_large.txt 2>&1
+timeout 600 python scripts/eig_large_time.py 1024 2048 4096 8192 --no-host --reps=20 --diag --blas-threads=8 > $out/${tag}_eig_large_20calls.txt 2>&1
+timeout 300 python scripts/eig_large_time.py 16384 --no-host --reps=2 --blas-threads=8 >> $out/${tag}_eig_large_20calls.txt 2>&1
+timeout 300 python scripts/eig_stall_diagnosis.py 2048 > $out/${tag}_eig_stall_diagnosis.txt 2>&1
+timeout 300 python scripts/dgemm_rate.py > $out/${tag}_dgemm_rate.txt 2>&1
+./hippyflow_amd/build/tile_stride_probe > $out/${tag}_tile_stride_probe.txt 2>&1
 bash scripts/eig_large_trace.sh $tag 512 1024 2048 4096 8192 > $out/${tag}_eig_large_trace.log 2>&1
+for n in 4096 8192; do bash scripts/pmc_eig.sh $tag $n > $out/${tag}_pmc_eig_n$n.txt 2>&1; done
 cd $R
 cat $out/${tag}_gputests.log
 ls $out | grep "^${tag}_" | wc -l

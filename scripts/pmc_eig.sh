@@ -1,0 +1,28 @@
+#!/bin/bash
+# Counter evidence for the whole-GPU eigensolver (VERDICT r5 "What's missing 4"): PMC passes over ONE solve of scripts/eig_large_time.py at
+# size n (one counter group per rocprofv3 run, the program directly after --): mean HBM bytes per launch of every kernel (FETCH_SIZE x2
+# gfx950 correction + WRITE_SIZE), MFMA busy, effective clock.   bash scripts/pmc_eig.sh <tag> <n>   -> gpurun_out/<tag>_pmc_eig_n<n>_summary.json
+tag=${1:-rXX}; n=${2:-4096}
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out; mkdir -p $out; rm -rf /tmp/pmc_eig; mkdir -p /tmp/pmc_eig
+i=0
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  ( cd $R && rocprofv3 --kernel-trace --output-format csv --pmc $grp -d /tmp/pmc_eig/run_$i -- python3 scripts/eig_large_time.py $n --no-host --reps=1 --blas-threads=8 > /dev/null 2>/tmp/pmc_eig/err_$i )
+  mkdir -p /tmp/pmc_eig/pmc_$i
+  f=$(find /tmp/pmc_eig/run_$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp $f /tmp/pmc_eig/pmc_$i/counter_collection.csv || { echo "group $i failed"; tail -3 /tmp/pmc_eig/err_$i; }
+done
+python3 $R/profiles/summarize_pmc.py /tmp/pmc_eig 0.0005 > $out/${tag}_pmc_eig_n${n}_summary.json
+python3 - <<PY
+import json
+d = json.load(open("$out/${tag}_pmc_eig_n${n}_summary.json"))
+n = $n
+print("n = %d: kernel, launches sampled (two solves: warm-up + one), mean duration, mean HBM bytes per launch (read x2-corrected + write), clock, MFMA busy" % n)
+for k, v in sorted(d.items(), key=lambda kv: -kv[1]["avg_duration_ms"] * kv[1]["launches_sampled"]):
+    if v["avg_duration_ms"] * v["launches_sampled"] < 0.2: continue
+    print("%-46s n=%6d  %9.2f us  read %10.3f MB  write %9.3f MB  clock %.2f GHz  mfma busy %.3f" % (
+        k.replace("void (anonymous namespace)::", "")[:46], v["launches_sampled"], 1e3 * v["avg_duration_ms"], v.get("hbm_read_bytes", 0) / 1e6,
+        v.get("hbm_write_bytes", 0) / 1e6, v.get("effective_clock_ghz", 0), v.get("mfma_pipe_util", 0)))
+PY

@@ -358,7 +358,7 @@ def _knob_child(n, extra, out):
     return np.load(out)
 
 
-@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"}, {"HFMI_EIG_UNB_MAX": "0"}, {"HFMI_EIG_UNB_MAX": "700"}, {"HFMI_XFER_PLAIN": "1"}, {"HFMI_EIG_GEMM": "0"}, {"HFMI_EIG_WY": "256"}, {"HFMI_XFER_D2H_ENGINE": "1"}, {"HFMI_EIG_FULL_UPDATE": "1"}, {"HFMI_EIG_NO_LD_PAD": "1"},
+@pytest.mark.parametrize("env", [{"HFMI_EIG_SYM_MIN": "0"}, {"HFMI_EIG_SYM_MIN": "1024"}, {"HFMI_EIG_LEAF": "64"}, {"HFMI_EIG_TRI_UNR": "4"}, {"HFMI_EIG_UNB_MAX": "0"}, {"HFMI_EIG_UNB_MAX": "700"}, {"HFMI_XFER_PLAIN": "1"}, {"HFMI_EIG_GEMM": "0"}, {"HFMI_EIG_WY": "256"}, {"HFMI_EIG_WY": "512"}, {"HFMI_XFER_D2H_ENGINE": "1"}, {"HFMI_EIG_FULL_UPDATE": "1"}, {"HFMI_EIG_NO_LD_PAD": "1"},
                                  {"HFMI_EIG_LARGE": "jacobi"}])
 def test_sym_eig_blocked_ab_knobs_give_the_same_spectrum(ctx, tmp_path, env):
     """The A/B switches of the whole-GPU solver (read once per process, hence a child interpreter each): full-column products only
