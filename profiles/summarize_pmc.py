@@ -28,7 +28,8 @@ def main(root, min_ms=1.0):
         for did, c in agg.items():
             if dur[did] < min_ms * 1e6:
                 continue
-            key = names[did].split("(")[0]
+            # kernel name without its argument list; kernels of an anonymous namespace demangle to "void (anonymous namespace)::k<...>(...)"
+            key = names[did].replace("(anonymous namespace)::", "").split("(")[0]
             for cn, v in c.items():
                 per_kernel[key][cn].append(v)
             per_kernel[key]["duration_ns"].append(dur[did])

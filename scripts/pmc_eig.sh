@@ -19,7 +19,7 @@ python3 - <<PY
 import json
 d = json.load(open("$out/${tag}_pmc_eig_n${n}_summary.json"))
 n = $n
-print("n = %d: kernel, launches sampled (two solves: warm-up + one), mean duration, mean HBM bytes per launch (read x2-corrected + write), clock, MFMA busy" % n)
+print("n = %d: kernel, launches sampled (three counter passes x [warm-up + one solve]), mean duration, mean HBM bytes per launch (read x2-corrected + write), clock, MFMA busy" % n)
 for k, v in sorted(d.items(), key=lambda kv: -kv[1]["avg_duration_ms"] * kv[1]["launches_sampled"]):
     if v["avg_duration_ms"] * v["launches_sampled"] < 0.2: continue
     print("%-46s n=%6d  %9.2f us  read %10.3f MB  write %9.3f MB  clock %.2f GHz  mfma busy %.3f" % (

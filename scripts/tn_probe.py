@@ -1,5 +1,5 @@
 """Where does tsgemm_tn's matrix-pipe idle time go?  probe 1: streamed operand re-reads one address (cache hits),
-probe 2: no stage loads / LDS stores / barriers, 3: both.  (Round 2 also measured 4 = staging kept, barrier dropped and 8 = LDS stores before the last iteration, profiles/r02e_tn_probe.txt; the two extra branches made the <2,9> instance spill 40 bytes per lane, so they were taken out again.)  Results are garbage in probe modes; timing only."""
+probe 2: no stage loads / LDS stores / barriers, 3: both.  (Round 2 also measured 4 = staging kept, barrier dropped and 8 = LDS stores before the last iteration, profiles/archive/r02e_tn_probe.txt; the two extra branches made the <2,9> instance spill 40 bytes per lane, so they were taken out again.)  Results are garbage in probe modes; timing only."""
 import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, '.')

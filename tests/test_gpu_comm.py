@@ -120,7 +120,7 @@ def test_row_panel_reduction_is_bit_identical_and_overlapped():
         d, U = hf.doublePass(A, Omega, r, s=1)
         ctx.profile_end()
         out[panels] = (d, U.to_dense(), ctx.profile_phases())
-    # the opt-in half-height last round (one more, smaller, panel; profiles/r04i_halve_last_ab.txt): still the same bits
+    # the opt-in half-height last round (one more, smaller, panel; profiles/archive/r04i_halve_last_ab.txt): still the same bits
     L.call("hfmi_tuning_set", b"comm_panels", 4)
     L.call("hfmi_tuning_set", b"nn_halve_last", 1)
     ctx.profile_begin()

@@ -658,3 +658,17 @@ def test_projectors_take_streamed_samples(ctx):
         out.append((d, V.to_dense() if hasattr(V, "to_dense") else np.asarray(V)))
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+def test_in_job_roofline_denominators_are_plausible(ctx):
+    """The micro-benchmarks bench.py quotes its fractions against (denominators measured in the same job): the MFMA loop on
+    constant operands, the same loop on Gaussian operands rotated through the registers (round 6: the ceiling the contractions can
+    reach on the solve's data), the copy and the read-only stream -- each inside the range a working MI355X can produce, and ordered
+    the way the power limit orders them (full-mantissa operands never faster than constants by more than noise)."""
+    p = ctx.bench_peaks()
+    r = ctx.bench_random_peaks()
+    h = ctx.bench_hbm_read()
+    assert 40.0 < p["mfma_f64_tflops"] < 82.0 and 2000.0 < p["hbm_copy_gbs"] < 8000.0
+    assert 40.0 < r["mfma_f64_tflops_random_operands"] < 82.0 and 30.0 < r["mfma_f64_tflops_random_operands_while_streaming"] < 82.0
+    assert r["mfma_f64_tflops_random_operands"] <= 1.05 * p["mfma_f64_tflops"]
+    assert 2500.0 < h["hbm_read_gbs"] < 8000.0
