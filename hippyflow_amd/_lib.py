@@ -106,6 +106,7 @@ SIGNATURES = {
     "hfmi_bench_loaded_peak": [_P, _D, _D],
     "hfmi_bench_random_peaks": [_P, _D, _D, _D],
     "hfmi_bench_hbm_read": [_P, _D],
+    "hfmi_dense_matmul": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D, _D, _D],
     "hfmi_bench_dgemm": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D, _D, _D, _D],
     "hfmi_profile_begin": [_P],
     "hfmi_profile_phases": [_P, _D],
@@ -315,6 +316,18 @@ class Context:
         a, b = C.c_double(0), C.c_double(0)
         call("hfmi_bench_loaded_peak", self.handle, C.byref(a), C.byref(b))
         return {"mfma_f64_tflops_while_streaming": a.value, "hbm_copy_gbs_beside_it": b.value}
+
+    def dense_matmul(self, A, B, ta=False, tb=False):
+        """op(A) op(B) of two dense host matrices on the device (the eigensolver's general fp64 MFMA product)."""
+        import numpy as np
+        A, B = np.asfortranarray(A, dtype=np.float64), np.asfortranarray(B, dtype=np.float64)
+        M, K = (A.shape[1], A.shape[0]) if ta else A.shape
+        N = B.shape[0] if tb else B.shape[1]
+        if (B.shape[1] if tb else B.shape[0]) != K:
+            raise ValueError("dense_matmul: inner dimensions differ")
+        Cm = np.empty((M, N), order="F")
+        call("hfmi_dense_matmul", self.handle, M, N, K, int(ta), int(tb), A.ctypes.data_as(_D), B.ctypes.data_as(_D), Cm.ctypes.data_as(_D))
+        return Cm
 
     def bench_dgemm(self, A, B, ta=False, tb=False, reps=5, want_c=True):
         """C = op(A) op(B) through the eigensolver's general fp64 MFMA product; returns (C or None, average ms of one launch)."""

@@ -2103,6 +2103,15 @@ extern "C" int hfmi_bench_loaded_peak(hfmi_ctx* ctx, double* mfma_f64_tflops, do
   HIP_TRY(hipSetDevice(ctx->device));
   return launch_bench_loaded_peak(ctx, mfma_f64_tflops, hbm_copy_gbs);
 }
+// C (M x N) = op(A) op(B) on the device's general fp64 MFMA product (hfmi_eig_blocked.hip), host column-major operands in and out: the two
+// N x N x N congruence products of the deterministic POD's N-dimensional route (PODProjector.py:812-833 when there are more snapshots
+// than the n x n eigensolver takes and the state dimension is the small one: S = B^T (X^T X) B with M = B B^T)
+extern "C" int hfmi_dense_matmul(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, const double* host_A, const double* host_B, double* host_C) {
+  if (!ctx || !host_A || !host_B || !host_C) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");
+  if (M < 1 || N < 1 || K < 1) HFMI_FAIL(HFMI_ERR_INVALID, "dense_matmul: bad shape %d x %d x %d", M, N, K);
+  HIP_TRY(hipSetDevice(ctx->device));
+  return eig_dgemm_bench(ctx, M, N, K, ta, tb, 0, host_A, host_B, host_C, nullptr);
+}
 extern "C" int hfmi_bench_dgemm(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, int reps, const double* host_A, const double* host_B,
                                 double* host_C, double* avg_ms) {
   if (!ctx || !host_A || !host_B) HFMI_FAIL(HFMI_ERR_INVALID, "null argument");

@@ -32,7 +32,7 @@ from .multivector import ingest_stream, MatMvMult, MultiVector, mv_to_dense
 from .operators import (CsrOperator, CsrPCGSolver, DeviceOperator, HostCallbackOperator, MassPreconditionedCovarianceOperator,
                         MeanJJTfromDataOperator, MeanJTJfromDataOperator, ObservableJacobian, SeriallySampledJacobianOperator,
                         SnapshotGramOperator, Solver2Operator, as_device_operator)
-from .randomized import doublePass, doublePassG, parRandom
+from .randomized import doublePass, doublePassG, parRandom, sym_eig_small
 
 
 class ParameterList(object):
@@ -955,8 +955,8 @@ class PODProjectorFromData:
     RANDOMIZED_OVERSAMPLING = 40
 
     def _randomized(self, u_data, u_rank, oversampling=None, passes=None):
-        """More than 16384 snapshots (the n x n eigensolve on the device stops there; the reference's :812-833 takes any n): the
-        same modes from the N-dimensional form of the problem, (1/n) M X X^T M phi = lambda M phi with phi^T M phi = 1, by the
+        """More than 16384 snapshots AND a state dimension beyond 16384 (neither the n x n nor the N x N problem fits the exact
+        eigensolver; the reference's :812-833 takes any n): the same modes from the N-dimensional form of the problem, (1/n) M X X^T M phi = lambda M phi with phi^T M phi = 1, by the
         randomized double pass this library is built around (``doublePassG`` with B = M, B^-1 = the device mass solve) with
         ``oversampling`` = 40 extra probe columns and ``passes`` = 3 applications of the operator per side.
 
@@ -986,6 +986,32 @@ class PODProjectorFromData:
         Mop.matMvMult(phi_mv, Mphi_mv)
         return d, phi_mv.to_dense(), Mphi_mv.to_dense()
 
+    def _state_dimension_route(self, u_data, u_rank):
+        """More snapshots than the n x n eigensolver takes, but a state dimension N it does take (the usual large case: the POD of an
+        OUTPUT of a few hundred or thousand observables over a training set of tens of thousands, dataGenerator.py:278-279): the same
+        eigenpairs, exactly, from the N-dimensional form.  With M = B B^T (B = Q_M diag(sqrt(lambda_M)) from the eigendecomposition of
+        the mass matrix) and phi = B^-T y the pencil (1/n) M X^T X M phi = lambda M phi becomes the symmetric N x N problem
+        (B^T (X^T X) B) y = n lambda y, phi^T M phi = y^T y = 1.  Every product and both eigensolves run on the device:
+        X^T X = ``dot_mv`` of the N columns of the snapshot matrix, the two N x N x N congruence products = ``hfmi_dense_matmul``."""
+        n, N = u_data.shape
+        Xt = MultiVector.from_vectors(np.ascontiguousarray(u_data.T), ctx=self.ctx)     # N vectors of length n: the columns of u_data
+        XtX = Xt.dot_mv(Xt)
+        lam_M, Q = sym_eig_small(self.M_csr.toarray(), ctx=self.ctx)
+        if not lam_M[-1] > 0.0:
+            raise ValueError("PODProjectorFromData: the output mass matrix is not positive definite (smallest eigenvalue %.3e)" % lam_M[-1])
+        root = np.sqrt(lam_M)
+        B = Q * root[None, :]
+        S = self.ctx.dense_matmul(B, self.ctx.dense_matmul(XtX, B), ta=True)
+        mu, Y = sym_eig_small(0.5 * (S + S.T), ctx=self.ctx, nvec=u_rank)
+        phi = self.ctx.dense_matmul(Q / root[None, :], np.ascontiguousarray(Y[:, :u_rank]))
+        phi_mv = MultiVector.from_dense(np.ascontiguousarray(phi), ctx=self.ctx)
+        Mphi_mv = MultiVector(phi_mv)
+        Mop = CsrOperator(self.M_csr, ctx=self.ctx)
+        Mop.matMvMult(phi_mv, Mphi_mv)
+        norms = np.sqrt(np.diag(phi_mv.dot_mv(Mphi_mv)))                 # weighted_l2_norm_vector, :829 (1 to rounding here)
+        phi = phi / norms[None, :]
+        return mu[:u_rank] / n, phi, Mphi_mv.to_dense() / norms[None, :]
+
     def construct_subspace(self, u_data, u_rank, shifted=True, method='hep', verify=False):
         n_data, dim_u = u_data.shape
         assert u_rank <= n_data, "number of samples needs to be greater than rank of projector"
@@ -994,8 +1020,10 @@ class PODProjectorFromData:
             u_data = u_data - u_shift
         else:
             u_shift = np.zeros(u_data.shape[1])
-        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > self.EXACT_MAX_SNAPSHOTS:
-            d, phi, Mphi = self._randomized(u_data, u_rank)
+        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > self.EXACT_MAX_SNAPSHOTS and dim_u <= self.EXACT_MAX_SNAPSHOTS:
+            d, phi, Mphi = self._state_dimension_route(u_data, u_rank)                  # exact: N x N instead of n x n
+        elif method in ('hep', 'ghep', 'inverse_ghep') and n_data > self.EXACT_MAX_SNAPSHOTS:
+            d, phi, Mphi = self._randomized(u_data, u_rank)                               # both n and N beyond the exact solver
         elif method in ('hep', 'ghep', 'inverse_ghep'):
             X = MultiVector.from_vectors(u_data, ctx=self.ctx)        # one snapshot per vector
             Mop = CsrOperator(self.M_csr, ctx=self.ctx)

@@ -293,6 +293,10 @@ int hfmi_double_pass_g(hfmi_op* A, hfmi_op* B, hfmi_op* Binv, const hfmi_block* 
 int hfmi_bench_tsgemm_tn(const hfmi_block* A, const hfmi_block* B, int nsplit, int reps, double* host_C,
                          double* avg_ms);
 int hfmi_bench_tsgemm_nn(const hfmi_block* A, const double* host_S, hfmi_block* Y, int reps, double* avg_ms);
+/* C (M x N) = op(A) op(B), column-major host operands with their natural leading dimensions (A: ta ? K x M : M x K; B: tb ? N x K : K x N),
+ * on the general fp64 MFMA product of the eigensolver: the N x N x N congruence products of the deterministic POD's N-dimensional route
+ * (la.eigh of PODProjector.py:812-833 reformulated in the state dimension when the snapshots outnumber it: hippyflow_amd/projectors.py) */
+int hfmi_dense_matmul(hfmi_ctx* ctx, int M, int N, int K, int ta, int tb, const double* host_A, const double* host_B, double* host_C);
 /* the general fp64 MFMA product inside the whole-GPU eigensolver (trailing rank-2k updates, Q S of the merges, block reflectors of
  * the back-transformation; la.eigh(G), PODProjector.py:812-833): C (M x N) = op(A) op(B), column-major host operands with their
  * natural leading dimensions, average kernel time of `reps` launches; host_C may be null */

@@ -322,22 +322,49 @@ def test_pod_from_data_8300_snapshots_is_the_exact_gram_route(ctx):
     assert np.abs(phi.T @ Mphi - np.eye(r)).max() < 1e-9
 
 
-def test_pod_from_data_randomized_fallback_tolerance(ctx):
-    """Beyond 16384 snapshots (both the n x n and, for a large state space, the N x N problem are out of the exact solver's reach) the
-    modes come from the randomized double pass on the N-dimensional generalized problem, k = r + 40 probe columns, 3 passes, WITH A
-    STATED TOLERANCE: relative eigenvalue error of mode i <= (lambda_{k+1} / lambda_i)^5 (PODProjectorFromData._randomized).  Checked on
-    a SLOWLY decaying spectrum (0.95^i per singular value): N = 600 here, so the exact answer is the dense generalized
-    eigenproblem of M H M / n against M."""
-    import scipy.linalg as sla
+def _slow_decay_snapshots(n, nx, ny, K, seed):
     from hippyflow_amd import workloads
-    rng = np.random.default_rng(17)
-    n, nx, ny, r = 16500, 30, 20, 12
+    rng = np.random.default_rng(seed)
     N = nx * ny
     M = workloads.grid_mass_matrix(nx, ny)
-    K = 200
     W0, _ = np.linalg.qr(rng.standard_normal((N, K)))
-    u_data = (rng.standard_normal((n, K)) * 0.95 ** np.arange(K)) @ W0.T
+    return (rng.standard_normal((n, K)) * 0.95 ** np.arange(K)) @ W0.T, M
+
+
+def test_pod_from_data_beyond_16384_snapshots_is_exact_in_the_state_dimension(ctx):
+    """More snapshots than the n x n eigensolver takes, a state dimension it does take (the POD of an output over a large training set,
+    dataGenerator.py:278-279): the N-dimensional route -- M = B B^T from the device eigendecomposition of the mass matrix, S = B^T (X^T X) B
+    by two device products, one more device eigensolve -- gives the reference's eigenpairs EXACTLY (no warning, nothing randomized):
+    16500 snapshots of a slowly decaying spectrum against the dense generalized eigenproblem of M H M / n and M."""
+    import warnings
+    import scipy.linalg as sla
+    n, r = 16500, 12
+    u_data, M = _slow_decay_snapshots(n, 30, 20, 200, 17)
     pod = hf.PODProjectorFromData(M_output=M)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=True, method="hep")
+    Md = M.toarray()
+    Xc = u_data - u_data.mean(axis=0)
+    lam, vec = sla.eigh(Md @ (Xc.T @ Xc / n) @ Md, Md)
+    lam, vec = lam[::-1], vec[:, ::-1]
+    np.testing.assert_allclose(d, lam[:r], rtol=1e-10)
+    cos = np.abs(np.einsum("ij,ij->j", phi, Md @ vec[:, :r]))
+    np.testing.assert_allclose(cos[:r - 2], 1.0, atol=1e-8)
+    assert np.abs(phi.T @ Mphi - np.eye(r)).max() < 1e-10 and np.abs(Md @ phi - Mphi).max() < 1e-10 * np.abs(Mphi).max()
+    np.testing.assert_allclose(shift, u_data.mean(axis=0), atol=1e-13)
+
+
+def test_pod_from_data_randomized_fallback_tolerance(ctx):
+    """Both the number of snapshots and the state dimension beyond the exact solver: the modes come from the randomized double pass on the
+    N-dimensional generalized problem, k = r + 40 probe columns, 3 passes, WITH A STATED TOLERANCE: relative eigenvalue error of mode i
+    <= (lambda_{k+1} / lambda_i)^5 (PODProjectorFromData._randomized).  Checked on a SLOWLY decaying spectrum (0.95^i per singular value)
+    with the exact routes switched off through the class limit (a genuine case needs a 16385 x 16385 dense reference solve)."""
+    import scipy.linalg as sla
+    n, r = 3000, 12
+    u_data, M = _slow_decay_snapshots(n, 30, 20, 200, 18)
+    pod = hf.PODProjectorFromData(M_output=M)
+    pod.EXACT_MAX_SNAPSHOTS = 256                        # instance attribute: this projector only
     with pytest.warns(UserWarning, match="randomized double pass"):
         d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=False, method="hep")
     Md = M.toarray()
