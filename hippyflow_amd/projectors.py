@@ -994,6 +994,8 @@ class PODProjectorFromData:
         (B^T (X^T X) B) y = n lambda y, phi^T M phi = y^T y = 1.  Every product and both eigensolves run on the device:
         X^T X = ``dot_mv`` of the N columns of the snapshot matrix, the two N x N x N congruence products = ``hfmi_dense_matmul``."""
         n, N = u_data.shape
+        if u_rank > N:
+            raise ValueError("PODProjectorFromData: rank %d exceeds the state dimension %d (the snapshots span at most that many modes)" % (u_rank, N))
         Xt = MultiVector.from_vectors(np.ascontiguousarray(u_data.T), ctx=self.ctx)     # N vectors of length n: the columns of u_data
         XtX = Xt.dot_mv(Xt)
         lam_M, Q = sym_eig_small(self.M_csr.toarray(), ctx=self.ctx)
