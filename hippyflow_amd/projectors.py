@@ -951,6 +951,7 @@ class PODProjectorFromData:
         self.ctx = ctx or L.Context.default()
 
     EXACT_MAX_SNAPSHOTS = 16384          # HFMI_EIG_MAXN: the largest n x n eigensolve on the device
+    prefer_state_dimension = True        # N x N form of the pencil when the state dimension is at most half the number of snapshots
     RANDOMIZED_PASSES = 3                # power passes of the fallback beyond it
     RANDOMIZED_OVERSAMPLING = 40
 
@@ -998,9 +999,12 @@ class PODProjectorFromData:
             raise ValueError("PODProjectorFromData: rank %d exceeds the state dimension %d (the snapshots span at most that many modes)" % (u_rank, N))
         Xt = MultiVector.from_vectors(np.ascontiguousarray(u_data.T), ctx=self.ctx)     # N vectors of length n: the columns of u_data
         XtX = Xt.dot_mv(Xt)
-        lam_M, Q = sym_eig_small(self.M_csr.toarray(), ctx=self.ctx)
-        if not lam_M[-1] > 0.0:
-            raise ValueError("PODProjectorFromData: the output mass matrix is not positive definite (smallest eigenvalue %.3e)" % lam_M[-1])
+        if getattr(self, "_mass_factor", None) is None:          # M = Q diag(lam_M) Q^T, once per projector (the mass matrix is fixed)
+            lam_M, Q = sym_eig_small(self.M_csr.toarray(), ctx=self.ctx)
+            if not lam_M[-1] > 0.0:
+                raise ValueError("PODProjectorFromData: the output mass matrix is not positive definite (smallest eigenvalue %.3e)" % lam_M[-1])
+            self._mass_factor = (lam_M, Q)
+        lam_M, Q = self._mass_factor
         root = np.sqrt(lam_M)
         B = Q * root[None, :]
         S = self.ctx.dense_matmul(B, self.ctx.dense_matmul(XtX, B), ta=True)
@@ -1022,7 +1026,12 @@ class PODProjectorFromData:
             u_data = u_data - u_shift
         else:
             u_shift = np.zeros(u_data.shape[1])
-        if method in ('hep', 'ghep', 'inverse_ghep') and n_data > self.EXACT_MAX_SNAPSHOTS and dim_u <= self.EXACT_MAX_SNAPSHOTS:
+        # the same pencil in whichever of its two exact forms is the smaller problem: n x n (the reference's la.eigh(G)) or N x N
+        # (the state dimension: the POD of an output of a few hundred observables over thousands of samples is 8300 x 600 -> a 600 x 600
+        # problem, 15 ms instead of 270).  ``prefer_state_dimension = False`` keeps the n x n form whenever it fits.
+        small_state = dim_u <= self.EXACT_MAX_SNAPSHOTS and u_rank <= dim_u and (
+            n_data > self.EXACT_MAX_SNAPSHOTS or (self.prefer_state_dimension and 2 * dim_u <= n_data))
+        if method in ('hep', 'ghep', 'inverse_ghep') and small_state:
             d, phi, Mphi = self._state_dimension_route(u_data, u_rank)                  # exact: N x N instead of n x n
         elif method in ('hep', 'ghep', 'inverse_ghep') and n_data > self.EXACT_MAX_SNAPSHOTS:
             d, phi, Mphi = self._randomized(u_data, u_rank)                               # both n and N beyond the exact solver

@@ -192,7 +192,10 @@ for n in (4096, 8192):
             P("| `%s` | %s | %.1f | %.1f |" % (re.sub(r"^_ZN12_GLOBAL__N_1\d+|^_Z\d+", "", r["Name"].replace(".kd", ""))[:48], r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
 for name, title in (("dgemm_rate.txt", "General fp64 MFMA product of the eigensolver (`scripts/dgemm_rate.py`)"), ("tile_stride_probe.txt", "Tile-stride probe (`scripts/tile_stride_probe.hip`): the access patterns of `k_tri_bs` / `k_tri_b` alone, by leading dimension"),
                     ("eig_stall_diagnosis.txt", "Stall diagnosis (`scripts/eig_stall_diagnosis.py`): 30 calls at n = 2048 with a host matmul between calls"),
-                    ("tn_tile_ab.txt", "The taller-tile experiment on `k_tsgemm_tn` (`scripts/tn_tile_ab.sh`; config 4, same box, interleaved)")):
+                    ("tn_tile_ab.txt", "The taller-tile experiment on `k_tsgemm_tn` (`scripts/tn_tile_ab.sh`; config 4, same box, interleaved)"),
+                    ("pod_routes_time.txt", "The deterministic POD in its two exact forms (`scripts/pod_routes_time.py`): n x n Gram problem vs N x N state-dimension form"),
+                    ("sync_price_probe.txt", "What one device-wide dependency costs (`scripts/sync_price_probe.hip`)"),
+                    ("eig_tuning_ab.txt", "Threshold A/B of the eigensolver (`HFMI_EIG_SYM_MIN`, `HFMI_EIG_UNB_MAX`; defaults 3072 / 2048)")):
     t = text(name)
     if t:
         P("\n### %s -- `profiles/%s_%s`\n" % (title, tag, name))

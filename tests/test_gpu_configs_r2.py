@@ -310,6 +310,7 @@ def test_pod_from_data_8300_snapshots_is_the_exact_gram_route(ctx):
     W0, _ = np.linalg.qr(rng.standard_normal((N, 30)))
     u_data = (rng.standard_normal((n, 30)) * np.exp(-0.3 * np.arange(30))) @ W0.T + 0.25
     pod = hf.PODProjectorFromData(M_output=M)
+    pod.prefer_state_dimension = False                   # the n x n form (the default here would be the 600 x 600 one)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=True, method="hep")

@@ -277,8 +277,9 @@ def test_pod_from_data_320_snapshots_matches_the_reference(ctx, golden_dir, meth
     assert np.linalg.norm(M @ phi - Mphi) / np.linalg.norm(Mphi) < 1e-8           # :170-174
 
 
+@pytest.mark.parametrize("state_dimension_form", [False, True])
 @pytest.mark.parametrize("shifted", [True, False])
-def test_pod_from_data_8300_snapshots_matches_the_reference(ctx, golden_dir, shifted):
+def test_pod_from_data_8300_snapshots_matches_the_reference(ctx, golden_dir, shifted, state_dimension_form):
     """MORE THAN 8192 snapshots with a slowly decaying spectrum (0.95^k per singular value, rank 150 + noise floor): the reference's
     exact la.eigh(G) (PODProjector.py:812-833; dataGenerator.py:278-279 hands it the whole training set) against the device's exact
     n x n route (hfmi_block_gram_eig up to 16384) -- tests/golden/pod_from_data_8300.npz holds the REFERENCE's outputs, the snapshot
@@ -294,9 +295,13 @@ def test_pod_from_data_8300_snapshots_matches_the_reference(ctx, golden_dir, shi
     N, r = int(g["N"]), int(g["r"])
     M = sp.csr_matrix((g["M_data"], g["M_indices"], g["M_indptr"]), shape=(N, N))
     u_data = snapshots(int(g["seed"]), int(g["n"]), N, int(g["K"]))
+    pod = hf.PODProjectorFromData(None, M)
+    # both exact forms of the pencil against the reference's outputs: the n x n Gram problem through the whole-GPU eigensolver
+    # (8300 > 8192: the size round 5 could not take), and the 600 x 600 state-dimension form the projector picks by default here
+    pod.prefer_state_dimension = state_dimension_form
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        d, phi, Mphi, shift = hf.PODProjectorFromData(None, M).construct_subspace(u_data.copy(), r, shifted=shifted, method="hep")
+        d, phi, Mphi, shift = pod.construct_subspace(u_data.copy(), r, shifted=shifted, method="hep")
     tag = "hep_%d" % int(shifted)
     np.testing.assert_allclose(shift, g["shift_" + tag], atol=1e-13)
     np.testing.assert_allclose(d, g["d_" + tag], rtol=1e-8)
