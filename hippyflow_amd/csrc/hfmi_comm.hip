@@ -423,6 +423,15 @@ static int p2p_ensure_stage(hfmi_comm* c, size_t bytes) {
       // (an export retried on some ranks only), so it stays out of it -- the allocation is merely up to 6 MB larger than this
       c->stage_bytes = want + ((size_t)(4 * gen) << 21);
       exp_err = hipIpcGetMemHandle(&me.handle, c->stage);
+      {      // test hook: HFMI_P2P_INJECT_EXPORT_FAIL=<rank> makes the FIRST export of that rank fail once (the retry path above runs on
+             // one rank only: tests/test_gpu_comm.py checks that the ranks still agree on when the buffers have to grow)
+        static const char* inj = getenv("HFMI_P2P_INJECT_EXPORT_FAIL");
+        static bool injected = false;
+        if (inj && !injected && atoi(inj) == c->rank && exp_err == hipSuccess) {
+          injected = true;
+          exp_err = hipErrorInvalidValue;
+        }
+      }
       if (exp_err == hipSuccess) break;
       (void)hipGetLastError();
       (void)hipFree(c->stage);

@@ -6,6 +6,9 @@
   panels  a Gram-form fused solve with at least two rounds of row tiles, so that the rank reduction runs panel by panel on
           the auxiliary stream across REAL peers; the result with 4 panels must equal the result with one all-reduce bit for
           bit, on every rank.
+  grow    block all-reduces of GROWING sizes (1, 3, 3.9, 9 MB per rank) while HFMI_P2P_INJECT_EXPORT_FAIL makes one rank retry the export
+          of its first staging buffer (its allocation is then 2 MB larger than its peers'): every rank must still take the same decision
+          about when the buffers grow -- each reduction complete and correct on every rank, no time-out.
   soak    200 block all-reduces in a row (alternating sum / avg, two block sizes) of the same rank-specific inputs: every
           repetition must give the bits of the first one, on every rank (fixed summation order of the p2p reduction)."""
 import json
@@ -48,6 +51,23 @@ def main():
         with open(os.path.join(outdir, "late_rank%d.json" % rank), "w") as f:
             json.dump(res, f)
         os._exit(0)                                  # the communicator is unusable: no barrier, no orderly close
+    if mode == "grow":
+        sums = []
+        for nrows in (13001, 39001, 51001, 118001):           # x 10 columns x 8 bytes: 1.0, 3.1, 4.1, 9.4 MB
+            X = hf.MultiVector(nrows, 10, ctx=ctx)
+            _ParRandom(70).normal(1.0, X)                     # the same block on every rank ...
+            ref = X.to_dense() * float(sum(r + 1 for r in range(world)))
+            X.scale(float(rank + 1))                          # ... scaled by rank + 1: the sum is known
+            coll.allReduce(X, "sum")
+            got = X.to_dense()
+            sums.append(float(np.abs(got - ref).max() / np.abs(ref).max()))
+        res["max_rel_err"] = sums
+        res["describe"] = coll.describe()
+        with open(os.path.join(outdir, "grow_rank%d.json" % rank), "w") as f:
+            json.dump(res, f)
+        coll.barrier()
+        coll.close()
+        return
     if mode == "panels":
         # per rank m = 16 x 100 rows of J: too many for the LDS-resident product (the hook lives in the tiled one), and N gives it
         # at least two rounds of row tiles whatever tile height the plan picks

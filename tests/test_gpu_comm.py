@@ -185,3 +185,21 @@ def test_p2p_reduction_is_bit_identical_over_200_repetitions(tmp_path):
         assert r["transport"] == "p2p" and r["p2p_sync"] == "stream" and r["reps"] == 200
         assert r["same"], r["mismatches"]
         assert r["digests"] == rs[0]["digests"] and len(r["digests"]) == 4
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (4, 2)])
+def test_staging_buffers_grow_in_step_when_one_rank_retried_its_export(tmp_path, world, bad_rank):
+    """Advisor (round 5, medium): a rank whose hipIpcGetMemHandle is retried allocates a larger staging buffer than its peers; if it kept
+    THAT size as its capacity, a later collective between the agreed size and its own would send it past the growth step its peers
+    enter (a hang until the time-out, or stores into a buffer being freed).  The capacity every rank compares with is the agreed size:
+    all-reduces of growing sizes with the first export of ONE rank failing (injected), all complete and exact on every rank.  (With the
+    old rule -- a build whose only difference is `stage_bytes = actual` -- this test fails exactly as predicted: rank 1 skips the growth
+    step of the second collective and both ranks end in the 60 s time-out, profiles/r06_p2p_capacity_ab.txt.)"""
+    import json
+    from hippyflow_amd.launch import spawn_ranks
+    env = dict(os.environ, HFMI_COMM_TIMEOUT_S="60", HFMI_P2P_SYNC="stream", HFMI_P2P_INJECT_EXPORT_FAIL=str(bad_rank))
+    assert spawn_ranks([WORKER2, str(tmp_path), "grow"], world, env=env, timeout=600) == 0
+    for r in range(world):
+        d = json.load(open(os.path.join(str(tmp_path), "grow_rank%d.json" % r)))
+        assert d["transport"] == "p2p" and max(d["max_rel_err"]) < 1e-14, d
+
