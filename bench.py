@@ -245,13 +245,13 @@ def _cpu_topology():
     return {"threads": threads, "physical_cores": len(cores) or threads, "sockets": len(sockets) or 1}
 
 
-def _cpu_quota():
+def _cpu_quota(cpu_max_path="/sys/fs/cgroup/cpu.max", v1_dir="/sys/fs/cgroup/cpu"):
     """CPUs' worth of run time the container's cgroup grants this process (cpu.max: quota / period), or None without a limit.
     The GPU boxes of this pool report 256 hardware threads and an affinity mask of 256 with cpu.max = 1600000 100000: SIXTEEN CPUs.
     A process that makes more threads runnable than that (numpy's default BLAS pool after any host matmul, busy-waiting helpers)
     is throttled by the scheduler for the rest of the 100 ms period -- every thread of it, the one that feeds the GPU included:
     the 15-80 ms stalls of rounds 4-5 (profiles/r06_eig_stall_diagnosis.txt)."""
-    for path in ("/sys/fs/cgroup/cpu.max",):
+    for path in (cpu_max_path,):
         try:
             quota, period = open(path).read().split()[:2]
             if quota != "max":
@@ -259,8 +259,8 @@ def _cpu_quota():
         except (OSError, ValueError):
             pass
     try:
-        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        q = int(open(os.path.join(v1_dir, "cpu.cfs_quota_us")).read())
+        per = int(open(os.path.join(v1_dir, "cpu.cfs_period_us")).read())
         if q > 0 and per > 0:
             return max(1, int(round(q / per)))
     except (OSError, ValueError):

@@ -60,3 +60,23 @@ def test_cpu_topology_is_sane():
     t = bench._cpu_topology()
     assert t["threads"] >= 1 and 1 <= t["physical_cores"] <= max(t["threads"], t["physical_cores"]) and t["sockets"] >= 1
     assert t["physical_cores"] >= t["sockets"]
+
+
+def test_cpu_quota_of_the_container_is_read_from_the_cgroup(tmp_path):
+    """bench.py keeps the host BLAS pool inside what the cgroup lets the process run: cgroup v2 `cpu.max`
+    ("quota period" or "max period"), cgroup v1 cfs files, nothing at all."""
+    f = tmp_path / "cpu.max"
+    f.write_text("1600000 100000\n")
+    assert bench._cpu_quota(str(f), str(tmp_path / "none")) == 16
+    f.write_text("max 100000\n")
+    assert bench._cpu_quota(str(f), str(tmp_path / "none")) is None
+    f.write_text("50000 100000\n")
+    assert bench._cpu_quota(str(f), str(tmp_path / "none")) == 1                  # half a CPU still means one thread
+    v1 = tmp_path / "v1"
+    v1.mkdir()
+    (v1 / "cpu.cfs_quota_us").write_text("800000\n")
+    (v1 / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench._cpu_quota(str(tmp_path / "missing"), str(v1)) == 8
+    (v1 / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench._cpu_quota(str(tmp_path / "missing"), str(v1)) is None
+
